@@ -1,0 +1,189 @@
+"""Benchmark of the message-passing hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W            (single GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one propagate (collect + distribute) over BASELINE.json config 4: the synthetic
+wide-clique junction tree (256 cliques of width 20, cardinality 2, 2^20-entry float32
+potentials, 10 variables shared per edge, balanced binary tree), potentials resident in HBM
+(generated on the device by jtp_fill_synthetic).  With N > 1 the tree is cut into subtrees
+(junctiontree_amd/partition.py), one process per GPU, separator messages exchanged by RCCL
+send/recv at the cuts; total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.  `value` = algorithmic clique-potential GB/s of the whole
+job (SURVEY.md 8d definition of algorithmic bytes), `messages_per_sec` beside it.
+`roofline` is for the dominant kernel, timed with hipEvent pairs around every launch on the
+plan's own stream during the timed steps.  `cpu_baseline` times the numpy restatement of the
+reference's einsum sequence (oracle/jt_oracle.py: beliefs_refshaped) on one host core over a
+bounded sample of the same workload; it is a checker/baseline, never the measured path.
+
+torch is imported only for the rendezvous (gloo barrier / all-reduce of the timings) and only
+AFTER libjtprop.so is loaded, so the HIP runtime in the process is the one libjtprop links.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "junction-tree_amd"))
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md "Chip-level parameters": 8.0 TB/s spec
+
+
+def cpu_baseline(width, sep, card, n_sample, seed):
+    """Reference-shaped numpy path on one core over a smaller tree of the same clique shape."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import jt_oracle as oracle
+    from junctiontree_amd import synthetic
+    spec = synthetic.wide_binary_tree(n_cliques=n_sample, width=width, sep=sep, card=card, seed=seed)
+    pots = synthetic.potentials_for(spec, seed=1, dtype=np.float32)
+    t0 = time.perf_counter()
+    c0 = time.process_time()
+    oracle.beliefs_refshaped(spec["tree"], pots, spec["node_vars"])
+    wall = time.perf_counter() - t0
+    cpu = time.process_time() - c0
+    ab = synthetic.algorithmic_bytes(spec, 4)
+    return {
+        "value": ab["total"] / wall / 1e9, "unit": "GB/s",
+        "messages_per_sec": ab["messages"] / wall,
+        "cores": 1, "kind": "port",
+        "sample": "%d-clique balanced binary tree, same clique shape (width %d, card %d, %d shared); "
+                  "one propagate, %.1f s wall, cpu/wall %.2f" % (n_sample, width, card, sep, wall, cpu / max(wall, 1e-9)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cliques", type=int, default=256)
+    ap.add_argument("--width", type=int, default=20)
+    ap.add_argument("--sep", type=int, default=10)
+    ap.add_argument("--card", type=int, default=2)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--cpu-sample", type=int, default=63, help="cliques in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="no hipEvent pairs in the timed region")
+    ap.add_argument("--block-log2", type=int, default=0)
+    ap.add_argument("--lds-budget", type=int, default=0)
+    ap.add_argument("--layout-policy", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import ctypes as C
+    from junctiontree_amd import _capi, engine, partition, synthetic
+    lib = _capi.lib()                               # loads libjtprop.so (and its HIP runtime) first
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist            # rendezvous only (CPU, gloo)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        uid = [bytes(128)]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            _capi.check(lib.jtp_comm_unique_id(buf))
+            uid = [buf.raw]
+        dist.broadcast_object_list(uid, src=0)
+        _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid[0]), local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    spec = synthetic.wide_binary_tree(n_cliques=args.cliques, width=args.width, sep=args.sep,
+                                      card=args.card, seed=0)
+    itemsize = 4 if args.dtype == "f32" else 8
+    alg = synthetic.algorithmic_bytes(spec, itemsize)
+    n = spec["n_cliques"]
+    owner = partition.subtree_owners(spec["parent"], [1.0] * n, world)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=args.dtype,
+                       device=local_rank, n_ranks=world, rank=rank, owner=owner,
+                       block_log2=args.block_log2, lds_budget=args.lds_budget,
+                       layout_policy=args.layout_policy)
+    plan.fill_synthetic(1, spec["scales"])
+
+    for _ in range(args.warmup):
+        plan.propagate(sync=False)
+    plan.sync()
+    if not args.no_profile:
+        plan.set_profiling(args.steps)
+    barrier()
+    plan.sync()                                      # hipStreamSynchronize on the plan's stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.propagate(sync=False)
+    plan.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stats = plan.stats()
+    z = plan.z() if plan.owns(plan.root) else None
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        gbps = alg["total"] * args.steps / elapsed / 1e9
+        out = {
+            "metric": "clique-potential GB/s (algorithmic bytes per propagate / time; messages/sec alongside), "
+                      "synthetic width-%d tree" % args.width,
+            "value": gbps, "unit": "GB/s",
+            "messages_per_sec": alg["messages"] * args.steps / elapsed,
+            "read_GBps": alg["read"] * args.steps / elapsed / 1e9,
+            "frac_of_hbm_roofline": gbps / (HBM_PEAK_GBPS * world),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[3]: %d cliques, width %d, cardinality %d (2^%d-entry %s "
+                            "potentials), %d shared variables per edge, balanced binary tree"
+                            % (n, args.width, args.card, args.width, args.dtype, args.sep),
+                "algorithmic_bytes_per_step": alg["total"], "messages_per_step": alg["messages"],
+                "parallelism": "1 GPU" if world == 1 else "subtree-sharded x%d, RCCL send/recv at cuts" % world,
+                "launches_per_step": stats["n_launches"], "Z": z,
+            },
+        }
+        if not args.no_profile and stats["kernels"]:
+            name, k = max(stats["kernels"].items(), key=lambda kv: kv[1]["ms"])
+            per_launch_bytes = k["bytes"] / k["launches"]
+            per_launch_ms = k["ms"] / k["launches"]
+            achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "launches_per_step": k["launches"], "avg_launch_ms": per_launch_ms,
+                "algorithmic_bytes_per_launch": per_launch_bytes,
+                "rank0_kernels": {kn: {"ms_per_step": kv["ms"], "launches": kv["launches"],
+                                       "GBps": kv["bytes"] / max(kv["ms"], 1e-12) / 1e6}
+                                  for kn, kv in stats["kernels"].items()},
+                "collect_ms": stats["collect_ms"], "distribute_ms": stats["distribute_ms"],
+            }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.width, args.sep, args.card, args.cpu_sample, 0)
+        print(json.dumps(out), flush=True)
+
+    plan.close()
+    if dist is not None:
+        barrier()
+        lib.jtp_comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

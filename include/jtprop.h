@@ -1,0 +1,163 @@
+/* jtprop.h - C ABI of libjtprop.so, the MI355X (gfx950) sum-product engine that replaces
+ * the message-passing hot path of jluttine/junction-tree.
+ *
+ * Boundary: the reference's per-call seam is
+ *     SumProduct(einsum).einsum(...)                 junctiontree/sum_product.py:22-43
+ * which is one host round trip per einsum and too fine for a GPU.  The device boundary is
+ * therefore `compute_beliefs` granularity - whole junction tree in, all beliefs out:
+ *     compute_beliefs(tree, potentials, clique_vars)  junctiontree/computation.py:37-246
+ *     JunctionTree.propagate(xs)                      junctiontree/junctiontree.py:297-331
+ * Each entry point below names the reference lines it stands in for.
+ *
+ * Conventions: plain C, no exceptions across the boundary.  Every function returning int
+ * returns JTP_OK (0) or a negative JTP_E* code; jtp_last_error() then holds a message
+ * (thread local).  Host arrays are C-order in the node's own variable order exactly as the
+ * reference passes numpy arrays (README.md:22-41).  A plan is not thread safe; distinct
+ * plans are independent.  All device work of a plan runs on the plan's own HIP stream.
+ */
+#ifndef JTPROP_H
+#define JTPROP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JTP_OK 0
+#define JTP_EINVAL (-1)     /* bad argument / malformed tree (Python: ValueError)        */
+#define JTP_EHIP (-2)       /* HIP runtime error, or no GPU (Python: RuntimeError)      */
+#define JTP_ECOMM (-3)      /* RCCL error                                               */
+#define JTP_ENOMEM (-4)     /* device or host allocation failed                         */
+#define JTP_EUNSUPPORTED (-5) /* structure outside engine limits (e.g. table > 2^31)    */
+
+#define JTP_F32 0           /* clique tables stored as float  (messages are always f64) */
+#define JTP_F64 1           /* clique tables stored as double                           */
+
+#define JTP_PLAN_ONLY 1u    /* jtp_tree_desc.flags: plan on the host only, touch no GPU  */
+
+typedef struct jtp_plan jtp_plan;
+
+/* Structure of one junction tree.  Mirrors the reference's data model
+ * (junctiontree/junctiontree.py:141-189, 283-291; README.md:50-77): a node list that is the
+ * concatenation of maximal cliques (nodes 0..n_cliques-1) and separators (nodes
+ * n_cliques..n_nodes-1), each node a list of variables, plus the tree given here in flat
+ * parent form instead of the nested list (the Python layer flattens it). */
+typedef struct jtp_tree_desc {
+    int32_t struct_size;            /* sizeof(jtp_tree_desc), for ABI versioning             */
+    int32_t n_vars;                 /* number of distinct variables                          */
+    const int32_t *var_card;        /* [n_vars] cardinality of each variable (>= 1)          */
+    int32_t n_cliques;              /* number of maximal cliques (>= 1)                      */
+    int32_t n_nodes;                /* n_cliques + number of separators (= 2*n_cliques - 1)  */
+    const int32_t *node_var_off;    /* [n_nodes+1] CSR offsets into node_var_ids             */
+    const int32_t *node_var_ids;    /* variable ids of each node in its host axis order      */
+    const int32_t *parent_clique;   /* [n_cliques] parent clique, -1 for the root            */
+    const int32_t *parent_sep;      /* [n_cliques] node index of the separator to the parent */
+    int32_t dtype;                  /* JTP_F32 or JTP_F64                                    */
+    int32_t device;                 /* HIP device ordinal used by this process               */
+    int32_t n_batch;                /* independent evidence sets sharing the structure (>=1) */
+    int32_t n_ranks;                /* processes sharing the tree (1 = single GPU)           */
+    int32_t rank;                   /* this process                                          */
+    const int32_t *clique_owner;    /* [n_cliques] owning rank, or NULL (all rank 0)         */
+    uint32_t flags;                 /* JTP_PLAN_ONLY                                         */
+    int32_t lds_budget;             /* bytes of LDS per workgroup the planner may use, 0=default */
+    int32_t block_log2;             /* log2 of target elements per workgroup, 0 = automatic  */
+    int32_t layout_policy;          /* 0 = default heuristic, 1 = keep host axis order       */
+} jtp_tree_desc;
+
+/* Counters of the last jtp_propagate (device time needs jtp_set_profiling(plan, 1)). */
+typedef struct jtp_stats {
+    int32_t struct_size;
+    int32_t n_launches;             /* kernel launches per propagate                         */
+    int32_t n_messages;             /* directed tree edges processed = 2*(n_cliques-1)       */
+    int32_t n_tasks;
+    double  algorithmic_bytes;      /* SURVEY.md 8d definition, this rank's share            */
+    double  collect_ms;             /* device time of the collect phase (profiling on)       */
+    double  distribute_ms;          /* device time of the distribute phase                   */
+    double  kernel_ms[32];          /* device time per kernel variant, mean per propagate    */
+    double  kernel_bytes[32];       /* algorithmic bytes processed per kernel variant        */
+    int32_t kernel_launches[32];    /* launches per kernel variant                           */
+    int32_t pad;
+} jtp_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* Compile a tree into a device plan: variable->bit layout of every table, level schedule
+ * of collect (computation.py:47-96) and distribute (:140-224), message buffers, kernel task
+ * tables, and (n_ranks > 1) the separator exchange schedule.  Replaces the per-call label
+ * bookkeeping of sum_product.py:22-43 and the recursion of computation.py:227-243. */
+int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out);
+void jtp_plan_destroy(jtp_plan *plan);
+
+/* JSON description of the plan (layouts, tasks, launches, exchange schedule).  The string is
+ * owned by the plan and valid until the plan is destroyed.  Used by tests and DESIGN.md. */
+const char *jtp_plan_describe(jtp_plan *plan);
+
+/* ---- data in -------------------------------------------------------------------------- */
+
+/* Upload the potential of clique `node` (0 <= node < n_cliques) for evidence set `batch`.
+ * `host` is a C-order array over the node's variables; `shape[i]` is the actual length of
+ * axis i: the variable's cardinality, or 1 to broadcast along it (numpy semantics the
+ * reference relies on, junctiontree.py:52-61).  `host_dtype` is JTP_F32 or JTP_F64.
+ * Stands in for `np.copy(p)` of computation.py:245.  Separator potentials are never
+ * uploaded: the reference overwrites them before use. */
+int jtp_set_potential(jtp_plan *plan, int32_t batch, int32_t node, const void *host,
+                      const int64_t *shape, int32_t host_dtype);
+
+/* Fill every clique potential on the device with the counter-based synthetic values of
+ * junctiontree_amd/synthetic.py: psi[i] = (0.5 + u(seed, node, i)) * scale[node], i the
+ * C-order host index.  For benchmarks (no host transfer). */
+int jtp_fill_synthetic(jtp_plan *plan, int32_t batch, uint64_t seed, const double *scale);
+
+/* ---- compute -------------------------------------------------------------------------- */
+
+/* Collect then distribute for evidence sets [batch_begin, batch_end): the body of
+ * compute_beliefs (computation.py:227-243).  Asynchronous; pair with jtp_sync. */
+int jtp_propagate(jtp_plan *plan, int32_t batch_begin, int32_t batch_end);
+int jtp_sync(jtp_plan *plan);
+
+/* ---- data out ------------------------------------------------------------------------- */
+
+/* Belief of `node` (clique: psi * all incoming messages, computation.py:216-224;
+ * separator: up * down, computation.py:210), written to `host` in the node's host axis
+ * order at full cardinalities, as `host_dtype`.  Unnormalised, sums to Z. */
+int jtp_get_belief(jtp_plan *plan, int32_t batch, int32_t node, void *host, int32_t host_dtype);
+
+/* Marginal of clique `clique`'s belief onto `out_vars` (a subset of its variables, in the
+ * requested order), as doubles: CliqueGraph.marginalize for one factor
+ * (junctiontree.py:264-274). */
+int jtp_get_marginal(jtp_plan *plan, int32_t batch, int32_t clique, const int32_t *out_vars,
+                     int32_t n_out, double *host);
+
+/* Z = sum of the root belief (the value the reference computes and drops,
+ * computation.py:90-96). */
+int jtp_get_z(jtp_plan *plan, int32_t batch, double *z);
+
+/* ---- instrumentation ------------------------------------------------------------------ */
+
+/* hipEvent pair around every launch of the next `keep` propagates (ring; 0 switches it off).
+ * jtp_get_stats then reports per-variant device time as the mean per propagate. */
+int jtp_set_profiling(jtp_plan *plan, int32_t keep);
+int jtp_get_stats(jtp_plan *plan, jtp_stats *stats);
+/* Name of kernel variant i as it appears in rocprofv3 traces, or NULL past the last one. */
+const char *jtp_kernel_name(int32_t variant);
+
+/* ---- multi-GPU: one process per GPU, RCCL point-to-point at subtree cuts --------------- */
+
+/* Rank 0 creates a 128-byte RCCL unique id and hands it to the other ranks out of band. */
+int jtp_comm_unique_id(void *id128);
+/* Collective: every rank calls it once before creating plans with n_ranks > 1. */
+int jtp_comm_init(int32_t rank, int32_t n_ranks, const void *id128, int32_t device);
+int jtp_comm_destroy(void);
+
+/* ---- misc ----------------------------------------------------------------------------- */
+
+int jtp_device_count(int32_t *count);
+const char *jtp_last_error(void);
+const char *jtp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JTPROP_H */

@@ -1,0 +1,644 @@
+// C ABI of libjtprop.so (declared in include/jtprop.h): device memory, launch schedule,
+// RCCL point-to-point exchange at subtree cuts, host<->device layout conversion.
+// Plain HIP runtime + RCCL; no PyTorch, no Triton.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "jtp_kernels.hip.h"
+#include "jtp_plan.h"
+
+// ------------------------------------------------------------------------------------------ errors
+
+static thread_local std::string g_err;
+
+static int set_err(int code, const char *fmt, ...) {
+    char buf[768];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return set_err(JTP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ RCCL (lazy)
+
+namespace rccl {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclFloat64 = 8 };
+typedef int (*GetUniqueId_t)(ncclUniqueId *);
+typedef int (*CommInitRank_t)(ncclComm_t *, int, ncclUniqueId, int);
+typedef int (*CommDestroy_t)(ncclComm_t);
+typedef int (*Send_t)(const void *, size_t, int, int, ncclComm_t, hipStream_t);
+typedef int (*Recv_t)(void *, size_t, int, int, ncclComm_t, hipStream_t);
+typedef int (*Group_t)(void);
+typedef const char *(*ErrStr_t)(int);
+
+static void *lib = nullptr;
+static GetUniqueId_t GetUniqueId;
+static CommInitRank_t CommInitRank;
+static CommDestroy_t CommDestroy;
+static Send_t Send;
+static Recv_t Recv;
+static Group_t GroupStart, GroupEnd;
+static ErrStr_t GetErrorString;
+static ncclComm_t comm = nullptr;
+static int comm_rank = 0, comm_size = 1;
+
+static int load() {
+    if (lib) return JTP_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+    }
+    if (!lib) return set_err(JTP_ECOMM, "cannot load librccl: %s", dlerror());
+#define SYM(var, name)                                                            \
+    var = (decltype(var))dlsym(lib, name);                                        \
+    if (!var) return set_err(JTP_ECOMM, "librccl lacks symbol %s", name);
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return JTP_OK;
+}
+}  // namespace rccl
+
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        int _r = (expr);                                                                        \
+        if (_r != rccl::ncclSuccess)                                                            \
+            return set_err(JTP_ECOMM, "%s failed: %s", #expr, rccl::GetErrorString(_r));         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ plan object
+
+typedef void (*jt_kernel_f32)(const JtTask *, const uint2 *, const float *, float *, double *);
+typedef void (*jt_kernel_f64)(const JtTask *, const uint2 *, const double *, double *, double *);
+
+template <typename T>
+struct KernelTable {
+    typedef void (*fn)(const JtTask *, const uint2 *, const T *, T *, double *);
+    static fn get(int variant) {
+        switch (variant) {
+            case JT_K_COLLECT0: return jt_collect<T, 0>;
+            case JT_K_COLLECT1: return jt_collect<T, 1>;
+            case JT_K_COLLECT2: return jt_collect<T, 2>;
+            case JT_K_COLLECT3: return jt_collect<T, 3>;
+            case JT_K_DIST_P0C0: return jt_distribute<T, 0, 0>;
+            case JT_K_DIST_P0C1: return jt_distribute<T, 0, 1>;
+            case JT_K_DIST_P0C2: return jt_distribute<T, 0, 2>;
+            case JT_K_DIST_P0C3: return jt_distribute<T, 0, 3>;
+            case JT_K_DIST_P1C0: return jt_distribute<T, 1, 0>;
+            case JT_K_DIST_P1C1: return jt_distribute<T, 1, 1>;
+            case JT_K_DIST_P1C2: return jt_distribute<T, 1, 2>;
+            case JT_K_DIST_P1C3: return jt_distribute<T, 1, 3>;
+        }
+        return nullptr;
+    }
+};
+
+static const char *k_names[JT_K_COUNT] = {
+    "jt_collect<T, 0>", "jt_collect<T, 1>", "jt_collect<T, 2>", "jt_collect<T, 3>",
+    "jt_distribute<T, 0, 0>", "jt_distribute<T, 0, 1>", "jt_distribute<T, 0, 2>", "jt_distribute<T, 0, 3>",
+    "jt_distribute<T, 1, 0>", "jt_distribute<T, 1, 1>", "jt_distribute<T, 1, 2>", "jt_distribute<T, 1, 3>",
+};
+
+struct BatchBuffers {
+    void *psi = nullptr;
+    void *bel = nullptr;
+    double *msg = nullptr;
+};
+
+struct jtp_plan {
+    HostPlan hp;
+    bool device = false;
+    std::vector<hipStream_t> streams;
+    std::vector<BatchBuffers> bufs;
+    JtTask *d_tasks = nullptr;
+    uint2 *d_blocks = nullptr;
+    void *stage = nullptr;          // device staging buffer for host<->device conversion
+    size_t stage_bytes = 0;
+    int prof_steps = 0;             // 0: off; else ring of this many event sets
+    std::vector<hipEvent_t> ev;     // prof_steps x (2 per launch)
+    int prof_cursor = 0;            // propagates recorded since profiling was switched on
+    int esize = 4;
+};
+
+static int ensure_stage(jtp_plan *pl, size_t bytes) {
+    if (pl->stage_bytes >= bytes) return JTP_OK;
+    if (pl->stage) HIP_TRY(hipFree(pl->stage));
+    pl->stage = nullptr;
+    pl->stage_bytes = 0;
+    HIP_TRY(hipMalloc(&pl->stage, bytes));
+    pl->stage_bytes = bytes;
+    return JTP_OK;
+}
+
+template <typename T, typename S>
+static void launch_pack(const JtPackDesc &d, const S *stage, T *arena, hipStream_t s) {
+    const int64_t n = (int64_t)1 << d.nbits;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL((jt_pack<T, S, 0>), dim3(grid), dim3(256), 0, s, d, stage, arena, 0ull, 0.0);
+}
+
+extern "C" {
+
+const char *jtp_last_error(void) { return g_err.c_str(); }
+const char *jtp_version(void) { return "jtprop 0.1.0 (gfx950, HIP, RCCL p2p)"; }
+
+int jtp_device_count(int32_t *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return set_err(JTP_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return JTP_OK;
+}
+
+const char *jtp_kernel_name(int32_t variant) {
+    if (variant < 0 || variant >= JT_K_COUNT) return nullptr;
+    return k_names[variant];
+}
+
+// ------------------------------------------------------------------------------------------ lifetime
+
+void jtp_plan_destroy(jtp_plan *pl) {
+    if (!pl) return;
+    if (pl->device) {
+        (void)hipSetDevice(pl->hp.device);
+        for (auto s : pl->streams) (void)hipStreamSynchronize(s);
+        for (auto &b : pl->bufs) {
+            if (b.psi) (void)hipFree(b.psi);
+            if (b.bel) (void)hipFree(b.bel);
+            if (b.msg) (void)hipFree(b.msg);
+        }
+        if (pl->d_tasks) (void)hipFree(pl->d_tasks);
+        if (pl->d_blocks) (void)hipFree(pl->d_blocks);
+        if (pl->stage) (void)hipFree(pl->stage);
+        for (auto e : pl->ev) (void)hipEventDestroy(e);
+        for (auto s : pl->streams) (void)hipStreamDestroy(s);
+    }
+    delete pl;
+}
+
+int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
+    if (!out) return set_err(JTP_EINVAL, "null output pointer");
+    *out = nullptr;
+    jtp_plan *pl = new jtp_plan();
+    std::string err;
+    int rc = jtp_build_plan(desc, pl->hp, err);
+    if (rc != JTP_OK) {
+        delete pl;
+        return set_err(rc, "%s", err.c_str());
+    }
+    HostPlan &hp = pl->hp;
+    pl->esize = hp.dtype == JTP_F32 ? 4 : 8;
+    if (hp.flags & JTP_PLAN_ONLY) {
+        *out = pl;
+        return JTP_OK;
+    }
+    if (hp.n_ranks > 1 && (!rccl::comm || rccl::comm_size != hp.n_ranks || rccl::comm_rank != hp.rank)) {
+        delete pl;
+        return set_err(JTP_ECOMM, "n_ranks=%d but jtp_comm_init was not called with a matching communicator", hp.n_ranks);
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        delete pl;
+        return set_err(JTP_EHIP, "no HIP device available (%s); libjtprop has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+#define CREATE_TRY(expr)                                                                                 \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            set_err(_e == hipErrorOutOfMemory ? JTP_ENOMEM : JTP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+            jtp_plan_destroy(pl);                                                                        \
+            return _e == hipErrorOutOfMemory ? JTP_ENOMEM : JTP_EHIP;                                    \
+        }                                                                                                \
+    } while (0)
+    pl->device = true;
+    CREATE_TRY(hipSetDevice(hp.device));
+    const int nstreams = std::min(hp.n_batch, 16);
+    pl->streams.resize(nstreams);
+    for (auto &s : pl->streams) CREATE_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    pl->bufs.resize(hp.n_batch);
+    const size_t abytes = (size_t)std::max<int64_t>(hp.arena_elems, 256) * pl->esize;
+    const size_t mbytes = (size_t)std::max<int64_t>(hp.msg_doubles, 2) * 8;
+    for (auto &b : pl->bufs) {
+        CREATE_TRY(hipMalloc(&b.psi, abytes));
+        CREATE_TRY(hipMalloc(&b.bel, abytes));
+        CREATE_TRY(hipMalloc((void **)&b.msg, mbytes));
+        CREATE_TRY(hipMemsetAsync(b.psi, 0, abytes, pl->streams[0]));
+        CREATE_TRY(hipMemsetAsync(b.bel, 0, abytes, pl->streams[0]));
+        CREATE_TRY(hipMemsetAsync(b.msg, 0, mbytes, pl->streams[0]));
+    }
+    if (!hp.tasks.empty()) {
+        CREATE_TRY(hipMalloc((void **)&pl->d_tasks, hp.tasks.size() * sizeof(JtTask)));
+        CREATE_TRY(hipMemcpy(pl->d_tasks, hp.tasks.data(), hp.tasks.size() * sizeof(JtTask), hipMemcpyHostToDevice));
+    }
+    if (!hp.blocks.empty()) {
+        CREATE_TRY(hipMalloc((void **)&pl->d_blocks, hp.blocks.size() * sizeof(BlockRef)));
+        CREATE_TRY(hipMemcpy(pl->d_blocks, hp.blocks.data(), hp.blocks.size() * sizeof(BlockRef), hipMemcpyHostToDevice));
+    }
+    if (hp.max_lds > 64 * 1024) {
+        for (int v = 0; v < JT_K_COUNT; ++v) {
+            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v);
+            CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hp.max_lds));
+        }
+    }
+    CREATE_TRY(hipStreamSynchronize(pl->streams[0]));
+#undef CREATE_TRY
+    *out = pl;
+    return JTP_OK;
+}
+
+const char *jtp_plan_describe(jtp_plan *pl) {
+    if (!pl) return "";
+    if (pl->hp.json.empty()) jtp_plan_to_json(pl->hp, pl->hp.tasks.size() <= 20000);
+    return pl->hp.json.c_str();
+}
+
+// ------------------------------------------------------------------------------------------ data in
+
+static int check_ready(jtp_plan *pl, int batch) {
+    if (!pl) return set_err(JTP_EINVAL, "null plan");
+    if (!pl->device) return set_err(JTP_EHIP, "plan was created with JTP_PLAN_ONLY: no device work possible");
+    if (batch < 0 || batch >= pl->hp.n_batch) return set_err(JTP_EINVAL, "batch %d out of range [0,%d)", batch, pl->hp.n_batch);
+    return JTP_OK;
+}
+
+int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *host, const int64_t *shape,
+                      int32_t host_dtype) {
+    int rc = check_ready(pl, batch);
+    if (rc) return rc;
+    HostPlan &hp = pl->hp;
+    if (node < 0 || node >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", node);
+    if (hp.pn[node].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", node, hp.pn[node].owner);
+    if (host_dtype != JTP_F32 && host_dtype != JTP_F64) return set_err(JTP_EINVAL, "bad host dtype");
+    JtPackDesc d = hp.pack[node];
+    int64_t stride = 1;
+    for (int i = d.nvars - 1; i >= 0; --i) {
+        const int64_t len = shape ? shape[i] : d.card[i];
+        if (len != d.card[i] && len != 1)
+            return set_err(JTP_EINVAL, "clique %d axis %d has length %lld, expected %d or 1", node, i, (long long)len, d.card[i]);
+        d.hstride[i] = (len == 1) ? 0 : stride;
+        stride *= len;
+    }
+    const size_t hbytes = (size_t)stride * (host_dtype == JTP_F32 ? 4 : 8);
+    HIP_TRY(hipSetDevice(hp.device));
+    rc = ensure_stage(pl, hbytes);
+    if (rc) return rc;
+    hipStream_t s = pl->streams[batch % pl->streams.size()];
+    HIP_TRY(hipMemcpyAsync(pl->stage, host, hbytes, hipMemcpyHostToDevice, s));
+    BatchBuffers &b = pl->bufs[batch];
+    if (hp.dtype == JTP_F32) {
+        if (host_dtype == JTP_F32) launch_pack<float, float>(d, (const float *)pl->stage, (float *)b.psi, s);
+        else launch_pack<float, double>(d, (const double *)pl->stage, (float *)b.psi, s);
+    } else {
+        if (host_dtype == JTP_F32) launch_pack<double, float>(d, (const float *)pl->stage, (double *)b.psi, s);
+        else launch_pack<double, double>(d, (const double *)pl->stage, (double *)b.psi, s);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));      // the staging buffer is reused by the next call
+    return JTP_OK;
+}
+
+static uint64_t host_splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double *scale) {
+    int rc = check_ready(pl, batch);
+    if (rc) return rc;
+    HostPlan &hp = pl->hp;
+    HIP_TRY(hipSetDevice(hp.device));
+    hipStream_t s = pl->streams[batch % pl->streams.size()];
+    BatchBuffers &b = pl->bufs[batch];
+    for (int c = 0; c < hp.n_cliques; ++c) {
+        if (hp.pn[c].owner != hp.rank) continue;
+        const JtPackDesc &d = hp.pack[c];
+        const uint64_t key = host_splitmix64(seed * 0x100000001B3ull + (uint64_t)c);
+        const double sc = scale ? scale[c] : 1.0;
+        const int64_t n = (int64_t)1 << d.nbits;
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+        if (hp.dtype == JTP_F32)
+            hipLaunchKernelGGL((jt_pack<float, float, 1>), dim3(grid), dim3(256), 0, s, d, (const float *)nullptr, (float *)b.psi, key, sc);
+        else
+            hipLaunchKernelGGL((jt_pack<double, double, 1>), dim3(grid), dim3(256), 0, s, d, (const double *)nullptr, (double *)b.psi, key, sc);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return JTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ compute
+
+static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipStream_t s, const JtTask *tasks,
+                          const uint2 *blocks, void *psi, void *bel, double *msg) {
+    if (pl->hp.dtype == JTP_F32) {
+        auto f = KernelTable<float>::get(variant);
+        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, (const float *)psi, (float *)bel, msg);
+    } else {
+        auto f = KernelTable<double>::get(variant);
+        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, (const double *)psi, (double *)bel, msg);
+    }
+    return JTP_OK;
+}
+
+int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
+    int rc = check_ready(pl, batch_begin);
+    if (rc) return rc;
+    HostPlan &hp = pl->hp;
+    if (batch_end <= batch_begin || batch_end > hp.n_batch) return set_err(JTP_EINVAL, "bad batch range [%d,%d)", batch_begin, batch_end);
+    HIP_TRY(hipSetDevice(hp.device));
+    const bool prof = pl->prof_steps > 0;
+    if (prof) {
+        size_t need = 2 * hp.launches.size() * (size_t)pl->prof_steps;
+        while (pl->ev.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            pl->ev.push_back(e);
+        }
+    }
+    const size_t ev_base = prof ? 2 * hp.launches.size() * (size_t)(pl->prof_cursor % pl->prof_steps) : 0;
+    for (int b = batch_begin; b < batch_end; ++b) {
+        hipStream_t s = pl->streams[b % pl->streams.size()];
+        BatchBuffers &bb = pl->bufs[b];
+        const bool pb = prof && b == batch_begin;
+        for (const Step &st : hp.steps) {
+            if (st.kind == 0) {
+                const Launch &L = hp.launches[st.first];
+                if (pb) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first], s));
+                launch_variant(pl, L.variant, L.nblocks, L.lds_bytes, s, pl->d_tasks, pl->d_blocks + L.blk_off, bb.psi, bb.bel, bb.msg);
+                if (pb) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first + 1], s));
+            } else {
+                NCCL_TRY(rccl::GroupStart());
+                for (int i = st.first; i < st.first + st.count; ++i) {
+                    const CommOp &op = hp.comm[i];
+                    if (op.send) NCCL_TRY(rccl::Send(bb.msg + op.off, (size_t)op.count, rccl::ncclFloat64, op.peer, rccl::comm, s));
+                    else NCCL_TRY(rccl::Recv(bb.msg + op.off, (size_t)op.count, rccl::ncclFloat64, op.peer, rccl::comm, s));
+                }
+                NCCL_TRY(rccl::GroupEnd());
+            }
+        }
+        if (pb) pl->prof_cursor++;
+    }
+    HIP_TRY(hipGetLastError());
+    return JTP_OK;
+}
+
+int jtp_sync(jtp_plan *pl) {
+    if (!pl) return set_err(JTP_EINVAL, "null plan");
+    if (!pl->device) return JTP_OK;
+    HIP_TRY(hipSetDevice(pl->hp.device));
+    for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
+    return JTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ data out
+
+int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_t host_dtype) {
+    int rc = check_ready(pl, batch);
+    if (rc) return rc;
+    HostPlan &hp = pl->hp;
+    if (node < 0 || node >= hp.n_nodes) return set_err(JTP_EINVAL, "node %d out of range", node);
+    if (host_dtype != JTP_F32 && host_dtype != JTP_F64) return set_err(JTP_EINVAL, "bad host dtype");
+    HIP_TRY(hipSetDevice(hp.device));
+    hipStream_t s = pl->streams[batch % pl->streams.size()];
+    BatchBuffers &b = pl->bufs[batch];
+    const size_t hsz = host_dtype == JTP_F32 ? 4 : 8;
+    if (node < hp.n_cliques) {
+        if (hp.pn[node].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", node, hp.pn[node].owner);
+        const JtPackDesc &d = hp.pack[node];
+        rc = ensure_stage(pl, (size_t)d.host_elems * hsz);
+        if (rc) return rc;
+        const int grid = (int)std::min<int64_t>((d.host_elems + 255) / 256, 4096);
+        if (hp.dtype == JTP_F32) {
+            if (host_dtype == JTP_F32) hipLaunchKernelGGL((jt_unpack<float, float>), dim3(grid), dim3(256), 0, s, d, (const float *)b.bel, (float *)pl->stage);
+            else hipLaunchKernelGGL((jt_unpack<float, double>), dim3(grid), dim3(256), 0, s, d, (const float *)b.bel, (double *)pl->stage);
+        } else {
+            if (host_dtype == JTP_F32) hipLaunchKernelGGL((jt_unpack<double, float>), dim3(grid), dim3(256), 0, s, d, (const double *)b.bel, (float *)pl->stage);
+            else hipLaunchKernelGGL((jt_unpack<double, double>), dim3(grid), dim3(256), 0, s, d, (const double *)b.bel, (double *)pl->stage);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)d.host_elems * hsz, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return JTP_OK;
+    }
+    const int si = hp.sep_of_node[node];
+    if (si < 0) return set_err(JTP_EINVAL, "separator node %d is not part of the tree", node);
+    const PSep &sp = hp.ps[si];
+    if (sp.up_off < 0) return set_err(JTP_EINVAL, "separator node %d is not held by rank %d", node, hp.rank);
+    JtPackDesc d;
+    memset(&d, 0, sizeof d);
+    d.nvars = (int)hp.node_vars[node].size();
+    d.nbits = sp.nbits;
+    int64_t stride = 1;
+    for (int i = d.nvars - 1; i >= 0; --i) {
+        const int v = hp.node_vars[node][i];
+        int j = 0;
+        while (sp.vars[j] != v) ++j;
+        d.pos[i] = (uint8_t)sp.pos[j];
+        d.nb[i] = (uint8_t)sp.nb[j];
+        d.card[i] = hp.card[v];
+        d.hstride[i] = stride;
+        stride *= hp.card[v];
+    }
+    d.host_elems = stride;
+    rc = ensure_stage(pl, (size_t)stride * hsz);
+    if (rc) return rc;
+    const int grid = (int)std::min<int64_t>((stride + 255) / 256, 4096);
+    const int64_t pstride = (int64_t)1 << sp.nbits;
+    if (host_dtype == JTP_F32)
+        hipLaunchKernelGGL((jt_msg_unpack<float>), dim3(grid), dim3(256), 0, s, d, b.msg + sp.up_off, sp.up_npart, b.msg + sp.dn_off, sp.dn_npart, pstride, (float *)pl->stage);
+    else
+        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, b.msg + sp.up_off, sp.up_npart, b.msg + sp.dn_off, sp.dn_npart, pstride, (double *)pl->stage);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)stride * hsz, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return JTP_OK;
+}
+
+int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t *out_vars, int32_t n_out, double *host) {
+    int rc = check_ready(pl, batch);
+    if (rc) return rc;
+    HostPlan &hp = pl->hp;
+    if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
+    if (hp.pn[clique].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
+    if (n_out < 0 || n_out > JT_MAX_VARS) return set_err(JTP_EINVAL, "bad variable count");
+    std::vector<int> ov(out_vars, out_vars + n_out);
+    for (int i = 0; i < n_out; ++i)
+        for (int j = 0; j < i; ++j)
+            if (ov[i] == ov[j]) return set_err(JTP_EINVAL, "variable %d requested twice", ov[i]);
+    JtTask tk;
+    int out_bits = 0, npart = 1;
+    std::vector<BlockRef> blocks;
+    std::string err;
+    rc = jtp_plan_marginal_task(hp, clique, ov, tk, out_bits, npart, blocks, err);
+    if (rc) return set_err(rc, "%s", err.c_str());
+    HIP_TRY(hipSetDevice(hp.device));
+    hipStream_t s = pl->streams[batch % pl->streams.size()];
+    BatchBuffers &b = pl->bufs[batch];
+    const int64_t pstride = (int64_t)1 << out_bits;
+    double *scratch = nullptr;
+    JtTask *d_task = nullptr;
+    uint2 *d_blk = nullptr;
+    HIP_TRY(hipMalloc((void **)&scratch, (size_t)pstride * npart * 8));
+    HIP_TRY(hipMalloc((void **)&d_task, sizeof(JtTask)));
+    HIP_TRY(hipMalloc((void **)&d_blk, blocks.size() * sizeof(BlockRef)));
+    tk.msg[JT_MAX_IN].off = 0;
+    HIP_TRY(hipMemcpyAsync(d_task, &tk, sizeof tk, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_blk, blocks.data(), blocks.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+    if (tk.lds_bytes > 64 * 1024) {
+        const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_COLLECT0) : (const void *)KernelTable<double>::get(JT_K_COLLECT0);
+        HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tk.lds_bytes));
+    }
+    // marginalise the BELIEF table: it is the "potential" argument of a childless collect
+    launch_variant(pl, JT_K_COLLECT0, (int)blocks.size(), tk.lds_bytes, s, d_task, d_blk, b.bel, b.bel, scratch);
+    HIP_TRY(hipGetLastError());
+    JtPackDesc d;
+    memset(&d, 0, sizeof d);
+    d.nvars = n_out;
+    d.nbits = out_bits;
+    int64_t stride = 1;
+    {
+        int bit = 0;
+        std::vector<int> pos(n_out);
+        for (int i = n_out - 1; i >= 0; --i) {           // last requested variable = lowest bits
+            pos[i] = bit;
+            bit += hp.vbits[ov[i]];
+        }
+        for (int i = n_out - 1; i >= 0; --i) {
+            d.pos[i] = (uint8_t)pos[i];
+            d.nb[i] = (uint8_t)hp.vbits[ov[i]];
+            d.card[i] = hp.card[ov[i]];
+            d.hstride[i] = stride;
+            stride *= hp.card[ov[i]];
+        }
+    }
+    d.host_elems = stride;
+    rc = ensure_stage(pl, (size_t)stride * 8);
+    if (rc == JTP_OK) {
+        const int grid = (int)std::min<int64_t>((stride + 255) / 256, 4096);
+        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, scratch, npart, (const double *)nullptr, 0, pstride, (double *)pl->stage);
+        hipError_t e1 = hipGetLastError();
+        hipError_t e2 = hipMemcpyAsync(host, pl->stage, (size_t)stride * 8, hipMemcpyDeviceToHost, s);
+        hipError_t e3 = hipStreamSynchronize(s);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+            rc = set_err(JTP_EHIP, "marginal read-back failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
+    }
+    (void)hipFree(scratch);
+    (void)hipFree(d_task);
+    (void)hipFree(d_blk);
+    return rc;
+}
+
+int jtp_get_z(jtp_plan *pl, int32_t batch, double *z) {
+    if (!pl) return set_err(JTP_EINVAL, "null plan");
+    if (pl->hp.pn[pl->hp.root].owner != pl->hp.rank) return set_err(JTP_EINVAL, "the root clique belongs to rank %d", pl->hp.pn[pl->hp.root].owner);
+    return jtp_get_marginal(pl, batch, pl->hp.root, nullptr, 0, z);
+}
+
+// ------------------------------------------------------------------------------------------ instrumentation
+
+int jtp_set_profiling(jtp_plan *pl, int32_t on) {
+    if (!pl) return set_err(JTP_EINVAL, "null plan");
+    pl->prof_steps = on > 0 ? std::min(on, 256) : 0;     // `on` = number of propagates to keep
+    pl->prof_cursor = 0;
+    return JTP_OK;
+}
+
+int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
+    if (!pl || !st) return set_err(JTP_EINVAL, "null argument");
+    HostPlan &hp = pl->hp;
+    memset(st, 0, sizeof *st);
+    st->struct_size = (int32_t)sizeof(jtp_stats);
+    st->n_launches = (int32_t)hp.launches.size();
+    st->n_messages = hp.n_messages;
+    st->n_tasks = (int32_t)hp.tasks.size();
+    st->algorithmic_bytes = hp.alg_bytes;
+    for (size_t i = 0; i < hp.launches.size(); ++i) {
+        const Launch &L = hp.launches[i];
+        st->kernel_bytes[L.variant] += L.alg_bytes;
+        st->kernel_launches[L.variant] += 1;
+    }
+    if (pl->device && pl->prof_steps > 0 && pl->prof_cursor > 0) {
+        HIP_TRY(hipSetDevice(hp.device));
+        const int kept = std::min(pl->prof_cursor, pl->prof_steps);
+        for (int k = 0; k < kept; ++k) {
+            const size_t base = 2 * hp.launches.size() * (size_t)k;
+            for (size_t i = 0; i < hp.launches.size(); ++i) {
+                const Launch &L = hp.launches[i];
+                HIP_TRY(hipEventSynchronize(pl->ev[base + 2 * i + 1]));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, pl->ev[base + 2 * i], pl->ev[base + 2 * i + 1]));
+                st->kernel_ms[L.variant] += ms / kept;      // mean per propagate
+                if (L.phase == 0) st->collect_ms += ms / kept;
+                else st->distribute_ms += ms / kept;
+            }
+        }
+    }
+    return JTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ multi-GPU
+
+int jtp_comm_unique_id(void *id128) {
+    int rc = rccl::load();
+    if (rc) return rc;
+    rccl::ncclUniqueId id;
+    NCCL_TRY(rccl::GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return JTP_OK;
+}
+
+int jtp_comm_init(int32_t rank, int32_t n_ranks, const void *id128, int32_t device) {
+    int rc = rccl::load();
+    if (rc) return rc;
+    if (rccl::comm) return set_err(JTP_ECOMM, "communicator already initialised");
+    HIP_TRY(hipSetDevice(device));
+    rccl::ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCL_TRY(rccl::CommInitRank(&rccl::comm, n_ranks, id, rank));
+    rccl::comm_rank = rank;
+    rccl::comm_size = n_ranks;
+    return JTP_OK;
+}
+
+int jtp_comm_destroy(void) {
+    if (rccl::comm) {
+        NCCL_TRY(rccl::CommDestroy(rccl::comm));
+        rccl::comm = nullptr;
+    }
+    return JTP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Internal structures shared by the host planner (jtp_plan.cpp), the kernels
+// (jtp_kernels.hip) and the C ABI (jtp_api.cpp).  See DESIGN.md "Data layout in HBM".
+//
+// Everything on the device is a *bit field*: a variable of cardinality k owns
+// ceil(log2 k) consecutive index bits of every table it appears in (tables are zero padded
+// when k is not a power of two), so "which separator entry does clique element x touch"
+// is a fixed re-arrangement of the bits of x.  A workgroup (256 threads) handles one
+// chunk of one clique; the clique's index bits are split into
+//     [ F | A and R | T ]        T = low TB bits: thread part (VEC elements x 256 threads)
+//   F bits: fixed per workgroup (chunk id)          -> no loop
+//   A bits: looped, belong to at least one outgoing message -> outer loop, epilogue each
+//   R bits: looped, belong to no outgoing message            -> inner loop, register sums
+#pragma once
+#include <stdint.h>
+
+#define JT_MAX_IN 4            // incoming messages per task (parent + 3 children)
+#define JT_MAX_OUT 3           // outgoing messages per task
+#define JT_MAX_MSG (JT_MAX_IN + JT_MAX_OUT)
+#define JT_NCOL 8              // increment-table columns: 0 = element offset, 1.. = messages
+#define JT_MAX_HI 22           // clique bits above the thread part
+#define JT_MAX_BITS 31         // max index bits of one clique table
+#define JT_MAX_FREE 13         // max log2(entries) of a staged message sub-box
+#define JT_THREADS 256
+#define JT_MAX_VARS 32         // variables per node
+
+struct JtMsg {
+    int64_t off;               // msg arena offset (doubles) of partial copy 0
+    int32_t npart;             // partial copies: summed when read, one written per chunk group
+    int32_t pstride;           // doubles between partial copies
+    int32_t nfree;             // the workgroup's sub-box has 2^nfree entries
+    int32_t lds_off;           // byte offset of the sub-box in dynamic LDS
+    int32_t e_w[2];            // sub-box slot weight of clique bits 0..EB-1 (0: bit not in message)
+    int32_t t_w[8];            // slot weight of the 6 lane bits then the 2 wave bits
+    int32_t red_e;             // outgoing: e bits NOT in the message (summed in-thread)
+    int32_t red_lane;          // outgoing: lane bits NOT in the message (summed by shuffles)
+    int32_t red_wave;          // outgoing: wave bits NOT in the message (summed through LDS)
+    int32_t e_dep;             // incoming: 1 if the message depends on any e bit
+    int32_t f_w[JT_MAX_HI];    // weight of F bit j in the message's global index
+    int32_t f_p[JT_MAX_HI];    // outgoing: weight of F bit j in the partial-copy number
+    uint8_t free_pos[16];      // global-index bit of each sub-box index bit
+};
+
+struct JtTask {
+    int64_t psi_off;           // element offset in the potential arena; < 0: virtual all-ones clique
+    int64_t bel_off;           // element offset in the belief arena; < 0: belief not written
+    int32_t nbits;             // index bits of the (padded) clique table, >= TB
+    int32_t nF, nA, nR;
+    int32_t n_in, n_out;
+    int32_t lds_bytes;
+    int32_t pnode;             // planner node this task belongs to
+    int32_t real_bits;         // index bits actually used by variables (<= nbits; rest is padding)
+    int32_t pad0;
+    uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
+    int32_t dA[JT_MAX_HI][JT_NCOL];   // A-loop increments: going from a to a+1 adds dA[ctz(a+1)]
+    int32_t dR[JT_MAX_HI][JT_NCOL];   // R-loop increments
+    JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing
+};
+
+// host <-> device layout conversion of one table (pack / unpack / synthetic fill)
+struct JtPackDesc {
+    int64_t dev_off;           // element offset in the arena
+    int32_t nbits;             // device index bits (padded)
+    int32_t nvars;
+    int64_t host_elems;        // product of host cardinalities
+    uint8_t pos[JT_MAX_VARS];  // first device bit of variable i (host axis order)
+    uint8_t nb[JT_MAX_VARS];   // bits of variable i
+    int32_t card[JT_MAX_VARS]; // cardinality
+    int64_t hstride[JT_MAX_VARS]; // host C-order stride in elements (0: broadcast axis)
+};
+
+// kernel variant ids: collect with n children; distribute with (has_parent, n children)
+enum {
+    JT_K_COLLECT0 = 0, JT_K_COLLECT1, JT_K_COLLECT2, JT_K_COLLECT3,
+    JT_K_DIST_P0C0, JT_K_DIST_P0C1, JT_K_DIST_P0C2, JT_K_DIST_P0C3,
+    JT_K_DIST_P1C0, JT_K_DIST_P1C1, JT_K_DIST_P1C2, JT_K_DIST_P1C3,
+    JT_K_COUNT
+};

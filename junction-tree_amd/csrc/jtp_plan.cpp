@@ -1,0 +1,861 @@
+// Host planner: junction tree description -> bit layouts, kernel task tables, level
+// schedule, message buffers, separator exchange schedule.  Pure C++ (no HIP calls), so it
+// also runs in JTP_PLAN_ONLY mode on machines without a GPU.
+//
+// Replaces, for the whole tree at once, what the reference does per einsum call:
+//   label -> axis-number remapping          junctiontree/sum_product.py:22-43
+//   recursion order of collect / distribute junctiontree/computation.py:47-96, 140-224
+// and removes `remove_message` (computation.py:99-136): every downward message is planned
+// as an all-but-one product, never as a division.
+#include "jtp_plan.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <sstream>
+
+namespace {
+
+int ceil_log2(int k) {
+    int b = 0;
+    while ((1 << b) < k) ++b;
+    return b;
+}
+
+int popc(uint32_t x) { return __builtin_popcount(x); }
+
+struct MsgView {
+    int psep = -1;
+    bool up = true;              // which buffer of the separator
+    int8_t dst[32];              // clique bit -> message bit, -1 if the bit is not in the message
+    uint32_t mask = 0;           // clique bits that are in the message
+    int msg_bits = 0;
+};
+
+#define FAIL(code, ...)                                   \
+    do {                                                  \
+        char _b[512];                                     \
+        snprintf(_b, sizeof _b, __VA_ARGS__);             \
+        err = _b;                                         \
+        return code;                                      \
+    } while (0)
+
+// variable -> (pos, nb) lookup inside a node layout
+int find_var(const std::vector<int> &vars, int v) {
+    for (size_t i = 0; i < vars.size(); ++i)
+        if (vars[i] == v) return (int)i;
+    return -1;
+}
+
+MsgView make_view(const PNode &p, const PSep &s, int psep, bool up) {
+    MsgView mv;
+    mv.psep = psep;
+    mv.up = up;
+    mv.msg_bits = s.nbits;
+    for (int i = 0; i < 32; ++i) mv.dst[i] = -1;
+    for (size_t i = 0; i < s.vars.size(); ++i) {
+        int j = find_var(p.vars, s.vars[i]);
+        for (int t = 0; t < s.nb[i]; ++t) {
+            mv.dst[p.pos[j] + t] = (int8_t)(s.pos[i] + t);
+            mv.mask |= 1u << (p.pos[j] + t);
+        }
+    }
+    return mv;
+}
+
+// Choose the F / A / R split of the high bits and fill every index table of the task.
+int plan_loops(const HostPlan &hp, JtTask &tk, int nbits, int real_bits, const std::vector<MsgView> &ins,
+               const std::vector<MsgView> &outs, int block_log2, std::string &err) {
+    const int TB = hp.TB;
+    const int budget = hp.lds_budget > 0 ? hp.lds_budget : 32 * 1024;
+    const int PMAX_LOG2 = 3;                 // at most 8 partial copies per outgoing message
+    const uint32_t himask = nbits >= 32 ? 0 : (((1u << nbits) - 1) & ~((1u << TB) - 1));
+    uint32_t allout = 0, everyout = himask;
+    for (auto &o : outs) {
+        allout |= o.mask;
+        everyout &= o.mask;
+    }
+    if (outs.empty()) everyout = 0;
+
+    auto lds_of = [&](uint32_t F) {
+        long total = 0;
+        for (auto &m : ins) total += 8L << popc(m.mask & ~F);
+        for (auto &m : outs) total += 8L << popc(m.mask & ~F);
+        return total;
+    };
+    auto max_free = [&](uint32_t F) {
+        int mx = 0;
+        for (auto &m : ins) mx = std::max(mx, popc(m.mask & ~F));
+        for (auto &m : outs) mx = std::max(mx, popc(m.mask & ~F));
+        return mx;
+    };
+    auto part_log2 = [&](uint32_t F) {       // worst partial count over the outputs
+        int mx = 0;
+        for (auto &o : outs) mx = std::max(mx, popc(F & ~o.mask));
+        return mx;
+    };
+
+    uint32_t F = 0;
+    // 1. LDS must fit: fix the high bit that shrinks the staged sub-boxes most.
+    while (lds_of(F) > budget || max_free(F) > JT_MAX_FREE) {
+        int best = -1;
+        long best_lds = 0;
+        int best_part = 0;
+        for (int b = TB; b < nbits; ++b) {
+            if (F >> b & 1) continue;
+            long l = lds_of(F | 1u << b);
+            int pl = part_log2(F | 1u << b);
+            if (best < 0 || l < best_lds || (l == best_lds && pl < best_part)) {
+                best = b, best_lds = l, best_part = pl;
+            }
+        }
+        if (best < 0 || best_lds >= lds_of(F)) {
+            if (lds_of(F) <= 150 * 1024 && max_free(F) <= JT_MAX_FREE) break;   // cannot shrink further
+            FAIL(JTP_EUNSUPPORTED, "message sub-boxes do not fit in LDS (%ld bytes)", lds_of(F));
+        }
+        F |= 1u << best;
+    }
+    // 2. Parallelism: split until a workgroup handles at most 2^block_log2 elements, preferring
+    //    bits that every outgoing message contains (no partial copies), highest bit first.
+    while (nbits - popc(F) > block_log2) {
+        int best = -1;
+        for (int b = nbits - 1; b >= TB; --b)
+            if (!(F >> b & 1) && (everyout >> b & 1)) {
+                best = b;
+                break;
+            }
+        if (best < 0) {
+            // otherwise: fewest partial copies, then the bit most incoming messages contain
+            // (smaller staged sub-boxes), then the highest
+            int best_pl = 1 << 30, best_in = -1;
+            for (int b = nbits - 1; b >= TB; --b) {
+                if (F >> b & 1) continue;
+                int pl = part_log2(F | 1u << b);
+                int nin = 0;
+                for (auto &m : ins) nin += (m.mask >> b) & 1;
+                if (pl < best_pl || (pl == best_pl && nin > best_in)) best_pl = pl, best_in = nin, best = b;
+            }
+            if (best < 0 || best_pl > PMAX_LOG2) break;
+        }
+        F |= 1u << best;
+    }
+    if (popc(F) > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "too many chunk bits (%d)", popc(F));
+
+    std::vector<int> Fb, Ab, Rb;
+    for (int b = TB; b < nbits; ++b) {
+        if (F >> b & 1) Fb.push_back(b);
+        else if (allout >> b & 1) Ab.push_back(b);
+        else Rb.push_back(b);
+    }
+    tk.nbits = nbits;
+    tk.real_bits = real_bits;
+    tk.nF = (int)Fb.size();
+    tk.nA = (int)Ab.size();
+    tk.nR = (int)Rb.size();
+    tk.n_in = (int)ins.size();
+    tk.n_out = (int)outs.size();
+    if (tk.nA > JT_MAX_HI || tk.nR > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "too many loop bits");
+    for (int j = 0; j < tk.nF; ++j) tk.f_x[j] = 1u << Fb[j];
+
+    int lds = 0;
+    // per-message tables
+    std::vector<std::vector<int>> slotw;      // [msg][clique bit] -> sub-box slot weight
+    auto fill_msg = [&](JtMsg &jm, const MsgView &mv, bool is_out) {
+        std::vector<int> sw(32, 0);
+        // free message bits = images of clique bits outside F, ascending message bit
+        std::vector<std::pair<int, int>> fr;   // (message bit, clique bit)
+        for (int b = 0; b < nbits; ++b)
+            if ((mv.mask >> b & 1) && !(F >> b & 1)) fr.push_back({mv.dst[b], b});
+        std::sort(fr.begin(), fr.end());
+        jm.nfree = (int)fr.size();
+        for (size_t r = 0; r < fr.size(); ++r) {
+            jm.free_pos[r] = (uint8_t)fr[r].first;
+            sw[fr[r].second] = 1 << r;
+        }
+        for (int e = 0; e < 2; ++e) jm.e_w[e] = (e < hp.EB) ? sw[e] : 0;
+        for (int t = 0; t < 8; ++t) jm.t_w[t] = sw[hp.EB + t];
+        jm.e_dep = 0;
+        for (int e = 0; e < hp.EB; ++e) jm.e_dep |= (mv.mask >> e & 1);
+        jm.red_e = jm.red_lane = jm.red_wave = 0;
+        if (is_out) {
+            for (int e = 0; e < hp.EB; ++e) if (!(mv.mask >> e & 1)) jm.red_e |= 1 << e;
+            for (int t = 0; t < 6; ++t) if (!(mv.mask >> (hp.EB + t) & 1)) jm.red_lane |= 1 << t;
+            for (int t = 0; t < 2; ++t) if (!(mv.mask >> (hp.EB + 6 + t) & 1)) jm.red_wave |= 1 << t;
+        }
+        int pbit = 0;
+        for (int j = 0; j < tk.nF; ++j) {
+            int b = Fb[j];
+            jm.f_w[j] = (mv.mask >> b & 1) ? (1 << mv.dst[b]) : 0;
+            jm.f_p[j] = 0;
+            if (is_out && !(mv.mask >> b & 1)) jm.f_p[j] = 1 << pbit++;
+        }
+        jm.npart = is_out ? (1 << pbit) : 1;      // incoming npart is patched in later
+        jm.pstride = 1 << mv.msg_bits;
+        jm.lds_off = lds;
+        lds += 8 << jm.nfree;
+        lds = (lds + 15) & ~15;
+        slotw.push_back(sw);
+    };
+    for (int k = 0; k < tk.n_in; ++k) fill_msg(tk.msg[k], ins[k], false);
+    for (int k = tk.n_in; k < JT_MAX_IN; ++k) slotw.push_back(std::vector<int>(32, 0));
+    for (int k = 0; k < tk.n_out; ++k) fill_msg(tk.msg[JT_MAX_IN + k], outs[k], true);
+    for (int k = tk.n_out; k < JT_MAX_OUT; ++k) slotw.push_back(std::vector<int>(32, 0));
+    tk.lds_bytes = std::max(lds, 16);
+
+    auto fill_delta = [&](int32_t (*d)[JT_NCOL], const std::vector<int> &bits) {
+        std::vector<int64_t> run(JT_NCOL, 0);
+        for (size_t t = 0; t < bits.size(); ++t) {
+            int b = bits[t];
+            int64_t w[JT_NCOL];
+            w[0] = (int64_t)1 << b;
+            for (int c = 1; c < JT_NCOL; ++c) w[c] = slotw[c - 1][b];
+            for (int c = 0; c < JT_NCOL; ++c) {
+                d[t][c] = (int32_t)(uint32_t)(w[c] - run[c]);   // wraps mod 2^32 for column 0
+                run[c] += w[c];
+            }
+        }
+    };
+    fill_delta(tk.dA, Ab);
+    fill_delta(tk.dR, Rb);
+    return JTP_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+
+int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
+    if (!d) FAIL(JTP_EINVAL, "null description");
+    if (d->struct_size != (int32_t)sizeof(jtp_tree_desc))
+        FAIL(JTP_EINVAL, "jtp_tree_desc size mismatch (%d vs %zu)", d->struct_size, sizeof(jtp_tree_desc));
+    if (d->n_cliques < 1 || d->n_vars < 0) FAIL(JTP_EINVAL, "empty tree");
+    if (d->n_nodes != 2 * d->n_cliques - 1)
+        FAIL(JTP_EINVAL, "n_nodes must be 2*n_cliques-1 (got %d for %d cliques)", d->n_nodes, d->n_cliques);
+    if (d->dtype != JTP_F32 && d->dtype != JTP_F64) FAIL(JTP_EINVAL, "bad dtype %d", d->dtype);
+    if (d->n_batch < 1) FAIL(JTP_EINVAL, "n_batch must be >= 1");
+    if (d->n_ranks < 1 || d->rank < 0 || d->rank >= d->n_ranks) FAIL(JTP_EINVAL, "bad rank %d/%d", d->rank, d->n_ranks);
+
+    hp.n_vars = d->n_vars;
+    hp.n_cliques = d->n_cliques;
+    hp.n_nodes = d->n_nodes;
+    hp.dtype = d->dtype;
+    hp.n_ranks = d->n_ranks;
+    hp.rank = d->rank;
+    hp.n_batch = d->n_batch;
+    hp.device = d->device;
+    hp.flags = d->flags;
+    hp.lds_budget = d->lds_budget;
+    hp.block_log2 = d->block_log2;
+    hp.layout_policy = d->layout_policy;
+    hp.VEC = d->dtype == JTP_F32 ? 4 : 2;
+    hp.EB = d->dtype == JTP_F32 ? 2 : 1;
+    hp.TB = hp.EB + 8;
+    const int N = d->n_cliques;
+    const int esize = d->dtype == JTP_F32 ? 4 : 8;
+
+    hp.card.assign(d->var_card, d->var_card + d->n_vars);
+    hp.vbits.resize(d->n_vars);
+    for (int v = 0; v < d->n_vars; ++v) {
+        if (hp.card[v] < 1) FAIL(JTP_EINVAL, "variable %d has cardinality %d", v, hp.card[v]);
+        hp.vbits[v] = ceil_log2(hp.card[v]);
+    }
+    hp.node_vars.resize(d->n_nodes);
+    for (int n = 0; n < d->n_nodes; ++n) {
+        int a = d->node_var_off[n], b = d->node_var_off[n + 1];
+        if (b < a || b - a > JT_MAX_VARS) FAIL(JTP_EUNSUPPORTED, "node %d has %d variables (max %d)", n, b - a, JT_MAX_VARS);
+        for (int i = a; i < b; ++i) {
+            int v = d->node_var_ids[i];
+            if (v < 0 || v >= d->n_vars) FAIL(JTP_EINVAL, "node %d: unknown variable %d", n, v);
+            if (find_var(hp.node_vars[n], v) >= 0) FAIL(JTP_EINVAL, "node %d: variable %d listed twice", n, v);
+            hp.node_vars[n].push_back(v);
+        }
+    }
+    hp.parent_clique.assign(d->parent_clique, d->parent_clique + N);
+    hp.parent_sep.assign(d->parent_sep, d->parent_sep + N);
+    hp.owner.assign(N, 0);
+    if (d->clique_owner)
+        for (int c = 0; c < N; ++c) {
+            hp.owner[c] = d->clique_owner[c];
+            if (hp.owner[c] < 0 || hp.owner[c] >= d->n_ranks) FAIL(JTP_EINVAL, "clique %d: bad owner %d", c, hp.owner[c]);
+        }
+
+    // ---- nodes and separators -------------------------------------------------------------
+    hp.pn.assign(N, PNode());
+    hp.sep_of_node.assign(d->n_nodes, -1);
+    hp.root = -1;
+    for (int c = 0; c < N; ++c) {
+        PNode &p = hp.pn[c];
+        p.real = c;
+        p.owner = hp.owner[c];
+        p.parent = hp.parent_clique[c];
+        if (p.parent < 0) {
+            if (hp.root >= 0) FAIL(JTP_EINVAL, "two roots (%d and %d)", hp.root, c);
+            hp.root = c;
+        } else if (p.parent >= N || p.parent == c) FAIL(JTP_EINVAL, "clique %d: bad parent %d", c, p.parent);
+    }
+    if (hp.root < 0) FAIL(JTP_EINVAL, "no root clique");
+    for (int c = 0; c < N; ++c) {
+        if (c == hp.root) continue;
+        int sn = hp.parent_sep[c];
+        if (sn < N || sn >= d->n_nodes) FAIL(JTP_EINVAL, "clique %d: separator node %d out of range", c, sn);
+        if (hp.sep_of_node[sn] >= 0) FAIL(JTP_EINVAL, "separator node %d used twice", sn);
+        for (int v : hp.node_vars[sn]) {
+            if (find_var(hp.node_vars[c], v) < 0 || find_var(hp.node_vars[hp.pn[c].parent], v) < 0)
+                FAIL(JTP_EINVAL, "separator node %d: variable %d is not in both adjacent cliques", sn, v);
+        }
+        PSep s;
+        s.node = sn;
+        s.child = c;
+        s.parent = hp.pn[c].parent;
+        s.vars = hp.node_vars[sn];
+        hp.sep_of_node[sn] = (int)hp.ps.size();
+        hp.pn[c].psep = (int)hp.ps.size();
+        hp.ps.push_back(s);
+        hp.pn[hp.pn[c].parent].children.push_back(c);
+    }
+    {   // reachability (rejects cycles)
+        std::vector<int> q{hp.root};
+        std::vector<char> seen(N, 0);
+        seen[hp.root] = 1;
+        for (size_t i = 0; i < q.size(); ++i)
+            for (int k : hp.pn[q[i]].children)
+                if (!seen[k]) seen[k] = 1, q.push_back(k);
+        if ((int)q.size() != N) FAIL(JTP_EINVAL, "parent pointers do not form a tree");
+    }
+
+    // ---- binarise: at most 3 children per node, via virtual all-ones cliques ---------------
+    for (int c = 0; c < (int)hp.pn.size(); ++c) {
+        while (hp.pn[c].children.size() > 3) {
+            std::vector<int> old = hp.pn[c].children, fresh;
+            for (size_t g = 0; g < old.size(); g += 3) {
+                size_t ge = std::min(old.size(), g + 3);
+                if (ge - g == 1) {
+                    fresh.push_back(old[g]);
+                    continue;
+                }
+                PNode v;
+                v.real = -1;
+                v.owner = hp.pn[c].owner;
+                v.parent = c;
+                for (size_t i = g; i < ge; ++i) {
+                    for (int var : hp.ps[hp.pn[old[i]].psep].vars)
+                        if (find_var(v.vars, var) < 0) v.vars.push_back(var);
+                    v.children.push_back(old[i]);
+                }
+                if (v.vars.size() > JT_MAX_VARS) FAIL(JTP_EUNSUPPORTED, "virtual clique too wide");
+                int vi = (int)hp.pn.size();
+                PSep s;
+                s.node = -1;
+                s.child = vi;
+                s.parent = c;
+                s.vars = v.vars;
+                v.psep = (int)hp.ps.size();
+                hp.ps.push_back(s);
+                for (size_t i = g; i < ge; ++i) {
+                    hp.pn[old[i]].parent = vi;
+                    hp.ps[hp.pn[old[i]].psep].parent = vi;
+                }
+                hp.pn.push_back(v);
+                fresh.push_back(vi);
+            }
+            hp.pn[c].children = fresh;
+        }
+    }
+    const int NP = (int)hp.pn.size();
+
+    // ---- depth ------------------------------------------------------------------------------
+    int maxdepth = 0;
+    {
+        std::vector<int> q{hp.root};
+        hp.pn[hp.root].depth = 0;
+        for (size_t i = 0; i < q.size(); ++i)
+            for (int k : hp.pn[q[i]].children) {
+                hp.pn[k].depth = hp.pn[q[i]].depth + 1;
+                maxdepth = std::max(maxdepth, hp.pn[k].depth);
+                q.push_back(k);
+            }
+    }
+
+    // ---- bit layouts ----------------------------------------------------------------------
+    for (int c = 0; c < NP; ++c) {
+        PNode &p = hp.pn[c];
+        std::vector<int> host = p.real >= 0 ? hp.node_vars[p.real] : p.vars;
+        std::vector<int> seps;
+        if (p.psep >= 0) seps.push_back(p.psep);
+        for (int k : p.children) seps.push_back(hp.pn[k].psep);
+        std::vector<int> order;                       // LSB first
+        if (hp.layout_policy == 1 || seps.empty()) {
+            order.assign(host.rbegin(), host.rend());
+        } else {
+            // Classes: priv = in no separator; part = in some but not all child separators (or
+            // only the parent's); allc = in every child separator (leaf: in the parent's).
+            // Target shape, low to high:  e bits <- priv | lane bits <- part | wave bits <- allc
+            // | rest of part, allc | rest of priv.  Outgoing-message bits in the thread part
+            // need no cross-lane sum; private bits up high become the register-summed R loop.
+            int nchild = (int)p.children.size();
+            std::vector<int> priv, part, allc;
+            for (size_t i = 0; i < host.size(); ++i) {
+                int v = host[i];
+                int in_parent = p.psep >= 0 && find_var(hp.ps[p.psep].vars, v) >= 0;
+                int in_child = 0;
+                for (int k : p.children) in_child += find_var(hp.ps[hp.pn[k].psep].vars, v) >= 0;
+                if (!in_parent && !in_child) priv.push_back(v);
+                else if ((nchild > 0 && in_child == nchild) || nchild == 0) allc.push_back(v);
+                else part.push_back(v);
+            }
+            auto take = [&](std::vector<int> &from, int want_bits) {
+                int got = 0;
+                while (!from.empty() && got < want_bits) {
+                    int v = from.front();
+                    from.erase(from.begin());
+                    order.push_back(v);
+                    got += hp.vbits[v];
+                }
+                return got;
+            };
+            int got = take(priv, hp.EB);
+            if (got < hp.EB) got += take(part, hp.EB - got);
+            if (got < hp.EB) got += take(allc, hp.EB - got);
+            auto bits_of = [&](const std::vector<int> &l) {
+                int b = 0;
+                for (int v : l) b += hp.vbits[v];
+                return b;
+            };
+            int lane = take(part, 6);
+            // lanes prefer message bits (no shuffle sum) but leave two allc bits for the waves
+            while (lane < 6 && !allc.empty() && bits_of(allc) - hp.vbits[allc.front()] >= 2) lane += take(allc, 1);
+            if (lane < 6) lane += take(priv, 6 - lane);
+            if (lane < 6) lane += take(allc, 6 - lane);
+            int wave = take(allc, 2);
+            if (wave < 2) wave += take(part, 2 - wave);
+            if (wave < 2) wave += take(priv, 2 - wave);
+            take(part, 1 << 20);
+            take(allc, 1 << 20);
+            take(priv, 1 << 20);
+        }
+        p.vars = order;
+        p.pos.clear();
+        p.nb.clear();
+        int bit = 0;
+        for (int v : p.vars) {
+            p.pos.push_back(bit);
+            p.nb.push_back(hp.vbits[v]);
+            bit += hp.vbits[v];
+        }
+        if (bit > JT_MAX_BITS) FAIL(JTP_EUNSUPPORTED, "clique %d needs %d index bits (max %d)", p.real, bit, JT_MAX_BITS);
+        p.nbits = std::max(bit, hp.TB);
+        if (p.nbits - hp.TB > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
+    }
+    for (size_t s = 0; s < hp.ps.size(); ++s) {
+        PSep &sp = hp.ps[s];
+        const PNode &ch = hp.pn[sp.child];
+        std::vector<int> order;
+        for (int v : ch.vars)
+            if (find_var(sp.vars, v) >= 0) order.push_back(v);
+        sp.vars = order;
+        int bit = 0;
+        sp.pos.clear();
+        sp.nb.clear();
+        for (int v : sp.vars) {
+            sp.pos.push_back(bit);
+            sp.nb.push_back(hp.vbits[v]);
+            bit += hp.vbits[v];
+        }
+        sp.nbits = bit;
+        if (bit > 28) FAIL(JTP_EUNSUPPORTED, "separator with %d index bits", bit);
+    }
+
+    // ---- arena offsets (this rank's real cliques) --------------------------------------------
+    hp.arena_elems = 0;
+    for (int c = 0; c < NP; ++c) {
+        PNode &p = hp.pn[c];
+        if (p.real < 0 || p.owner != hp.rank) continue;
+        p.arena_off = hp.arena_elems;
+        hp.arena_elems += (int64_t)1 << p.nbits;
+        hp.arena_elems = (hp.arena_elems + 255) & ~(int64_t)255;
+    }
+    hp.pack.assign(N, JtPackDesc());
+    for (int c = 0; c < N; ++c) {
+        const PNode &p = hp.pn[c];
+        JtPackDesc &pd = hp.pack[c];
+        memset(&pd, 0, sizeof pd);
+        pd.dev_off = p.arena_off;
+        pd.nbits = p.nbits;
+        pd.nvars = (int)hp.node_vars[c].size();
+        int64_t stride = 1;
+        for (int i = pd.nvars - 1; i >= 0; --i) {
+            int v = hp.node_vars[c][i];
+            int j = find_var(p.vars, v);
+            pd.pos[i] = (uint8_t)p.pos[j];
+            pd.nb[i] = (uint8_t)p.nb[j];
+            pd.card[i] = hp.card[v];
+            pd.hstride[i] = stride;
+            stride *= hp.card[v];
+        }
+        pd.host_elems = stride;
+    }
+
+    // ---- per (phase, level) work, to size workgroups -------------------------------------------
+    std::vector<double> lvl_elems[2];
+    lvl_elems[0].assign(maxdepth + 1, 0);
+    lvl_elems[1].assign(maxdepth + 1, 0);
+    for (int c = 0; c < NP; ++c) {
+        double e = (double)((int64_t)1 << hp.pn[c].nbits);
+        if (c != hp.root) lvl_elems[0][hp.pn[c].depth] += e;
+        lvl_elems[1][hp.pn[c].depth] += e;
+    }
+    auto block_log2_for = [&](int phase, int level) {
+        if (hp.block_log2 > 0) return std::max(hp.block_log2, hp.TB);
+        double want = lvl_elems[phase][level] / 2048.0;
+        int lg = 13;
+        while (lg < 16 && (double)(1 << (lg + 1)) <= want) ++lg;
+        return std::max(lg, hp.TB);
+    };
+
+    // ---- tasks ------------------------------------------------------------------------------
+    auto host_elems = [&](const std::vector<int> &vars) {
+        double e = 1;
+        for (int v : vars) e *= hp.card[v];
+        return e;
+    };
+    std::vector<double> task_bytes;
+    for (int c = 0; c < NP; ++c) {
+        PNode &p = hp.pn[c];
+        int nch = (int)p.children.size();
+        for (int phase = 0; phase < 2; ++phase) {
+            if (phase == 0 && c == hp.root) continue;
+            JtTask tk;
+            memset(&tk, 0, sizeof tk);
+            tk.pnode = c;
+            tk.psi_off = p.real >= 0 ? p.arena_off : -1;
+            if (p.real >= 0 && p.owner != hp.rank) tk.psi_off = 0;       // not executed here
+            tk.bel_off = (phase == 1 && p.real >= 0) ? (p.owner == hp.rank ? p.arena_off : 0) : -1;
+            std::vector<MsgView> ins, outs;
+            if (phase == 1 && p.psep >= 0) ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
+            for (int k : p.children) ins.push_back(make_view(p, hp.ps[hp.pn[k].psep], hp.pn[k].psep, true));
+            if (phase == 0) outs.push_back(make_view(p, hp.ps[p.psep], p.psep, true));
+            else for (int k : p.children) outs.push_back(make_view(p, hp.ps[hp.pn[k].psep], hp.pn[k].psep, false));
+            int real_bits = 0;
+            for (int nb : p.nb) real_bits += nb;
+            int rc = plan_loops(hp, tk, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth), err);
+            if (rc != JTP_OK) return rc;
+            int ti = (int)hp.tasks.size();
+            if (phase == 0) {
+                p.collect_task = ti;
+                hp.ps[p.psep].up_npart = tk.msg[JT_MAX_IN].npart;
+                hp.task_variant.push_back(JT_K_COLLECT0 + nch);
+            } else {
+                p.distribute_task = ti;
+                for (int j = 0; j < nch; ++j) hp.ps[hp.pn[p.children[j]].psep].dn_npart = tk.msg[JT_MAX_IN + j].npart;
+                hp.task_variant.push_back(JT_K_DIST_P0C0 + 4 * (p.psep >= 0 ? 1 : 0) + nch);
+            }
+            // algorithmic bytes: clique table read (+ belief written), messages
+            double b = 0;
+            if (p.real >= 0) b += host_elems(hp.node_vars[p.real]) * esize * (phase == 1 ? 2 : 1);
+            for (auto &m : ins) if (hp.ps[m.psep].node >= 0) b += host_elems(hp.ps[m.psep].vars) * 8;
+            for (auto &m : outs) if (hp.ps[m.psep].node >= 0) b += host_elems(hp.ps[m.psep].vars) * 8 * (phase == 1 ? 2 : 1);
+            task_bytes.push_back(b);
+            hp.tasks.push_back(tk);
+        }
+    }
+
+    // ---- message arena ----------------------------------------------------------------------
+    hp.msg_doubles = 0;
+    for (auto &s : hp.ps) {
+        bool mine = hp.pn[s.child].owner == hp.rank || hp.pn[s.parent].owner == hp.rank;
+        if (!mine) continue;
+        int64_t n = (int64_t)1 << s.nbits;
+        s.up_off = hp.msg_doubles;
+        hp.msg_doubles += n * s.up_npart;
+        s.dn_off = hp.msg_doubles;
+        hp.msg_doubles += n * s.dn_npart;
+        hp.msg_doubles = (hp.msg_doubles + 1) & ~(int64_t)1;
+    }
+    for (size_t t = 0; t < hp.tasks.size(); ++t) {
+        JtTask &tk = hp.tasks[t];
+        const PNode &p = hp.pn[tk.pnode];
+        bool collect = (int)t == p.collect_task;
+        int k = 0;
+        if (!collect && p.psep >= 0) {
+            tk.msg[k].off = hp.ps[p.psep].dn_off;
+            tk.msg[k].npart = hp.ps[p.psep].dn_npart;
+            ++k;
+        }
+        for (int ch : p.children) {
+            const PSep &s = hp.ps[hp.pn[ch].psep];
+            tk.msg[k].off = s.up_off;
+            tk.msg[k].npart = s.up_npart;
+            ++k;
+        }
+        if (collect) tk.msg[JT_MAX_IN].off = hp.ps[p.psep].up_off;
+        else
+            for (size_t j = 0; j < p.children.size(); ++j) tk.msg[JT_MAX_IN + j].off = hp.ps[hp.pn[p.children[j]].psep].dn_off;
+    }
+
+    // ---- launches, blocks, exchange schedule -----------------------------------------------------
+    hp.alg_bytes = 0;
+    hp.max_lds = 0;
+    std::vector<CommOp> pending;            // comm ops waiting to be grouped before the next launch
+    auto flush_comm = [&]() {
+        if (pending.empty()) return;
+        Step st;
+        st.kind = 1;
+        st.first = (int)hp.comm.size();
+        st.count = (int)pending.size();
+        for (auto &op : pending) hp.comm.push_back(op);
+        hp.steps.push_back(st);
+        pending.clear();
+    };
+    auto comm_op = [&](int send, int psep, int up, int peer) {
+        const PSep &s = hp.ps[psep];
+        CommOp op;
+        op.send = send;
+        op.psep = psep;
+        op.up = up;
+        op.peer = peer;
+        op.off = up ? s.up_off : s.dn_off;
+        op.count = ((int64_t)1 << s.nbits) * (up ? s.up_npart : s.dn_npart);
+        pending.push_back(op);
+    };
+    auto by_level = [&](int level) {
+        std::vector<int> v;
+        for (int c = 0; c < NP; ++c) if (hp.pn[c].depth == level) v.push_back(c);
+        return v;
+    };
+    auto emit_launches = [&](int phase, int level) {
+        std::map<int, std::vector<int>> groups;
+        for (int c : by_level(level)) {
+            const PNode &p = hp.pn[c];
+            if (p.owner != hp.rank) continue;
+            int t = phase == 0 ? p.collect_task : p.distribute_task;
+            if (t < 0) continue;
+            groups[hp.task_variant[t]].push_back(t);
+        }
+        if (!groups.empty()) flush_comm();
+        for (auto &g : groups) {
+            Launch L;
+            L.phase = phase;
+            L.level = level;
+            L.variant = g.first;
+            L.tasks = g.second;
+            L.blk_off = (int64_t)hp.blocks.size();
+            for (int t : L.tasks) {
+                const JtTask &tk = hp.tasks[t];
+                for (uint32_t f = 0; f < (1u << tk.nF); ++f) hp.blocks.push_back({(uint32_t)t, f});
+                L.lds_bytes = std::max(L.lds_bytes, tk.lds_bytes);
+                L.alg_bytes += task_bytes[t];
+            }
+            L.nblocks = (int)(hp.blocks.size() - L.blk_off);
+            hp.max_lds = std::max(hp.max_lds, L.lds_bytes);
+            hp.alg_bytes += L.alg_bytes;
+            Step st;
+            st.kind = 0;
+            st.first = (int)hp.launches.size();
+            st.count = 1;
+            hp.launches.push_back(L);
+            hp.steps.push_back(st);
+        }
+    };
+    for (int level = maxdepth; level >= 0; --level) {          // collect
+        for (int c : by_level(level)) {                        // receive what this level consumes
+            if (hp.pn[c].owner != hp.rank) continue;
+            for (int k : hp.pn[c].children)
+                if (hp.pn[k].owner != hp.rank) comm_op(0, hp.pn[k].psep, 1, hp.pn[k].owner);
+        }
+        if (level >= 1) emit_launches(0, level);
+        for (int c : by_level(level)) {                        // send what this level produced
+            const PNode &p = hp.pn[c];
+            if (p.owner != hp.rank || p.parent < 0) continue;
+            if (hp.pn[p.parent].owner != hp.rank) comm_op(1, p.psep, 1, hp.pn[p.parent].owner);
+        }
+    }
+    for (int level = 0; level <= maxdepth; ++level) {          // distribute
+        for (int c : by_level(level)) {
+            const PNode &p = hp.pn[c];
+            if (p.owner != hp.rank || p.parent < 0) continue;
+            if (hp.pn[p.parent].owner != hp.rank) comm_op(0, p.psep, 0, hp.pn[p.parent].owner);
+        }
+        emit_launches(1, level);
+        for (int c : by_level(level)) {
+            if (hp.pn[c].owner != hp.rank) continue;
+            for (int k : hp.pn[c].children)
+                if (hp.pn[k].owner != hp.rank) comm_op(1, hp.pn[k].psep, 0, hp.pn[k].owner);
+        }
+    }
+    flush_comm();
+    hp.n_messages = 0;
+    for (int c = 0; c < N; ++c)
+        if (c != hp.root && hp.owner[c] == hp.rank) hp.n_messages += 2;
+    return JTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+
+int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
+                           JtTask &tk, int &out_bits, int &npart, std::vector<BlockRef> &blocks,
+                           std::string &err) {
+    const PNode &p = hp.pn[pnode];
+    PSep s;
+    s.vars.assign(out_vars.rbegin(), out_vars.rend());       // last requested variable = lowest bits
+    int bit = 0;
+    for (int v : s.vars) {
+        if (find_var(p.vars, v) < 0) FAIL(JTP_EINVAL, "variable %d is not in clique %d", v, p.real);
+        s.pos.push_back(bit);
+        s.nb.push_back(hp.vbits[v]);
+        bit += hp.vbits[v];
+    }
+    s.nbits = bit;
+    if (bit > 28) FAIL(JTP_EUNSUPPORTED, "marginal with %d index bits", bit);
+    memset(&tk, 0, sizeof tk);
+    tk.pnode = pnode;
+    tk.psi_off = p.arena_off;
+    tk.bel_off = -1;
+    std::vector<MsgView> ins, outs;
+    outs.push_back(make_view(p, s, -1, true));
+    int real_bits = 0;
+    for (int nb : p.nb) real_bits += nb;
+    int rc = plan_loops(hp, tk, p.nbits, real_bits, ins, outs, 14, err);
+    if (rc != JTP_OK) return rc;
+    out_bits = bit;
+    npart = tk.msg[JT_MAX_IN].npart;
+    blocks.clear();
+    for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back({0u, f});
+    return JTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+
+namespace {
+template <typename It>
+void json_list(std::ostringstream &o, It a, It b) {
+    o << "[";
+    for (It i = a; i != b; ++i) {
+        if (i != a) o << ",";
+        o << (long long)*i;
+    }
+    o << "]";
+}
+template <typename V>
+void json_vec(std::ostringstream &o, const V &v) { json_list(o, v.begin(), v.end()); }
+
+void json_msg(std::ostringstream &o, const JtMsg &m, int nF) {
+    o << "{\"off\":" << m.off << ",\"npart\":" << m.npart << ",\"pstride\":" << m.pstride
+      << ",\"nfree\":" << m.nfree << ",\"lds_off\":" << m.lds_off << ",\"e_w\":";
+    json_list(o, m.e_w, m.e_w + 2);
+    o << ",\"t_w\":";
+    json_list(o, m.t_w, m.t_w + 8);
+    o << ",\"red_e\":" << m.red_e << ",\"red_lane\":" << m.red_lane << ",\"red_wave\":" << m.red_wave
+      << ",\"e_dep\":" << m.e_dep << ",\"f_w\":";
+    json_list(o, m.f_w, m.f_w + nF);
+    o << ",\"f_p\":";
+    json_list(o, m.f_p, m.f_p + nF);
+    o << ",\"free_pos\":";
+    json_list(o, m.free_pos, m.free_pos + m.nfree);
+    o << "}";
+}
+}  // namespace
+
+void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
+    std::ostringstream o;
+    o << "{\"version\":1,\"dtype\":" << hp.dtype << ",\"VEC\":" << hp.VEC << ",\"EB\":" << hp.EB << ",\"TB\":" << hp.TB
+      << ",\"n_cliques\":" << hp.n_cliques << ",\"n_ranks\":" << hp.n_ranks << ",\"rank\":" << hp.rank
+      << ",\"root\":" << hp.root << ",\"arena_elems\":" << hp.arena_elems << ",\"msg_doubles\":" << hp.msg_doubles
+      << ",\"max_lds\":" << hp.max_lds << ",\"alg_bytes\":" << (long long)hp.alg_bytes
+      << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
+      << ",\"n_blocks\":" << hp.blocks.size();
+    o << ",\"pnodes\":[";
+    for (size_t i = 0; i < hp.pn.size(); ++i) {
+        const PNode &p = hp.pn[i];
+        if (i) o << ",";
+        o << "{\"real\":" << p.real << ",\"parent\":" << p.parent << ",\"psep\":" << p.psep << ",\"depth\":" << p.depth
+          << ",\"owner\":" << p.owner << ",\"nbits\":" << p.nbits << ",\"arena_off\":" << p.arena_off
+          << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"vars\":";
+        json_vec(o, p.vars);
+        o << ",\"pos\":";
+        json_vec(o, p.pos);
+        o << ",\"nb\":";
+        json_vec(o, p.nb);
+        o << ",\"children\":";
+        json_vec(o, p.children);
+        o << "}";
+    }
+    o << "],\"pseps\":[";
+    for (size_t i = 0; i < hp.ps.size(); ++i) {
+        const PSep &s = hp.ps[i];
+        if (i) o << ",";
+        o << "{\"node\":" << s.node << ",\"child\":" << s.child << ",\"parent\":" << s.parent << ",\"nbits\":" << s.nbits
+          << ",\"up_npart\":" << s.up_npart << ",\"dn_npart\":" << s.dn_npart << ",\"up_off\":" << s.up_off
+          << ",\"dn_off\":" << s.dn_off << ",\"vars\":";
+        json_vec(o, s.vars);
+        o << ",\"pos\":";
+        json_vec(o, s.pos);
+        o << ",\"nb\":";
+        json_vec(o, s.nb);
+        o << "}";
+    }
+    o << "],\"launches\":[";
+    for (size_t i = 0; i < hp.launches.size(); ++i) {
+        const Launch &L = hp.launches[i];
+        if (i) o << ",";
+        o << "{\"phase\":" << L.phase << ",\"level\":" << L.level << ",\"variant\":" << L.variant
+          << ",\"nblocks\":" << L.nblocks << ",\"blk_off\":" << L.blk_off << ",\"lds_bytes\":" << L.lds_bytes
+          << ",\"alg_bytes\":" << (long long)L.alg_bytes << ",\"tasks\":";
+        json_vec(o, L.tasks);
+        o << "}";
+    }
+    o << "],\"steps\":[";
+    for (size_t i = 0; i < hp.steps.size(); ++i) {
+        if (i) o << ",";
+        o << "[" << hp.steps[i].kind << "," << hp.steps[i].first << "," << hp.steps[i].count << "]";
+    }
+    o << "],\"comm\":[";
+    for (size_t i = 0; i < hp.comm.size(); ++i) {
+        const CommOp &c = hp.comm[i];
+        if (i) o << ",";
+        o << "{\"send\":" << c.send << ",\"psep\":" << c.psep << ",\"up\":" << c.up << ",\"peer\":" << c.peer
+          << ",\"off\":" << c.off << ",\"count\":" << c.count << "}";
+    }
+    o << "]";
+    if (with_tasks) {
+        o << ",\"tasks\":[";
+        for (size_t t = 0; t < hp.tasks.size(); ++t) {
+            const JtTask &tk = hp.tasks[t];
+            if (t) o << ",";
+            o << "{\"pnode\":" << tk.pnode << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
+              << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
+              << ",\"nR\":" << tk.nR << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
+              << ",\"lds_bytes\":" << tk.lds_bytes << ",\"f_x\":";
+            json_list(o, tk.f_x, tk.f_x + tk.nF);
+            o << ",\"dA\":[";
+            for (int a = 0; a < tk.nA; ++a) {
+                if (a) o << ",";
+                json_list(o, tk.dA[a], tk.dA[a] + JT_NCOL);
+            }
+            o << "],\"dR\":[";
+            for (int r = 0; r < tk.nR; ++r) {
+                if (r) o << ",";
+                json_list(o, tk.dR[r], tk.dR[r] + JT_NCOL);
+            }
+            o << "],\"in\":[";
+            for (int k = 0; k < tk.n_in; ++k) {
+                if (k) o << ",";
+                json_msg(o, tk.msg[k], tk.nF);
+            }
+            o << "],\"out\":[";
+            for (int k = 0; k < tk.n_out; ++k) {
+                if (k) o << ",";
+                json_msg(o, tk.msg[JT_MAX_IN + k], tk.nF);
+            }
+            o << "]}";
+        }
+        o << "],\"blocks\":[";
+        for (size_t b = 0; b < hp.blocks.size(); ++b) {
+            if (b) o << ",";
+            o << "[" << hp.blocks[b].task << "," << hp.blocks[b].chunk << "]";
+        }
+        o << "]";
+    }
+    o << "}";
+    hp.json = o.str();
+}

@@ -1,0 +1,100 @@
+// Host-side plan: what jtp_plan_create compiles a junction tree into.  Pure C++ (no HIP).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/jtprop.h"
+#include "jtp_internal.h"
+
+struct PNode {                       // a clique of the (binarised) tree
+    int real = -1;                   // clique index in the caller's node list, -1: virtual unit clique
+    std::vector<int> vars;           // variable ids, device order (first = lowest bits)
+    std::vector<int> pos, nb;        // first bit / number of bits of each variable
+    int nbits = 0;                   // padded index bits (>= TB)
+    int parent = -1;                 // parent pnode
+    int psep = -1;                   // separator to the parent (index into HostPlan::ps)
+    std::vector<int> children;       // child pnodes in message order
+    int depth = 0;
+    int owner = 0;                   // owning rank
+    int64_t arena_off = -1;          // element offset in the potential/belief arenas (real, owned)
+    int collect_task = -1, distribute_task = -1;
+};
+
+struct PSep {                        // a separator = one message tensor per direction
+    int node = -1;                   // node index in the caller's node list, -1: virtual
+    std::vector<int> vars, pos, nb;  // device order / bit layout of the message tensor
+    int nbits = 0;
+    int child = -1, parent = -1;     // pnodes
+    int up_npart = 1, dn_npart = 1;  // partial copies written by the producer
+    int64_t up_off = -1, dn_off = -1;  // msg arena offsets (doubles); -1: not held by this rank
+};
+
+struct Launch {
+    int phase = 0;                   // 0 collect, 1 distribute
+    int level = 0;
+    int variant = 0;                 // JT_K_*
+    std::vector<int> tasks;          // indices into HostPlan::tasks
+    int64_t blk_off = 0;             // first entry of this launch in HostPlan::blocks
+    int nblocks = 0;
+    int lds_bytes = 0;
+    double alg_bytes = 0;            // algorithmic bytes this launch accounts for
+};
+
+struct CommOp {
+    int send = 0;                    // 1 send, 0 recv
+    int psep = 0;
+    int up = 0;                      // 1: upward (collect) message, 0: downward
+    int peer = 0;
+    int64_t off = 0;                 // msg arena offset (doubles)
+    int64_t count = 0;               // doubles (all partial copies)
+};
+
+struct Step {
+    int kind = 0;                    // 0 launch, 1 comm group
+    int first = 0, count = 0;        // launch index, or [first, first+count) in comm
+};
+
+struct BlockRef { uint32_t task, chunk; };
+
+struct HostPlan {
+    // copy of the description
+    int n_vars = 0, n_cliques = 0, n_nodes = 0, dtype = 0, n_ranks = 1, rank = 0, n_batch = 1;
+    int device = 0;
+    uint32_t flags = 0;
+    int lds_budget = 0, block_log2 = 0, layout_policy = 0;
+    std::vector<int> card, vbits;
+    std::vector<std::vector<int>> node_vars;
+    std::vector<int> parent_clique, parent_sep, owner;
+    // derived
+    int VEC = 4, EB = 2, TB = 10;
+    int root = 0;
+    std::vector<PNode> pn;
+    std::vector<PSep> ps;
+    std::vector<int> sep_of_node;    // caller's separator node -> psep (size n_nodes, -1 for cliques)
+    std::vector<JtTask> tasks;
+    std::vector<int> task_variant;
+    std::vector<Launch> launches;
+    std::vector<BlockRef> blocks;
+    std::vector<CommOp> comm;
+    std::vector<Step> steps;
+    std::vector<JtPackDesc> pack;    // per real clique (host order)
+    int64_t arena_elems = 0;         // potential arena == belief arena size (elements)
+    int64_t msg_doubles = 0;
+    int max_lds = 0;
+    double alg_bytes = 0;
+    int n_messages = 0;
+    std::string json;
+};
+
+// Build the plan.  Returns JTP_OK or an error code with `err` set.
+int jtp_build_plan(const jtp_tree_desc *desc, HostPlan &hp, std::string &err);
+
+// One-off task: marginalise table `src_off` (layout of pnode `p`) onto `out_vars` (message layout:
+// out_vars[0] slowest, padded to power-of-two bits).  The task writes `npart` partial copies of
+// 2^out_bits doubles at msg-arena offset `dst_off`.  Returns JTP_OK or error.
+int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
+                           JtTask &task, int &out_bits, int &npart, std::vector<BlockRef> &blocks,
+                           std::string &err);
+
+void jtp_plan_to_json(HostPlan &hp, bool with_tasks);

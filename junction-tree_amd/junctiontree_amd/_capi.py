@@ -1,0 +1,126 @@
+"""ctypes binding of libjtprop.so (include/jtprop.h).  No torch, no pybind: a plain C ABI.
+
+The library is required: if it cannot be loaded, or no MI355X is visible when a plan needs
+the device, every entry point raises - there is no CPU fallback in this package.
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjtprop.so")
+
+JTP_OK, JTP_EINVAL, JTP_EHIP, JTP_ECOMM, JTP_ENOMEM, JTP_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+JTP_F32, JTP_F64 = 0, 1
+JTP_PLAN_ONLY = 1
+N_VARIANTS = 12
+
+
+class TreeDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("n_vars", C.c_int32),
+        ("var_card", C.POINTER(C.c_int32)),
+        ("n_cliques", C.c_int32),
+        ("n_nodes", C.c_int32),
+        ("node_var_off", C.POINTER(C.c_int32)),
+        ("node_var_ids", C.POINTER(C.c_int32)),
+        ("parent_clique", C.POINTER(C.c_int32)),
+        ("parent_sep", C.POINTER(C.c_int32)),
+        ("dtype", C.c_int32),
+        ("device", C.c_int32),
+        ("n_batch", C.c_int32),
+        ("n_ranks", C.c_int32),
+        ("rank", C.c_int32),
+        ("clique_owner", C.POINTER(C.c_int32)),
+        ("flags", C.c_uint32),
+        ("lds_budget", C.c_int32),
+        ("block_log2", C.c_int32),
+        ("layout_policy", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("n_launches", C.c_int32),
+        ("n_messages", C.c_int32),
+        ("n_tasks", C.c_int32),
+        ("algorithmic_bytes", C.c_double),
+        ("collect_ms", C.c_double),
+        ("distribute_ms", C.c_double),
+        ("kernel_ms", C.c_double * 32),
+        ("kernel_bytes", C.c_double * 32),
+        ("kernel_launches", C.c_int32 * 32),
+        ("pad", C.c_int32),
+    ]
+
+
+class JtpError(RuntimeError):
+    """HIP / RCCL / allocation failure reported by libjtprop."""
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/jtprop.h declares
+SYMBOLS = {
+    "jtp_plan_create": (C.c_int, [C.POINTER(TreeDesc), C.POINTER(C.c_void_p)]),
+    "jtp_plan_destroy": (None, [C.c_void_p]),
+    "jtp_plan_describe": (C.c_char_p, [C.c_void_p]),
+    "jtp_set_potential": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                    C.POINTER(C.c_int64), C.c_int32]),
+    "jtp_fill_synthetic": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_double)]),
+    "jtp_propagate": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "jtp_sync": (C.c_int, [C.c_void_p]),
+    "jtp_get_belief": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "jtp_get_marginal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                   C.c_int32, C.POINTER(C.c_double)]),
+    "jtp_get_z": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
+    "jtp_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "jtp_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "jtp_kernel_name": (C.c_char_p, [C.c_int32]),
+    "jtp_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "jtp_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "jtp_comm_destroy": (C.c_int, []),
+    "jtp_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
+    "jtp_last_error": (C.c_char_p, []),
+    "jtp_version": (C.c_char_p, []),
+}
+
+
+def lib():
+    """Load libjtprop.so once.  Raises ImportError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libjtprop.so not found at %s: build it with `python junction-tree_amd/build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    handle = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(handle, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Map a libjtprop status to the exception the reference's users would expect:
+    structural problems -> ValueError (numpy raises ValueError for shape mismatches in the
+    reference), everything else -> JtpError (a RuntimeError)."""
+    if rc == JTP_OK:
+        return
+    msg = lib().jtp_last_error().decode("utf-8", "replace")
+    if rc in (JTP_EINVAL, JTP_EUNSUPPORTED):
+        raise ValueError(msg)
+    if rc == JTP_ENOMEM:
+        raise MemoryError(msg)
+    raise JtpError(msg)
+
+
+def device_count():
+    n = C.c_int32(0)
+    rc = lib().jtp_device_count(C.byref(n))
+    return n.value if rc == JTP_OK else 0

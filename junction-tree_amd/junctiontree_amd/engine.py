@@ -1,0 +1,249 @@
+"""Host side of the device boundary: a junction tree in the reference's nested-list form
+-> a `Plan` on the MI355X (libjtprop.so through ctypes).
+
+The reference walks the nested list recursively on every call
+(`junctiontree/computation.py:47-96, 140-224`); here the list is flattened once into parent
+arrays (no recursion limit on deep chains), variables are numbered, and the
+C side compiles layouts, kernel task tables and the level schedule (`jtp_plan_create`).
+"""
+
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _capi
+
+__all__ = ["Plan", "flatten_tree", "plan_for", "clear_plan_cache"]
+
+
+def flatten_tree(tree):
+    """[clique, (sep, subtree), ...] -> (cliques in pre-order, parent, parent_sep, children).
+
+    The format is the reference's (`README.md:50-66`); tuples and lists are interchangeable
+    as in its tests.  Iterative.
+    """
+    order, parent, parent_sep, children = [], {}, {}, {}
+    stack = [(tree, -1, -1)]
+    while stack:
+        sub, par, sep = stack.pop()
+        c = sub[0]
+        if c in parent:
+            raise ValueError("clique index %r appears twice in the tree" % (c,))
+        order.append(c)
+        parent[c], parent_sep[c] = par, sep
+        children[c] = [(entry[0], entry[1][0]) for entry in sub[1:]]
+        for entry in reversed(sub[1:]):
+            stack.append((entry[1], c, entry[0]))
+    return order, parent, parent_sep, children
+
+
+def _int_array(values):
+    arr = (C.c_int32 * max(len(values), 1))()
+    for i, v in enumerate(values):
+        arr[i] = int(v)
+    return arr
+
+
+class Plan:
+    """A compiled junction tree resident on one GPU (or, with `plan_only`, on the host).
+
+    `node_vars[i]` lists the variable labels of node i of the caller's node list (cliques
+    and separators in any numbering, as `compute_beliefs` allows); `sizes` maps a label to
+    its cardinality.  `dtype` is the storage type of clique tables ("f32" or "f64");
+    messages and accumulation are always float64.
+    """
+
+    def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
+                 n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
+                 layout_policy=0):
+        self._lib = _capi.lib()
+        self._handle = C.c_void_p()
+        order, parent, parent_sep, children = flatten_tree(tree)
+        cliques = sorted(order)
+        seps = sorted(parent_sep[c] for c in order if parent[c] != -1)
+        if set(cliques) & set(seps):
+            raise ValueError("a node index is used both as clique and as separator")
+        self.cliques, self.seps = cliques, seps
+        self.node_ids = cliques + seps                    # ABI node number -> caller's index
+        self.abi_of = {n: i for i, n in enumerate(self.node_ids)}
+        self.n_cliques = len(cliques)
+        self.tree_order = order
+        self.parent = parent
+        self.root = order[0]
+
+        labels = {}
+        for n in self.node_ids:
+            for lab in node_vars[n]:
+                labels.setdefault(lab, len(labels))
+        self.var_id = labels
+        self.var_labels = list(labels)
+        try:
+            self.card = [int(sizes[lab]) for lab in self.var_labels]
+        except KeyError as exc:                           # the reference raises KeyError too
+            raise KeyError(exc.args[0])
+        self.node_vars = {n: list(node_vars[n]) for n in self.node_ids}
+        self.node_shape = {n: tuple(int(sizes[lab]) for lab in node_vars[n]) for n in self.node_ids}
+        self.dtype = {"f32": _capi.JTP_F32, "f64": _capi.JTP_F64, np.float32: _capi.JTP_F32,
+                      np.float64: _capi.JTP_F64}[dtype]
+        self.n_batch = n_batch
+        self.rank, self.n_ranks = rank, n_ranks
+
+        off, ids = [0], []
+        for n in self.node_ids:
+            ids += [labels[lab] for lab in node_vars[n]]
+            off.append(len(ids))
+        par = [self.abi_of[parent[c]] if parent[c] != -1 else -1 for c in cliques]
+        psep = [self.abi_of[parent_sep[c]] if parent[c] != -1 else -1 for c in cliques]
+        self.owner = [0] * len(cliques) if owner is None else [int(owner[c]) for c in cliques]
+
+        d = _capi.TreeDesc()
+        d.struct_size = C.sizeof(_capi.TreeDesc)
+        d.n_vars = len(self.card)
+        self._keep = [_int_array(self.card), _int_array(off), _int_array(ids), _int_array(par),
+                      _int_array(psep), _int_array(self.owner)]
+        d.var_card, d.node_var_off, d.node_var_ids, d.parent_clique, d.parent_sep, d.clique_owner = \
+            [C.cast(a, C.POINTER(C.c_int32)) for a in self._keep]
+        d.n_cliques = len(cliques)
+        d.n_nodes = len(self.node_ids)
+        d.dtype = self.dtype
+        d.device = device
+        d.n_batch = n_batch
+        d.n_ranks = n_ranks
+        d.rank = rank
+        d.flags = _capi.JTP_PLAN_ONLY if plan_only else 0
+        d.lds_budget = lds_budget
+        d.block_log2 = block_log2
+        d.layout_policy = layout_policy
+        _capi.check(self._lib.jtp_plan_create(C.byref(d), C.byref(self._handle)))
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.jtp_plan_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def describe(self):
+        return json.loads(self._lib.jtp_plan_describe(self._handle).decode())
+
+    def owns(self, clique):
+        return self.owner[self.abi_of[clique]] == self.rank
+
+    # ------------------------------------------------------------------ data in
+    def set_potential(self, node, array, batch=0):
+        """Upload the potential of clique `node` (caller's index).  The array must have one
+        axis per variable, each of the variable's cardinality or length 1 (broadcast)."""
+        arr = np.asarray(array)
+        if arr.dtype not in (np.float32, np.float64):
+            arr = arr.astype(np.float64)
+        arr = np.ascontiguousarray(arr)
+        full = self.node_shape[node]
+        if arr.ndim != len(full):
+            raise ValueError("potential of node %r has %d axes, its variable list has %d"
+                             % (node, arr.ndim, len(full)))
+        shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+        host_dtype = _capi.JTP_F32 if arr.dtype == np.float32 else _capi.JTP_F64
+        _capi.check(self._lib.jtp_set_potential(self._handle, batch, self.abi_of[node],
+                                                arr.ctypes.data_as(C.c_void_p), shape, host_dtype))
+
+    def fill_synthetic(self, seed, scales=None, batch=0):
+        """Device-side counter-based potentials (see synthetic.synth_values).  `scales` is
+        indexed by the caller's clique index."""
+        sc = None
+        if scales is not None:
+            sc = (C.c_double * self.n_cliques)(*[float(scales[c]) for c in self.cliques])
+        # node keys are the ABI clique numbers; callers that compare with
+        # synthetic.synth_values must number cliques 0..N-1 (all recipes do)
+        _capi.check(self._lib.jtp_fill_synthetic(self._handle, batch, seed, sc))
+
+    # ------------------------------------------------------------------ compute
+    def propagate(self, batch_begin=0, batch_end=None, sync=True):
+        end = self.n_batch if batch_end is None else batch_end
+        _capi.check(self._lib.jtp_propagate(self._handle, batch_begin, end))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        _capi.check(self._lib.jtp_sync(self._handle))
+
+    # ------------------------------------------------------------------ data out
+    def belief(self, node, batch=0, dtype=np.float64):
+        out = np.empty(self.node_shape[node], dtype=dtype)
+        host_dtype = _capi.JTP_F32 if out.dtype == np.float32 else _capi.JTP_F64
+        _capi.check(self._lib.jtp_get_belief(self._handle, batch, self.abi_of[node],
+                                             out.ctypes.data_as(C.c_void_p), host_dtype))
+        return out
+
+    def marginal(self, clique, labels, batch=0):
+        """Marginal of the clique belief onto `labels` (in that axis order), float64."""
+        ids = _int_array([self.var_id[lab] for lab in labels])
+        shape = tuple(self.card[self.var_id[lab]] for lab in labels)
+        out = np.empty(shape, dtype=np.float64)
+        _capi.check(self._lib.jtp_get_marginal(self._handle, batch, self.abi_of[clique],
+                                               C.cast(ids, C.POINTER(C.c_int32)), len(labels),
+                                               out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def z(self, batch=0):
+        val = C.c_double(0.0)
+        _capi.check(self._lib.jtp_get_z(self._handle, batch, C.byref(val)))
+        return val.value
+
+    # ------------------------------------------------------------------ instrumentation
+    def set_profiling(self, keep=1):
+        """Record a hipEvent pair around every launch of the next `keep` propagates."""
+        _capi.check(self._lib.jtp_set_profiling(self._handle, int(keep)))
+
+    def stats(self):
+        st = _capi.Stats()
+        _capi.check(self._lib.jtp_get_stats(self._handle, C.byref(st)))
+        tname = "float" if self.dtype == _capi.JTP_F32 else "double"
+        kernels = {}
+        for v in range(_capi.N_VARIANTS):
+            if st.kernel_launches[v]:
+                name = self._lib.jtp_kernel_name(v).decode().replace("<T", "<" + tname)
+                kernels[name] = {"launches": st.kernel_launches[v], "ms": st.kernel_ms[v],
+                                 "bytes": st.kernel_bytes[v]}
+        return {"n_launches": st.n_launches, "n_messages": st.n_messages, "n_tasks": st.n_tasks,
+                "algorithmic_bytes": st.algorithmic_bytes, "collect_ms": st.collect_ms,
+                "distribute_ms": st.distribute_ms, "kernels": kernels}
+
+
+# ---------------------------------------------------------------------- plan cache
+
+_cache = {}
+
+
+def _freeze(tree):
+    order, parent, parent_sep, _ = flatten_tree(tree)
+    return tuple((c, parent[c], parent_sep[c]) for c in order)
+
+
+def plan_for(tree, node_vars, sizes, dtype, **kwargs):
+    """Return a cached Plan for this structure (plans are expensive relative to tiny trees:
+    device allocations and a task-table upload)."""
+    order, parent, parent_sep, _ = flatten_tree(tree)
+    used = list(order) + [parent_sep[c] for c in order if parent[c] != -1]
+    labels = set(lab for n in used for lab in node_vars[n])
+    key = (_freeze(tree), tuple((n, tuple(node_vars[n])) for n in used),
+           tuple(sorted((repr(k), int(sizes[k])) for k in labels)),
+           dtype, tuple(sorted(kwargs.items())))
+    plan = _cache.get(key)
+    if plan is None:
+        if len(_cache) >= 16:
+            _cache.pop(next(iter(_cache))).close()
+        plan = Plan(tree, node_vars, sizes, dtype=dtype, **kwargs)
+        _cache[key] = plan
+    return plan
+
+
+def clear_plan_cache():
+    for plan in _cache.values():
+        plan.close()
+    _cache.clear()

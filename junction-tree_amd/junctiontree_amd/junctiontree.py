@@ -1,0 +1,157 @@
+"""User interface of the junction-tree library, MI355X build.
+
+Same public names and data model as the reference's `junctiontree/junctiontree.py`:
+`create_junction_tree(factors, sizes)` (:12-16) returns a `JunctionTree` whose
+`propagate(values)` (:297-331) turns factor values into consistent, unnormalised factor
+marginals.  Structure classes are plain Python; all numeric work of `propagate` after the
+factor product runs on the GPU through `engine.Plan`:
+
+    values --evaluate (factor products, host)--> clique potentials --H2D--> collect +
+    distribute on the device (computation.py:37-246 in one plan) --> per-factor marginals
+    computed on the device (junctiontree.py:264-274) --D2H--> list shaped like `values`.
+"""
+
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+from . import construction as cons
+
+__all__ = ["create_junction_tree", "argfind1", "take", "is_subset", "einsum",
+           "FactorGraph", "CliqueGraph", "JunctionTree"]
+
+
+def create_junction_tree(factors, sizes):
+    """Create a junction tree for a factor graph (reference: `junctiontree.py:12-16`)."""
+    assert all(type(f) == list for f in factors), "Provided factor is not a list"
+    return FactorGraph(factors=factors, sizes=sizes).triangulate().create_junction_tree()
+
+
+def argfind1(xs, cond):
+    """Index of the first element of xs satisfying cond (`junctiontree.py:19-21`)."""
+    for i, x in enumerate(xs):
+        if cond(x):
+            return i
+    raise StopIteration
+
+
+def take(xs, inds):
+    """Pick several list elements (`junctiontree.py:24-26`)."""
+    return [xs[i] for i in inds]
+
+
+def is_subset(a, b):
+    """Whether every element of a is in b (`junctiontree.py:29-31`)."""
+    return set(a) <= set(b)
+
+
+def einsum(xs, xs_keys, y_keys):
+    """Product of arrays onto `y_keys` with arbitrary labels; labels that appear only in
+    the output become length-1 axes (reference helper `junctiontree.py:34-80`).  Host-side
+    (numpy): it builds clique potentials from factor tables, outside the message-passing
+    path."""
+    xs = [np.asarray(x) for x in xs]
+    xs_keys = [list(k) for k in xs_keys]
+    have = set(k for keys in xs_keys for k in keys)
+    fresh = [k for k in y_keys if k not in have]
+    if fresh:
+        xs[0] = xs[0].reshape((1,) * len(fresh) + xs[0].shape)
+        xs_keys[0] = fresh + xs_keys[0]
+    number = {}
+    for keys in xs_keys + [list(y_keys)]:
+        for k in keys:
+            number.setdefault(k, len(number))
+    call = []
+    for x, keys in zip(xs, xs_keys):
+        call += [x, [number[k] for k in keys]]
+    call.append([number[k] for k in y_keys])
+    return np.einsum(*call)
+
+
+@dataclass(frozen=True)
+class FactorGraph:
+    """Factors (lists of variables) and the size of every variable (`junctiontree.py:83-117`)."""
+
+    factors: Any
+    sizes: Any
+
+    def triangulate(self):
+        """Triangulate and collect the maximal cliques (`junctiontree.py:102-117`)."""
+        maxcliques, factor_to_maxclique = cons.triangulate(self.factors, self.sizes)
+        return CliqueGraph(maxcliques=maxcliques, factor_to_maxclique=factor_to_maxclique,
+                           factor_graph=self)
+
+
+@dataclass
+class CliqueGraph:
+    """Maximal cliques of a triangulated factor graph (`junctiontree.py:120-274`)."""
+
+    maxcliques: Any
+    factor_to_maxclique: Any
+    factor_graph: Any
+
+    def create_junction_tree(self):
+        """`junctiontree.py:138-200`: node list = maxcliques ++ separators, tree of indices."""
+        tree, separators = cons.construct_junction_tree(self.maxcliques, self.factor_graph.sizes)
+        return JunctionTree(tree=tree, separators=separators, clique_tree=self)
+
+    def _members(self):
+        members = [[] for _ in self.maxcliques]
+        for fi, mc in enumerate(self.factor_to_maxclique):
+            members[mc].append(fi)
+        return members
+
+    def evaluate(self, xs):
+        """Clique values from factor values (`junctiontree.py:203-226`): the product of the
+        factors assigned to each clique in the clique's axis order; variables no assigned
+        factor covers stay length-1 axes."""
+        out = []
+        for clique, members in zip(self.maxcliques, self._members()):
+            if not members:
+                out.append(np.ones((1,) * len(clique)))
+                continue
+            out.append(einsum(take(xs, members), take(self.factor_graph.factors, members), clique))
+        return out
+
+    def marginalize(self, ys):
+        """Factor results from clique results (`junctiontree.py:229-274`) for arrays already
+        on the host: sum the clique axes that are not in the factor."""
+        return [einsum([ys[mc]], [self.maxcliques[mc]], list(fvars))
+                for fvars, mc in zip(self.factor_graph.factors, self.factor_to_maxclique)]
+
+
+@dataclass(frozen=True)
+class JunctionTree:
+    """Junction tree of a factor graph (`junctiontree.py:277-331`).
+
+    `tree` = [clique, (separator, subtree), ...] over the node list
+    `clique_tree.maxcliques + separators`."""
+
+    tree: Any
+    separators: Any
+    clique_tree: Any
+    _opts: dict = field(default_factory=dict, compare=False, repr=False)
+
+    def plan(self, dtype="f64"):
+        """The device plan for the current variable sizes (sizes are read at call time, as
+        `junctiontree.py:311` does: the reference's tests condition on evidence by setting
+        a size to 1, `tests/test_junctiontree.py:393-411`)."""
+        from . import engine
+
+        node_vars = [list(c) for c in self.clique_tree.maxcliques] + [list(s) for s in self.separators]
+        return engine.plan_for(self.tree, node_vars, self.clique_tree.factor_graph.sizes, dtype,
+                               **self._opts)
+
+    def propagate(self, xs):
+        """Belief propagation: factor values in, unnormalised factor marginals out (same
+        list length and array shapes as `xs`; float64)."""
+        ct = self.clique_tree
+        psi = ct.evaluate(xs)
+        all_f32 = all(isinstance(x, np.ndarray) and x.dtype == np.float32 for x in xs)
+        plan = self.plan("f32" if all_f32 else "f64")
+        for c, p in enumerate(psi):
+            plan.set_potential(c, p)
+        plan.propagate()
+        return [plan.marginal(mc, list(fvars))
+                for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)]

@@ -1,0 +1,76 @@
+"""Cut a junction tree at separator edges into per-GPU parts.
+
+The only interaction between two sides of a cut is one upward and one downward separator
+message (`get_message` returns it / `send_message` receives it, `computation.py:63, 212`),
+so whole subtrees can live on different GPUs.  Dependencies follow the tree, so the parts
+should hang off a *small* top part: `subtree_owners` expands the heaviest frontier subtree
+(its root joins the top part, its children join the frontier) until no frontier subtree is
+heavier than an even share, then packs frontier subtrees onto ranks largest-first and
+gives the top part to the least loaded rank.
+"""
+
+__all__ = ["subtree_owners", "part_weights"]
+
+
+def subtree_owners(parent, weights, n_parts, slack=1.05):
+    """parent[c] = parent clique (-1 for the root), weights[c] = cost of clique c (table
+    bytes).  Returns owner[c] in [0, n_parts)."""
+    n = len(parent)
+    if n_parts <= 1:
+        return [0] * n
+    children = [[] for _ in range(n)]
+    root = 0
+    for c, p in enumerate(parent):
+        if p < 0:
+            root = c
+        else:
+            children[p].append(c)
+    order, stack = [], [root]
+    while stack:
+        c = stack.pop()
+        order.append(c)
+        stack.extend(children[c])
+    sub = list(weights)
+    for c in reversed(order):
+        if parent[c] >= 0:
+            sub[parent[c]] += sub[c]
+    share = sub[root] / float(n_parts)
+    frontier, top = [root], []
+    while True:
+        heavy = max(frontier, key=lambda c: sub[c])
+        if (sub[heavy] <= share * slack and len(frontier) >= n_parts) or not children[heavy]:
+            if not children[heavy] and sub[heavy] > share * slack and len(frontier) < n_parts:
+                # a heavy leaf cannot be split further; try the next heaviest expandable one
+                cands = [c for c in frontier if children[c]]
+                if not cands:
+                    break
+                heavy = max(cands, key=lambda c: sub[c])
+            else:
+                break
+        frontier.remove(heavy)
+        top.append(heavy)
+        frontier.extend(children[heavy])
+        if not frontier:
+            break
+    load = [0.0] * n_parts
+    owner = [0] * n
+    for c in sorted(frontier, key=lambda c: -sub[c]):
+        r = min(range(n_parts), key=lambda i: load[i])
+        load[r] += sub[c]
+        stack = [c]
+        while stack:
+            x = stack.pop()
+            owner[x] = r
+            stack.extend(children[x])
+    r = min(range(n_parts), key=lambda i: load[i])
+    for c in top:
+        owner[c] = r
+        load[r] += weights[c]
+    return owner
+
+
+def part_weights(owner, weights, n_parts):
+    out = [0.0] * n_parts
+    for o, w in zip(owner, weights):
+        out[o] += w
+    return out

@@ -1,0 +1,213 @@
+"""CPU emulation of the device task tables, for tests only.
+
+`jtp_plan_describe` exports every index table the HIP kernels consume (csrc/jtp_internal.h:
+JtTask / JtMsg).  This module executes those tables with numpy exactly the way
+csrc/jtp_kernels.hip.h `jt_pass` does - chunk decode, sub-box staging with partial-copy
+summation, incremental A/R loop offsets, per-thread slot offsets, partial-copy flush - so
+that the planner (layouts, F/A/R split, message buffers, level schedule) can be checked
+against the oracle on machines without a GPU.  It is a checker of the *plan*, not a compute
+path: nothing in the product imports it.
+"""
+
+import numpy as np
+
+JT_MAX_IN = 4
+
+
+def _ctz(n):
+    return (n & -n).bit_length() - 1
+
+
+def _loop_offsets(delta_rows, col, count):
+    """offsets[i] after i increments, built incrementally as the kernel does (mod 2^32)."""
+    out = np.zeros(count, dtype=np.int64)
+    cur = 0
+    for i in range(1, count):
+        cur = (cur + delta_rows[_ctz(i)][col]) & 0xFFFFFFFF
+        out[i] = cur
+    return out
+
+
+def _signed(v):
+    v = np.asarray(v, dtype=np.int64) & 0xFFFFFFFF
+    return np.where(v >= 2 ** 31, v - 2 ** 32, v)
+
+
+def _scatter(s, free_pos):
+    idx = np.zeros_like(s)
+    for b, pos in enumerate(free_pos):
+        idx += ((s >> b) & 1) << pos
+    return idx
+
+
+class Emulator:
+    def __init__(self, desc):
+        self.d = desc
+        self.VEC, self.EB, self.TB = desc["VEC"], desc["EB"], desc["TB"]
+        self.psi = np.zeros(max(desc["arena_elems"], 1), dtype=np.float64)
+        self.bel = np.zeros_like(self.psi)
+        self.msg = np.full(max(desc["msg_doubles"], 1), np.nan)     # NaN = never written
+
+    # ---------------------------------------------------------------- layout conversion
+    def _dev_index(self, pnode, host_vars, cards):
+        """device element index of every host C-order element of a clique"""
+        p = self.d["pnodes"][pnode]
+        pos = {v: (p["pos"][i], p["nb"][i]) for i, v in enumerate(p["vars"])}
+        n = int(np.prod(cards)) if cards else 1
+        digits = np.unravel_index(np.arange(n), cards) if cards else ()
+        x = np.zeros(n, dtype=np.int64)
+        for v, dig in zip(host_vars, digits):
+            x += dig.astype(np.int64) << pos[v][0]
+        return x
+
+    def set_potential(self, clique, host_vars, cards, array):
+        p = self.d["pnodes"][clique]
+        x = self._dev_index(clique, host_vars, cards)
+        lo = p["arena_off"]
+        self.psi[lo:lo + (1 << p["nbits"])] = 0.0
+        self.psi[lo + x] = np.broadcast_to(np.asarray(array, dtype=np.float64), cards).ravel()
+
+    def belief(self, clique, host_vars, cards):
+        p = self.d["pnodes"][clique]
+        x = self._dev_index(clique, host_vars, cards)
+        return self.bel[p["arena_off"] + x].reshape(cards)
+
+    def sep_belief(self, psep, host_vars, cards):
+        s = self.d["pseps"][psep]
+        pos = {v: s["pos"][i] for i, v in enumerate(s["vars"])}
+        n = int(np.prod(cards)) if cards else 1
+        digits = np.unravel_index(np.arange(n), cards) if cards else ()
+        x = np.zeros(n, dtype=np.int64)
+        for v, dig in zip(host_vars, digits):
+            x += dig.astype(np.int64) << pos[v]
+        size = 1 << s["nbits"]
+        up = sum(self.msg[s["up_off"] + p * size + x] for p in range(s["up_npart"]))
+        dn = sum(self.msg[s["dn_off"] + p * size + x] for p in range(s["dn_npart"]))
+        return (up * dn).reshape(cards)
+
+    # ---------------------------------------------------------------- one workgroup
+    def _block(self, tk, chunk, variant):
+        VEC, EB = self.VEC, self.EB
+        collect = variant < 4
+        n_in, n_out = tk["n_in"], tk["n_out"]
+        ins, outs = tk["in"], tk["out"]
+        xF = 0
+        gb_in, gb_out, pnum = [0] * n_in, [0] * n_out, [0] * n_out
+        for j in range(tk["nF"]):
+            if (chunk >> j) & 1:
+                xF += tk["f_x"][j]
+                for k in range(n_in):
+                    gb_in[k] += ins[k]["f_w"][j]
+                for k in range(n_out):
+                    gb_out[k] += outs[k]["f_w"][j]
+                    pnum[k] += outs[k]["f_p"][j]
+        # staging
+        subs = []
+        for k, m in enumerate(ins):
+            s = np.arange(1 << m["nfree"], dtype=np.int64)
+            idx = _scatter(s, m["free_pos"])
+            tot = np.zeros(len(s))
+            for p in range(m["npart"]):
+                tot = tot + self.msg[m["off"] + p * m["pstride"] + gb_in[k] + idx]
+            subs.append(tot)
+        osubs = [np.zeros(1 << m["nfree"]) for m in outs]
+
+        nA, nR = 1 << tk["nA"], 1 << tk["nR"]
+        tid = np.arange(256, dtype=np.int64)
+        lane, wave = tid & 63, tid >> 6
+
+        def thread_off(m):
+            t = np.zeros(256, dtype=np.int64)
+            for b in range(6):
+                t += ((lane >> b) & 1) * m["t_w"][b]
+            for b in range(2):
+                t += ((wave >> b) & 1) * m["t_w"][6 + b]
+            return t
+
+        def e_off(m):
+            return np.array([((e & 1) and m["e_w"][0]) + ((e & 2) and m["e_w"][1]) for e in range(VEC)],
+                            dtype=np.int64)
+
+        for m in outs:      # the kernel relies on: "reduce" bits have weight 0, others do not
+            for e in range(EB):
+                assert bool(m["red_e"] >> e & 1) == (m["e_w"][e] == 0)
+            for b in range(6):
+                assert bool(m["red_lane"] >> b & 1) == (m["t_w"][b] == 0)
+            for b in range(2):
+                assert bool(m["red_wave"] >> b & 1) == (m["t_w"][6 + b] == 0)
+        for m in ins:
+            assert bool(m["e_dep"]) == any(m["e_w"][e] != 0 for e in range(EB))
+
+        xa = _loop_offsets(tk["dA"], 0, nA)
+        xr = _loop_offsets(tk["dR"], 0, nR)
+        oa_in = [_signed(_loop_offsets(tk["dA"], 1 + k, nA)) for k in range(n_in)]
+        or_in = [_signed(_loop_offsets(tk["dR"], 1 + k, nR)) for k in range(n_in)]
+        oa_out = [_signed(_loop_offsets(tk["dA"], 1 + JT_MAX_IN + j, nA)) for j in range(n_out)]
+        for j in range(n_out):      # R bits never belong to an outgoing message
+            assert not np.any(_loop_offsets(tk["dR"], 1 + JT_MAX_IN + j, nR))
+
+        # element index of every (a, r, tid, e)
+        x = (xF + xa[:, None, None, None] + xr[None, :, None, None]
+             + (tid * VEC)[None, None, :, None] + np.arange(VEC)[None, None, None, :]) & 0xFFFFFFFF
+        assert x.max() < (1 << tk["nbits"])
+        assert len(np.unique(x)) == x.size            # every element visited exactly once
+        virt = tk["psi_off"] < 0
+        if virt:
+            p = (x < (1 << tk["real_bits"])).astype(np.float64)
+        else:
+            p = self.psi[tk["psi_off"] + x]
+        vals = []
+        for k, m in enumerate(ins):
+            slot = (oa_in[k][:, None, None, None] + or_in[k][None, :, None, None]
+                    + thread_off(m)[None, None, :, None] + e_off(m)[None, None, None, :])
+            assert slot.min() >= 0 and slot.max() < len(subs[k])
+            vals.append(subs[k][slot])
+        if collect:
+            q = p.copy()
+            for v in vals:
+                q = q * v
+            contrib = [q]
+        else:
+            npar = n_in - n_out
+            pre = p.copy()
+            for v in vals[:npar]:
+                pre = pre * v
+            contrib = []
+            for j in range(n_out):
+                q = pre.copy()
+                for i in range(n_out):
+                    if i != j:
+                        q = q * vals[npar + i]
+                contrib.append(q)
+            b = pre.copy()
+            for v in vals[npar:]:
+                b = b * v
+            if tk["bel_off"] >= 0:
+                self.bel[tk["bel_off"] + x] = b
+        for j, m in enumerate(outs):
+            slot = (oa_out[j][:, None, None, None] + np.zeros((1, nR, 1, 1), dtype=np.int64)
+                    + thread_off(m)[None, None, :, None] + e_off(m)[None, None, None, :])
+            assert slot.min() >= 0 and slot.max() < len(osubs[j])
+            np.add.at(osubs[j], slot.ravel(), contrib[j].ravel())
+        for j, m in enumerate(outs):
+            s = np.arange(1 << m["nfree"], dtype=np.int64)
+            dst = m["off"] + pnum[j] * m["pstride"] + gb_out[j] + _scatter(s, m["free_pos"])
+            assert np.all(np.isnan(self.msg[dst])), "a partial-copy entry is written twice"
+            self.msg[dst] = osubs[j]
+
+    # ---------------------------------------------------------------- whole schedule
+    def propagate(self):
+        d = self.d
+        self.msg[:] = np.nan
+        for kind, first, count in d["steps"]:
+            assert kind == 0, "the emulator runs single-rank plans"
+            launch = d["launches"][first]
+            blocks = d["blocks"][launch["blk_off"]:launch["blk_off"] + launch["nblocks"]]
+            seen = set()
+            for t, chunk in blocks:
+                tk = d["tasks"][t]
+                assert t in launch["tasks"] and d["tasks"][t]["variant"] == launch["variant"]
+                assert tk["lds_bytes"] <= launch["lds_bytes"]
+                seen.add((t, chunk))
+                self._block(tk, chunk, launch["variant"])
+            assert len(seen) == len(blocks) == sum(1 << d["tasks"][t]["nF"] for t in launch["tasks"])

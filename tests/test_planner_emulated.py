@@ -1,0 +1,160 @@
+"""Planner checks on the CPU: the task tables `jtp_plan_create` emits (JTP_PLAN_ONLY, no GPU
+needed) are executed by tests/emulator.py and compared with the oracle.  This pins layouts,
+the F/A/R loop split, message buffers with partial copies, virtual-clique binarisation and
+the level schedule; the HIP kernels consuming the same tables are checked on the GPU in
+tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import jt_oracle as oracle
+from conftest import as_tree
+from emulator import Emulator
+from junctiontree_amd import engine, synthetic
+
+
+def emulate(tree, potentials, node_vars, sizes, dtype="f64", **opts):
+    plan = engine.Plan(tree, node_vars, sizes, dtype=dtype, plan_only=True, **opts)
+    desc = plan.describe()
+    emu = Emulator(desc)
+    for c in plan.cliques:
+        ids = [plan.var_id[lab] for lab in node_vars[c]]
+        emu.set_potential(plan.abi_of[c], ids, [sizes[lab] for lab in node_vars[c]], potentials[c])
+    emu.propagate()
+    psep_of = {s["node"]: i for i, s in enumerate(desc["pseps"]) if s["node"] >= 0}
+    out = {}
+    for c in plan.cliques:
+        ids = [plan.var_id[lab] for lab in node_vars[c]]
+        out[c] = emu.belief(plan.abi_of[c], ids, [sizes[lab] for lab in node_vars[c]])
+    for s in plan.seps:
+        ids = [plan.var_id[lab] for lab in node_vars[s]]
+        out[s] = emu.sep_belief(psep_of[plan.abi_of[s]], ids, [sizes[lab] for lab in node_vars[s]])
+    plan.close()
+    return out, desc
+
+
+def check(tree, potentials, node_vars, sizes, **opts):
+    want = oracle.beliefs_exact(tree, potentials, node_vars)
+    stats = None
+    for dtype in ("f64", "f32"):
+        got, desc = emulate(tree, potentials, node_vars, sizes, dtype=dtype, **opts)
+        for n, arr in got.items():
+            full = np.broadcast_to(want[n], arr.shape)
+            np.testing.assert_allclose(arr, full, rtol=1e-11, atol=1e-13, err_msg="node %d" % n)
+        stats = desc
+    return stats
+
+
+def infer_sizes(potentials, node_vars):
+    sizes = {}
+    for p, labels in zip(potentials, node_vars):
+        for n, lab in zip(np.shape(p), labels):
+            sizes[lab] = max(sizes.get(lab, 1), n)
+    return sizes
+
+
+def test_reference_tree_cases(golden):
+    g = golden("tree_cases.npz")
+    for case in g.meta["cases"]:
+        pots = g.arrs(case["potentials"])
+        check(as_tree(case["tree"]), pots, case["variables"], infer_sizes(pots, case["variables"]))
+
+
+def test_divergent_cases(golden):
+    g = golden("divergent.npz")
+    for case in g.meta["cases"]:
+        if "tree" not in case:
+            continue
+        pots = g.arrs(case["potentials"])
+        check(as_tree(case["tree"]), pots, case["variables"], infer_sizes(pots, case["variables"]))
+
+
+@pytest.mark.parametrize("opts", [
+    {}, {"block_log2": 10}, {"block_log2": 11, "lds_budget": 256}, {"layout_policy": 1},
+    {"layout_policy": 1, "block_log2": 10, "lds_budget": 128},
+])
+def test_synthetic_trees(opts):
+    specs = [
+        synthetic.chain_tree(n_cliques=5, card=4, width=3),
+        synthetic.chain_tree(n_cliques=4, card=16, width=3),
+        synthetic.chain_tree(n_cliques=4, card=3, width=3),
+        synthetic.wide_binary_tree(n_cliques=7, width=12, sep=6, card=2, seed=1),
+        synthetic.wide_binary_tree(n_cliques=6, width=14, sep=7, card=2, seed=2),
+        synthetic.wide_binary_tree(n_cliques=7, width=5, sep=2, card=3, seed=4),
+        synthetic.random_tree(n_cliques=9, width=11, sep=5, card=2, seed=3),
+        synthetic.random_tree(n_cliques=8, width=4, sep=2, card=5, seed=6),
+    ]
+    for spec in specs:
+        pots = synthetic.potentials_for(spec, seed=21)
+        desc = check(spec["tree"], pots, spec["node_vars"], spec["sizes"], **opts)
+        assert desc["n_messages"] == 2 * (spec["n_cliques"] - 1)
+
+
+def star(n_children, card=2, seed=0):
+    rng = np.random.default_rng(seed)
+    hub = list(range(6))
+    node_vars = [hub]
+    nxt = 6
+    for _ in range(n_children):
+        shared = [hub[i] for i in rng.choice(6, size=int(rng.integers(1, 4)), replace=False)]
+        node_vars.append(shared + [nxt, nxt + 1])
+        nxt += 2
+    n = n_children + 1
+    seps = [[v for v in node_vars[c] if v in hub] for c in range(1, n)]
+    tree = [0] + [(n + i, [1 + i]) for i in range(n_children)]
+    sizes = {v: card for v in range(nxt)}
+    node_vars = node_vars + seps
+    pots = [rng.uniform(0.5, 1.5, [card] * len(vs)) for vs in node_vars[:n]]
+    pots += [np.ones([card] * len(vs)) for vs in seps]
+    return tree, pots, node_vars, sizes
+
+
+@pytest.mark.parametrize("n_children", [4, 5, 7, 10, 13])
+def test_many_children_use_virtual_cliques(n_children):
+    tree, pots, node_vars, sizes = star(n_children, card=2, seed=n_children)
+    desc = check(tree, pots, node_vars, sizes)
+    assert any(p["real"] < 0 for p in desc["pnodes"])
+    assert all(len(p["children"]) <= 3 for p in desc["pnodes"])
+    tree, pots, node_vars, sizes = star(n_children, card=3, seed=n_children)
+    check(tree, pots, node_vars, sizes, block_log2=10)
+
+
+def test_broadcast_axes_and_card_one():
+    # clique 1's potential is constant along variable 9 (length-1 axis), variable 4 has cardinality 1
+    tree = [0, (2, [1])]
+    node_vars = [[3, 5, 4], [5, 9], [5]]
+    sizes = {3: 2, 5: 3, 4: 1, 9: 4}
+    rng = np.random.default_rng(0)
+    pots = [rng.standard_normal((2, 3, 1)), rng.standard_normal((3, 1)), np.ones(3)]
+    got, _ = emulate(tree, pots, node_vars, sizes)
+    full = [pots[0], np.broadcast_to(pots[1], (3, 4)).copy(), pots[2]]
+    want = oracle.beliefs_exact(tree, full, node_vars)
+    for n in range(3):
+        np.testing.assert_allclose(got[n], want[n], rtol=1e-11, atol=1e-13)
+
+
+def test_invalid_structures_are_rejected():
+    with pytest.raises(ValueError):      # separator variable missing from the parent clique
+        engine.Plan([0, (2, [1])], [[1, 2], [2, 3], [3]], {1: 2, 2: 2, 3: 2}, plan_only=True)
+    with pytest.raises(ValueError):      # clique index used twice
+        engine.Plan([0, (2, [0])], [[1, 2], [2, 3], [2]], {1: 2, 2: 2, 3: 2}, plan_only=True)
+    with pytest.raises(KeyError):        # unknown variable size, like the reference (junctiontree.py:313)
+        engine.Plan([0], [[1, 2]], {1: 2}, plan_only=True)
+    with pytest.raises(ValueError):      # table too large for one plan
+        engine.Plan([0], [list(range(40))], {v: 2 for v in range(40)}, plan_only=True)
+
+
+def test_full_scale_configs_plan():
+    """C4 and C2 at BASELINE.json's sizes: plan only (no tables are allocated)."""
+    spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", plan_only=True)
+    d = plan.describe()
+    assert d["n_messages"] == 510 and d["arena_elems"] == 256 << 20
+    assert abs(d["alg_bytes"] / 1e9 - 3.22) < 0.03
+    assert d["max_lds"] <= 64 * 1024
+    assert max(max(s["up_npart"], s["dn_npart"]) for s in d["pseps"]) <= 8
+    plan.close()
+    spec = synthetic.chain_tree(n_cliques=1000, card=64, width=3)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", plan_only=True)
+    d = plan.describe()
+    assert d["n_messages"] == 1998 and len(d["launches"]) == 1999
+    plan.close()
