@@ -142,7 +142,7 @@ class Plan:
         arr = np.asarray(array)
         if arr.dtype not in (np.float32, np.float64):
             arr = arr.astype(np.float64)
-        arr = np.ascontiguousarray(arr)
+        arr = np.ascontiguousarray(arr).reshape(arr.shape)      # ascontiguousarray makes 0-d 1-d
         full = self.node_shape[node]
         if arr.ndim != len(full):
             raise ValueError("potential of node %r has %d axes, its variable list has %d"
