@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--block-log2", type=int, default=0)
     ap.add_argument("--lds-budget", type=int, default=0)
     ap.add_argument("--layout-policy", type=int, default=0)
+    ap.add_argument("--per-launch", action="store_true", help="print per-launch device times to stderr")
+    ap.add_argument("--split-variants", action="store_true",
+                    help="one launch per (level, clique shape): per-shape timings (profiling aid)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +115,7 @@ def main():
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=args.dtype,
                        device=local_rank, n_ranks=world, rank=rank, owner=owner,
                        block_log2=args.block_log2, lds_budget=args.lds_budget,
-                       layout_policy=args.layout_policy)
+                       layout_policy=args.layout_policy, split_variants=args.split_variants)
     plan.fill_synthetic(1, spec["scales"])
 
     for _ in range(args.warmup):
@@ -136,6 +139,11 @@ def main():
 
     stats = plan.stats()
     z = plan.z() if plan.owns(plan.root) else None
+    if args.per_launch and not args.no_profile and rank == 0:
+        for L in plan.launch_ms():
+            print("# %s level %d: %4d tasks %5d blocks %8.4f ms %7.0f GB/s" % (
+                "collect   " if L["phase"] == 0 else "distribute", L["level"], L["ntasks"], L["nblocks"],
+                L["ms"], L["alg_bytes"] / max(L["ms"], 1e-9) / 1e6), file=sys.stderr)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

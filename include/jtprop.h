@@ -36,6 +36,8 @@ extern "C" {
 #define JTP_F64 1           /* clique tables stored as double                           */
 
 #define JTP_PLAN_ONLY 1u    /* jtp_tree_desc.flags: plan on the host only, touch no GPU  */
+#define JTP_SPLIT_VARIANTS 2u /* one launch per (level, neighbour count) instead of per level:
+                               profiling aid, attributes device time to each clique shape   */
 
 typedef struct jtp_plan jtp_plan;
 
@@ -60,7 +62,7 @@ typedef struct jtp_tree_desc {
     int32_t n_ranks;                /* processes sharing the tree (1 = single GPU)           */
     int32_t rank;                   /* this process                                          */
     const int32_t *clique_owner;    /* [n_cliques] owning rank, or NULL (all rank 0)         */
-    uint32_t flags;                 /* JTP_PLAN_ONLY                                         */
+    uint32_t flags;                 /* JTP_PLAN_ONLY | JTP_SPLIT_VARIANTS                    */
     int32_t lds_budget;             /* bytes of LDS per workgroup the planner may use, 0=default */
     int32_t block_log2;             /* log2 of target elements per workgroup, 0 = automatic  */
     int32_t layout_policy;          /* 0 = default heuristic, 1 = keep host axis order       */
@@ -140,6 +142,9 @@ int jtp_get_z(jtp_plan *plan, int32_t batch, double *z);
  * jtp_get_stats then reports per-variant device time as the mean per propagate. */
 int jtp_set_profiling(jtp_plan *plan, int32_t keep);
 int jtp_get_stats(jtp_plan *plan, jtp_stats *stats);
+/* Mean device time (ms) of each of the plan's launches, in schedule order; `n` = capacity of
+ * `ms`.  Returns the number of launches (or a negative error).  Needs jtp_set_profiling. */
+int jtp_get_launch_ms(jtp_plan *plan, double *ms, int32_t n);
 /* Name of kernel variant i as it appears in rocprofv3 traces, or NULL past the last one. */
 const char *jtp_kernel_name(int32_t variant);
 

@@ -94,12 +94,12 @@ static int load() {
 
 // ------------------------------------------------------------------------------------------ plan object
 
-typedef void (*jt_kernel_f32)(const JtTask *, const uint2 *, const float *, float *, double *);
-typedef void (*jt_kernel_f64)(const JtTask *, const uint2 *, const double *, double *, double *);
+typedef void (*jt_kernel_f32)(const JtTask *, const JtBlock *, const float *, float *, double *);
+typedef void (*jt_kernel_f64)(const JtTask *, const JtBlock *, const double *, double *, double *);
 
 template <typename T>
 struct KernelTable {
-    typedef void (*fn)(const JtTask *, const uint2 *, const T *, T *, double *);
+    typedef void (*fn)(const JtTask *, const JtBlock *, const T *, T *, double *);
     static fn get(int variant) {
         switch (variant) {
             case JT_K_COLLECT0: return jt_collect<T, 0>;
@@ -114,6 +114,8 @@ struct KernelTable {
             case JT_K_DIST_P1C1: return jt_distribute<T, 1, 1>;
             case JT_K_DIST_P1C2: return jt_distribute<T, 1, 2>;
             case JT_K_DIST_P1C3: return jt_distribute<T, 1, 3>;
+            case JT_K_COLLECT_LEVEL: return jt_collect_level<T>;
+            case JT_K_DISTRIBUTE_LEVEL: return jt_distribute_level<T>;
         }
         return nullptr;
     }
@@ -123,6 +125,7 @@ static const char *k_names[JT_K_COUNT] = {
     "jt_collect<T, 0>", "jt_collect<T, 1>", "jt_collect<T, 2>", "jt_collect<T, 3>",
     "jt_distribute<T, 0, 0>", "jt_distribute<T, 0, 1>", "jt_distribute<T, 0, 2>", "jt_distribute<T, 0, 3>",
     "jt_distribute<T, 1, 0>", "jt_distribute<T, 1, 1>", "jt_distribute<T, 1, 2>", "jt_distribute<T, 1, 3>",
+    "jt_collect_level<T>", "jt_distribute_level<T>",
 };
 
 struct BatchBuffers {
@@ -137,7 +140,7 @@ struct jtp_plan {
     std::vector<hipStream_t> streams;
     std::vector<BatchBuffers> bufs;
     JtTask *d_tasks = nullptr;
-    uint2 *d_blocks = nullptr;
+    JtBlock *d_blocks = nullptr;
     void *stage = nullptr;          // device staging buffer for host<->device conversion
     size_t stage_bytes = 0;
     int prof_steps = 0;             // 0: off; else ring of this many event sets
@@ -257,13 +260,22 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         CREATE_TRY(hipMemsetAsync(b.bel, 0, abytes, pl->streams[0]));
         CREATE_TRY(hipMemsetAsync(b.msg, 0, mbytes, pl->streams[0]));
     }
+    for (auto &b : pl->bufs) {
+        for (const VirtualFill &vf : hp.virtual_fills) {
+            const int64_t n = (int64_t)1 << vf.nbits;
+            const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+            if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_fill_ones<float>), dim3(grid), dim3(256), 0, pl->streams[0], (float *)b.psi, vf.off, vf.nbits, vf.real_bits);
+            else hipLaunchKernelGGL((jt_fill_ones<double>), dim3(grid), dim3(256), 0, pl->streams[0], (double *)b.psi, vf.off, vf.nbits, vf.real_bits);
+        }
+        CREATE_TRY(hipGetLastError());
+    }
     if (!hp.tasks.empty()) {
         CREATE_TRY(hipMalloc((void **)&pl->d_tasks, hp.tasks.size() * sizeof(JtTask)));
         CREATE_TRY(hipMemcpy(pl->d_tasks, hp.tasks.data(), hp.tasks.size() * sizeof(JtTask), hipMemcpyHostToDevice));
     }
     if (!hp.blocks.empty()) {
-        CREATE_TRY(hipMalloc((void **)&pl->d_blocks, hp.blocks.size() * sizeof(BlockRef)));
-        CREATE_TRY(hipMemcpy(pl->d_blocks, hp.blocks.data(), hp.blocks.size() * sizeof(BlockRef), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc((void **)&pl->d_blocks, hp.blocks.size() * sizeof(JtBlock)));
+        CREATE_TRY(hipMemcpy(pl->d_blocks, hp.blocks.data(), hp.blocks.size() * sizeof(JtBlock), hipMemcpyHostToDevice));
     }
     if (hp.max_lds > 64 * 1024) {
         for (int v = 0; v < JT_K_COUNT; ++v) {
@@ -362,7 +374,7 @@ int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double 
 // ------------------------------------------------------------------------------------------ compute
 
 static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipStream_t s, const JtTask *tasks,
-                          const uint2 *blocks, void *psi, void *bel, double *msg) {
+                          const JtBlock *blocks, void *psi, void *bel, double *msg) {
     if (pl->hp.dtype == JTP_F32) {
         auto f = KernelTable<float>::get(variant);
         hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, (const float *)psi, (float *)bel, msg);
@@ -500,7 +512,7 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
             if (ov[i] == ov[j]) return set_err(JTP_EINVAL, "variable %d requested twice", ov[i]);
     JtTask tk;
     int out_bits = 0, npart = 1;
-    std::vector<BlockRef> blocks;
+    std::vector<JtBlock> blocks;
     std::string err;
     rc = jtp_plan_marginal_task(hp, clique, ov, tk, out_bits, npart, blocks, err);
     if (rc) return set_err(rc, "%s", err.c_str());
@@ -510,13 +522,13 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
     const int64_t pstride = (int64_t)1 << out_bits;
     double *scratch = nullptr;
     JtTask *d_task = nullptr;
-    uint2 *d_blk = nullptr;
+    JtBlock *d_blk = nullptr;
     HIP_TRY(hipMalloc((void **)&scratch, (size_t)pstride * npart * 8));
     HIP_TRY(hipMalloc((void **)&d_task, sizeof(JtTask)));
-    HIP_TRY(hipMalloc((void **)&d_blk, blocks.size() * sizeof(BlockRef)));
+    HIP_TRY(hipMalloc((void **)&d_blk, blocks.size() * sizeof(JtBlock)));
     tk.msg[JT_MAX_IN].off = 0;
     HIP_TRY(hipMemcpyAsync(d_task, &tk, sizeof tk, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_blk, blocks.data(), blocks.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_blk, blocks.data(), blocks.size() * sizeof(JtBlock), hipMemcpyHostToDevice, s));
     if (tk.lds_bytes > 64 * 1024) {
         const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_COLLECT0) : (const void *)KernelTable<double>::get(JT_K_COLLECT0);
         HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tk.lds_bytes));
@@ -607,6 +619,26 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
         }
     }
     return JTP_OK;
+}
+
+int jtp_get_launch_ms(jtp_plan *pl, double *out, int32_t n) {
+    if (!pl) return set_err(JTP_EINVAL, "null plan");
+    HostPlan &hp = pl->hp;
+    const int nl = (int)hp.launches.size();
+    if (!(pl->device && pl->prof_steps > 0 && pl->prof_cursor > 0)) return set_err(JTP_EINVAL, "profiling is off or nothing was recorded");
+    HIP_TRY(hipSetDevice(hp.device));
+    const int kept = std::min(pl->prof_cursor, pl->prof_steps);
+    for (int i = 0; i < nl && i < n; ++i) out[i] = 0.0;
+    for (int k = 0; k < kept; ++k) {
+        const size_t base = 2 * hp.launches.size() * (size_t)k;
+        for (int i = 0; i < nl && i < n; ++i) {
+            HIP_TRY(hipEventSynchronize(pl->ev[base + 2 * i + 1]));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, pl->ev[base + 2 * i], pl->ev[base + 2 * i + 1]));
+            out[i] += ms / kept;
+        }
+    }
+    return nl;
 }
 
 // ------------------------------------------------------------------------------------------ multi-GPU

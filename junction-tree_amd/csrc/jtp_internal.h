@@ -41,7 +41,7 @@ struct JtMsg {
 };
 
 struct JtTask {
-    int64_t psi_off;           // element offset in the potential arena; < 0: virtual all-ones clique
+    int64_t psi_off;           // element offset in the potential arena (virtual cliques: a 0/1 table)
     int64_t bel_off;           // element offset in the belief arena; < 0: belief not written
     int32_t nbits;             // index bits of the (padded) clique table, >= TB
     int32_t nF, nA, nR;
@@ -54,6 +54,14 @@ struct JtTask {
     int32_t dA[JT_MAX_HI][JT_NCOL];   // A-loop increments: going from a to a+1 adds dA[ctz(a+1)]
     int32_t dR[JT_MAX_HI][JT_NCOL];   // R-loop increments
     JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing
+};
+
+// one workgroup: which task, and the chunk's decoded bases (so the kernel does no bit decode)
+struct JtBlock {
+    uint32_t task;             // index into the task table
+    uint32_t xF;               // element offset of the chunk (F bits deposited)
+    int32_t gbase[JT_MAX_MSG]; // per message: global-index base of the chunk's sub-box
+    int32_t pnum[JT_MAX_OUT];  // per outgoing message: partial-copy number written by this chunk
 };
 
 // host <-> device layout conversion of one table (pack / unpack / synthetic fill)
@@ -73,5 +81,6 @@ enum {
     JT_K_COLLECT0 = 0, JT_K_COLLECT1, JT_K_COLLECT2, JT_K_COLLECT3,
     JT_K_DIST_P0C0, JT_K_DIST_P0C1, JT_K_DIST_P0C2, JT_K_DIST_P0C3,
     JT_K_DIST_P1C0, JT_K_DIST_P1C1, JT_K_DIST_P1C2, JT_K_DIST_P1C3,
+    JT_K_COLLECT_LEVEL, JT_K_DISTRIBUTE_LEVEL,      // one launch per tree level (default)
     JT_K_COUNT
 };

@@ -38,56 +38,102 @@ __device__ __forceinline__ double jt_shfl_xor(double v, int laneMask) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ int jt_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// message-index bit of sub-box index bit b (free_pos[] packed four per word)
+#define JT_FPOS(fp, b) (((fp)[(b) >> 2] >> (8 * ((b) & 3))) & 0xffu)
+
 template <typename T, int NIN, int NOUT, int MODE>
-__device__ __forceinline__ void jt_pass(const JtTask *__restrict__ tasks, const uint2 *__restrict__ blk,
+__device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
                                         double *__restrict__ msg_arena) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int EB = (VEC == 4) ? 2 : 1;
     constexpr int NMSG = NIN + NOUT;
+    constexpr int NPAR = NIN - NOUT * (MODE == 1);   // distribute: leading inputs that are not children
+    constexpr int U = 4;                             // element loads in flight per wave
     using VT = typename JtVec<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const uint2 bt = blk[blockIdx.x];
-    const JtTask &tk = tasks[bt.x];
-    const uint32_t chunk = bt.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // ---- chunk decode: element base, message bases, partial-copy numbers ----------------
-    uint32_t xF = 0;
-    int gbase[NMSG > 0 ? NMSG : 1];
-    int pnum[NOUT > 0 ? NOUT : 1];
+    const uint32_t xF = bk.xF + (uint32_t)tid * VEC;
+    const bool wbel = (MODE == 1) && tk.bel_off >= 0;
+    const T *psi = psi_arena + tk.psi_off;
+    T *bel = bel_arena + (wbel ? tk.bel_off : 0);
+    const int nA = 1 << tk.nA, nR = 1 << tk.nR;
+    const int total = nA * nR;
+
+    // ---- loop increment tables live in lanes: lane t < 32 holds row t of dR, lane 32 + t row t
+    //      of dA; a wave reads "row t, column c" with v_readlane (no memory access in the loops)
+    int dcol[1 + (NMSG > 0 ? NMSG : 1)];
+    {
+        const int t = lane & 31;
+        const int32_t *row = (lane >= 32) ? tk.dA[t < JT_MAX_HI ? t : 0] : tk.dR[t < JT_MAX_HI ? t : 0];
+        const bool ok = t < JT_MAX_HI;
+        dcol[0] = ok ? row[0] : 0;
 #pragma unroll
-    for (int k = 0; k < NMSG; ++k) gbase[k] = 0;
+        for (int k = 0; k < NIN; ++k) dcol[1 + k] = ok ? row[1 + k] : 0;
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) pnum[k] = 0;
-    for (int j = 0; j < tk.nF; ++j) {
-        if ((chunk >> j) & 1u) {
-            xF += tk.f_x[j];
-#pragma unroll
-            for (int k = 0; k < NIN; ++k) gbase[k] += tk.msg[k].f_w[j];
-#pragma unroll
-            for (int k = 0; k < NOUT; ++k) {
-                gbase[NIN + k] += tk.msg[JT_MAX_IN + k].f_w[j];
-                pnum[k] += tk.msg[JT_MAX_IN + k].f_p[j];
-            }
-        }
+        for (int j = 0; j < NOUT; ++j) dcol[1 + NIN + j] = ok ? row[1 + JT_MAX_IN + j] : 0;
     }
 
+    // ---- element loads: a producer counter runs U iterations ahead of the consumer ---------
+    int pi = 0, pa = 0, pr = 0;
+    uint32_t pxa = 0, pxr = 0;
+    auto issue = [&](VT &slot) {
+        if (pi < total) {
+            slot = *reinterpret_cast<const VT *>(psi + (xF + pxa + pxr));
+            ++pi;
+            if (pr + 1 < nR) {
+                pxr += (uint32_t)jt_readlane(dcol[0], __builtin_ctz((unsigned)(pr + 1)));
+                ++pr;
+            } else {
+                pr = 0;
+                pxr = 0;
+                if (pa + 1 < nA) pxa += (uint32_t)jt_readlane(dcol[0], 32 + __builtin_ctz((unsigned)(pa + 1)));
+                ++pa;
+            }
+        }
+    };
+    VT q0 = VT(), q1 = VT(), q2 = VT(), q3 = VT();
+    issue(q0);
+    issue(q1);
+    issue(q2);
+    issue(q3);
+
     // ---- stage incoming sub-boxes (summing partial copies), zero outgoing sub-boxes -----
+    // (the first element loads are already in flight)
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         const JtMsg &m = tk.msg[k];
         double *sub = reinterpret_cast<double *>(smem + m.lds_off);
-        const double *src = msg_arena + m.off + gbase[k];
-        const int n = 1 << m.nfree;
-        for (int s = tid; s < n; s += JT_THREADS) {
-            int idx = 0;
-            for (int b = 0; b < m.nfree; ++b) idx += ((s >> b) & 1) << m.free_pos[b];
+        const double *src = msg_arena + m.off + bk.gbase[k];
+        const int nfree = m.nfree;
+        const int n = 1 << nfree;
+        const int npart = m.npart;
+        const int64_t ps = m.pstride;
+        const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+        const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
+        int idx_t = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (b < nfree) idx_t += ((tid >> b) & 1) << JT_FPOS(fp, b);
+        for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
+            int idx = idx_t;
+#pragma unroll
+            for (int b = 8; b < JT_MAX_FREE; ++b)
+                if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
             double sum = 0.0;
-            for (int p = 0; p < m.npart; ++p) sum += src[(int64_t)p * m.pstride + idx];
+            for (int p = 0; p < npart; p += 4) {          // four copies in flight, summed in copy order
+                const double c0 = src[(int64_t)p * ps + idx];
+                const double c1 = (p + 1 < npart) ? src[(int64_t)(p + 1) * ps + idx] : 0.0;
+                const double c2 = (p + 2 < npart) ? src[(int64_t)(p + 2) * ps + idx] : 0.0;
+                const double c3 = (p + 3 < npart) ? src[(int64_t)(p + 3) * ps + idx] : 0.0;
+                sum = (((sum + c0) + c1) + c2) + c3;
+            }
             sub[s] = sum;
         }
     }
@@ -104,6 +150,7 @@ __device__ __forceinline__ void jt_pass(const JtTask *__restrict__ tasks, const 
     int thr[NMSG > 0 ? NMSG : 1];
     const double *in_sub[NIN > 0 ? NIN : 1];
     double *out_sub[NOUT > 0 ? NOUT : 1];
+    int in_ew0[NIN > 0 ? NIN : 1], in_ew1[NIN > 0 ? NIN : 1], in_edep[NIN > 0 ? NIN : 1];
 #pragma unroll
     for (int k = 0; k < NMSG; ++k) {
         const JtMsg &m = tk.msg[k < NIN ? k : JT_MAX_IN + (k - NIN)];
@@ -113,58 +160,102 @@ __device__ __forceinline__ void jt_pass(const JtTask *__restrict__ tasks, const 
 #pragma unroll
         for (int b = 0; b < 2; ++b) t += ((wave >> b) & 1) * m.t_w[6 + b];
         thr[k] = t;
-        if (k < NIN) in_sub[k < NIN ? k : 0] = reinterpret_cast<const double *>(smem + m.lds_off);
-        else out_sub[k >= NIN ? k - NIN : 0] = reinterpret_cast<double *>(smem + m.lds_off);
+        if (k < NIN) {
+            in_sub[k < NIN ? k : 0] = reinterpret_cast<const double *>(smem + m.lds_off);
+            in_ew0[k < NIN ? k : 0] = m.e_w[0];
+            in_ew1[k < NIN ? k : 0] = m.e_w[1];
+            in_edep[k < NIN ? k : 0] = m.e_dep;
+        } else {
+            out_sub[k >= NIN ? k - NIN : 0] = reinterpret_cast<double *>(smem + m.lds_off);
+        }
     }
 
-    const bool virt = tk.psi_off < 0;
-    const bool wbel = (MODE == 1) && tk.bel_off >= 0;
-    const T *psi = psi_arena + (virt ? 0 : tk.psi_off);
-    T *bel = bel_arena + (wbel ? tk.bel_off : 0);
-    const uint32_t real_limit = tk.real_bits >= 32 ? 0xffffffffu : (1u << tk.real_bits);
-    const int nA = 1 << tk.nA, nR = 1 << tk.nR;
-    constexpr int NPAR = NIN - NOUT * (MODE == 1);   // distribute: leading inputs that are not children
-
-    uint32_t xa = 0;
-    int oa[NMSG > 0 ? NMSG : 1];
+    // ---- consumer state ------------------------------------------------------------------------
+    int ci = 0, ca = 0, cr = 0;
+    uint32_t xa = 0, xr = 0;
+    int oa[NMSG > 0 ? NMSG : 1], orr[NIN > 0 ? NIN : 1];
 #pragma unroll
     for (int k = 0; k < NMSG; ++k) oa[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) orr[k] = 0;
+    double acc[NOUT > 0 ? NOUT : 1][VEC];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[j][e] = 0.0;
 
-    for (int a = 0; a < nA; ++a) {
-        double acc[NOUT > 0 ? NOUT : 1][VEC];
+    // fold this thread's sums of one A iteration into the outgoing sub-boxes
+    auto epilogue = [&]() {
 #pragma unroll
-        for (int j = 0; j < NOUT; ++j)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[j][e] = 0.0;
-        uint32_t xr = 0;
-        int orr[NIN > 0 ? NIN : 1];
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) orr[k] = 0;
-
-        for (int r = 0; r < nR; ++r) {
-            const uint32_t x = xF + xa + xr + (uint32_t)tid * VEC;
-            double p[VEC];
-            if (!virt) {
-                const VT v = *reinterpret_cast<const VT *>(psi + x);
-                p[0] = (double)v.x;
-                p[1] = (double)v.y;
-                if constexpr (VEC == 4) {
-                    p[2] = (double)v.z;
-                    p[3] = (double)v.w;
+        for (int j = 0; j < NOUT; ++j) {
+            const JtMsg &m = tk.msg[JT_MAX_IN + j];
+            const int red_e = m.red_e, red_lane = m.red_lane, red_wave = m.red_wave;
+            if constexpr (VEC == 4) {
+                if (red_e & 1) {
+                    acc[j][0] += acc[j][1];
+                    acc[j][2] += acc[j][3];
+                }
+                if (red_e & 2) {
+                    acc[j][0] += acc[j][2];
+                    acc[j][1] += acc[j][3];
                 }
             } else {
+                if (red_e & 1) acc[j][0] += acc[j][1];
+            }
+#pragma nounroll
+            for (int b = 0; b < 6; ++b) {
+                if ((red_lane >> b) & 1) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) p[e] = (x + e) < real_limit ? 1.0 : 0.0;
+                    for (int e = 0; e < VEC; ++e)
+                        if ((e & red_e) == 0) acc[j][e] += jt_shfl_xor(acc[j][e], 1 << b);
+                }
+            }
+            const bool rep = (lane & red_lane) == 0;
+            const int slot = oa[NIN + j] + thr[NIN + j];
+            const int nph = 1 << __builtin_popcount((unsigned)red_wave);
+            // waves that share slots (wave bits not in the message) take turns, in wave order
+            int myph = 0;
+            if (red_wave == 1) myph = wave & 1;
+            else if (red_wave == 2) myph = wave >> 1;
+            else if (red_wave == 3) myph = wave;
+            for (int ph = 0; ph < nph; ++ph) {
+                if (rep && myph == ph) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if ((e & red_e) == 0) {
+                            const int eo = ((e & 1) ? m.e_w[0] : 0) + ((e & 2) ? m.e_w[1] : 0);
+                            out_sub[j][slot + eo] += acc[j][e];
+                        }
+                    }
+                }
+                if (nph > 1) __syncthreads();
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[j][e] = 0.0;
+        }
+    };
+
+    // one iteration: consume `slot`, refill it for iteration ci + U, multiply, accumulate
+    auto step = [&](VT &slot) {
+        if (ci < total) {
+            const VT v = slot;
+            issue(slot);
+            const uint32_t x = xF + xa + xr;
+            double p[VEC];
+            p[0] = (double)v.x;
+            p[1] = (double)v.y;
+            if constexpr (VEC == 4) {
+                p[2] = (double)v.z;
+                p[3] = (double)v.w;
             }
             double in[NIN > 0 ? NIN : 1][VEC];
 #pragma unroll
             for (int k = 0; k < NIN; ++k) {
-                const JtMsg &m = tk.msg[k];
                 const int base = oa[k] + orr[k] + thr[k];
-                if (m.e_dep) {
+                if (in_edep[k]) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
-                        const int eo = ((e & 1) ? m.e_w[0] : 0) + ((e & 2) ? m.e_w[1] : 0);
+                        const int eo = ((e & 1) ? in_ew0[k] : 0) + ((e & 2) ? in_ew1[k] : 0);
                         in[k][e] = in_sub[k][base + eo];
                     }
                 } else {
@@ -176,10 +267,10 @@ __device__ __forceinline__ void jt_pass(const JtTask *__restrict__ tasks, const 
             if constexpr (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    double q = p[e];
+                    double w = p[e];
 #pragma unroll
-                    for (int k = 0; k < NIN; ++k) q *= in[k][e];
-                    if constexpr (NOUT > 0) acc[0][e] += q;
+                    for (int k = 0; k < NIN; ++k) w *= in[k][e];
+                    if constexpr (NOUT > 0) acc[0][e] += w;
                 }
             } else {
                 double b[VEC];
@@ -212,67 +303,35 @@ __device__ __forceinline__ void jt_pass(const JtTask *__restrict__ tasks, const 
                     *reinterpret_cast<VT *>(bel + x) = o;
                 }
             }
-            if (r + 1 < nR) {
-                const int t = __builtin_ctz((unsigned)(r + 1));
-                xr += (uint32_t)tk.dR[t][0];
+            ++ci;
+            if (cr + 1 < nR) {
+                const int t = __builtin_ctz((unsigned)(cr + 1));
+                xr += (uint32_t)jt_readlane(dcol[0], t);
 #pragma unroll
-                for (int k = 0; k < NIN; ++k) orr[k] += tk.dR[t][1 + k];
-            }
-        }
-
-        // ---- epilogue: fold this thread's sums into the outgoing sub-boxes ------------------
-#pragma unroll
-        for (int j = 0; j < NOUT; ++j) {
-            const JtMsg &m = tk.msg[JT_MAX_IN + j];
-            if constexpr (VEC == 4) {
-                if (m.red_e & 1) {
-                    acc[j][0] += acc[j][1];
-                    acc[j][2] += acc[j][3];
-                }
-                if (m.red_e & 2) {
-                    acc[j][0] += acc[j][2];
-                    acc[j][1] += acc[j][3];
-                }
+                for (int k = 0; k < NIN; ++k) orr[k] += jt_readlane(dcol[1 + k], t);
+                ++cr;
             } else {
-                if (m.red_e & 1) acc[j][0] += acc[j][1];
-            }
+                if constexpr (NOUT > 0) epilogue();
+                cr = 0;
+                xr = 0;
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                if ((m.red_lane >> b) & 1) {
+                for (int k = 0; k < NIN; ++k) orr[k] = 0;
+                if (ca + 1 < nA) {
+                    const int t = 32 + __builtin_ctz((unsigned)(ca + 1));
+                    xa += (uint32_t)jt_readlane(dcol[0], t);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        if ((e & m.red_e) == 0) acc[j][e] += jt_shfl_xor(acc[j][e], 1 << b);
+                    for (int k = 0; k < NMSG; ++k) oa[k] += jt_readlane(dcol[1 + k], t);
                 }
-            }
-            const bool rep = (lane & m.red_lane) == 0;
-            const int slot = oa[NIN + j] + thr[NIN + j];
-            const int nph = 1 << __builtin_popcount((unsigned)m.red_wave);
-            // waves that share slots (wave bits not in the message) take turns, in wave order
-            int myph = 0;
-            if (m.red_wave == 1) myph = wave & 1;
-            else if (m.red_wave == 2) myph = wave >> 1;
-            else if (m.red_wave == 3) myph = wave;
-            for (int ph = 0; ph < nph; ++ph) {
-                if (rep && myph == ph) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        if ((e & m.red_e) == 0) {
-                            const int eo = ((e & 1) ? m.e_w[0] : 0) + ((e & 2) ? m.e_w[1] : 0);
-                            out_sub[j][slot + eo] += acc[j][e];
-                        }
-                    }
-                }
-                if (nph > 1) __syncthreads();
+                ++ca;
             }
         }
-        if (a + 1 < nA) {
-            const int t = __builtin_ctz((unsigned)(a + 1));
-            xa += (uint32_t)tk.dA[t][0];
-#pragma unroll
-            for (int k = 0; k < NIN; ++k) oa[k] += tk.dA[t][1 + k];
-#pragma unroll
-            for (int j = 0; j < NOUT; ++j) oa[NIN + j] += tk.dA[t][1 + JT_MAX_IN + j];
-        }
+    };
+
+    for (int i0 = 0; i0 < total; i0 += U) {
+        step(q0);
+        step(q1);
+        step(q2);
+        step(q3);
     }
 
     // ---- flush outgoing sub-boxes as this chunk's partial copy ----------------------------------
@@ -281,30 +340,78 @@ __device__ __forceinline__ void jt_pass(const JtTask *__restrict__ tasks, const 
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
             const JtMsg &m = tk.msg[JT_MAX_IN + j];
-            double *dst = msg_arena + m.off + (int64_t)pnum[j] * m.pstride + gbase[NIN + j];
-            const int n = 1 << m.nfree;
-            for (int s = tid; s < n; s += JT_THREADS) {
-                int idx = 0;
-                for (int b = 0; b < m.nfree; ++b) idx += ((s >> b) & 1) << m.free_pos[b];
+            double *dst = msg_arena + m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+            const int nfree = m.nfree;
+            const int n = 1 << nfree;
+            const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+            const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
+            int idx_t = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (b < nfree) idx_t += ((tid >> b) & 1) << JT_FPOS(fp, b);
+            for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
+                int idx = idx_t;
+#pragma unroll
+                for (int b = 8; b < JT_MAX_FREE; ++b)
+                    if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
                 dst[idx] = out_sub[j][s];
             }
         }
     }
 }
 
-// Named entry points (these names appear in rocprofv3 traces).
+// Entry points (these names appear in rocprofv3 traces).  One launch covers every clique of
+// one tree level, whatever its number of neighbours: the workgroup dispatches on its task.
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS) void jt_collect_level(const JtTask *__restrict__ tasks,
+                                                               const JtBlock *__restrict__ blk,
+                                                               const T *__restrict__ psi, T *__restrict__ bel,
+                                                               double *__restrict__ msg) {
+    const JtBlock &bk = blk[blockIdx.x];
+    const JtTask &tk = tasks[bk.task];
+    switch (tk.n_in) {
+        case 0: jt_pass<T, 0, 1, 0>(tk, bk, psi, bel, msg); break;
+        case 1: jt_pass<T, 1, 1, 0>(tk, bk, psi, bel, msg); break;
+        case 2: jt_pass<T, 2, 1, 0>(tk, bk, psi, bel, msg); break;
+        default: jt_pass<T, 3, 1, 0>(tk, bk, psi, bel, msg); break;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS) void jt_distribute_level(const JtTask *__restrict__ tasks,
+                                                                  const JtBlock *__restrict__ blk,
+                                                                  const T *__restrict__ psi, T *__restrict__ bel,
+                                                                  double *__restrict__ msg) {
+    const JtBlock &bk = blk[blockIdx.x];
+    const JtTask &tk = tasks[bk.task];
+    switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
+        case 0: jt_pass<T, 0, 0, 1>(tk, bk, psi, bel, msg); break;
+        case 1: jt_pass<T, 1, 1, 1>(tk, bk, psi, bel, msg); break;
+        case 2: jt_pass<T, 2, 2, 1>(tk, bk, psi, bel, msg); break;
+        case 3: jt_pass<T, 3, 3, 1>(tk, bk, psi, bel, msg); break;
+        case 4: jt_pass<T, 1, 0, 1>(tk, bk, psi, bel, msg); break;
+        case 5: jt_pass<T, 2, 1, 1>(tk, bk, psi, bel, msg); break;
+        case 6: jt_pass<T, 3, 2, 1>(tk, bk, psi, bel, msg); break;
+        default: jt_pass<T, 4, 3, 1>(tk, bk, psi, bel, msg); break;
+    }
+}
+
+// Per-shape entry points, used when the plan is built with JTP_SPLIT_VARIANTS (profiling aid:
+// one launch per (level, neighbour count), so rocprofv3 attributes time to each shape).
 template <typename T, int NCH>
-__global__ __launch_bounds__(JT_THREADS) void jt_collect(const JtTask *__restrict__ tasks, const uint2 *__restrict__ blk,
+__global__ __launch_bounds__(JT_THREADS) void jt_collect(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                          const T *__restrict__ psi, T *__restrict__ bel,
                                                          double *__restrict__ msg) {
-    jt_pass<T, NCH, 1, 0>(tasks, blk, psi, bel, msg);
+    const JtBlock &bk = blk[blockIdx.x];
+    jt_pass<T, NCH, 1, 0>(tasks[bk.task], bk, psi, bel, msg);
 }
 
 template <typename T, int HASP, int NCH>
-__global__ __launch_bounds__(JT_THREADS) void jt_distribute(const JtTask *__restrict__ tasks, const uint2 *__restrict__ blk,
+__global__ __launch_bounds__(JT_THREADS) void jt_distribute(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                             const T *__restrict__ psi, T *__restrict__ bel,
                                                             double *__restrict__ msg) {
-    jt_pass<T, HASP + NCH, NCH, 1>(tasks, blk, psi, bel, msg);
+    const JtBlock &bk = blk[blockIdx.x];
+    jt_pass<T, HASP + NCH, NCH, 1>(tasks[bk.task], bk, psi, bel, msg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -352,6 +459,15 @@ __global__ __launch_bounds__(256) void jt_pack(JtPackDesc d, const S *__restrict
         }
         arena[d.dev_off + x] = (T)v;
     }
+}
+
+// potential of a virtual (all-ones) clique: 1 on its real index range, 0 on the padding
+template <typename T>
+__global__ __launch_bounds__(256) void jt_fill_ones(T *__restrict__ arena, int64_t off, int nbits, int real_bits) {
+    const int64_t n = (int64_t)1 << nbits;
+    const int64_t lim = (int64_t)1 << real_bits;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x)
+        arena[off + x] = (T)(x < lim ? 1.0 : 0.0);
 }
 
 // host index -> device index

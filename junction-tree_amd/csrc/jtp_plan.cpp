@@ -69,7 +69,9 @@ int plan_loops(const HostPlan &hp, JtTask &tk, int nbits, int real_bits, const s
                const std::vector<MsgView> &outs, int block_log2, std::string &err) {
     const int TB = hp.TB;
     const int budget = hp.lds_budget > 0 ? hp.lds_budget : 32 * 1024;
-    const int PMAX_LOG2 = 3;                 // at most 8 partial copies per outgoing message
+    // at most 8 partial copies per outgoing message; small levels (few cliques) may use up to 64
+    // so that a lone clique still spreads over >= 128 workgroups
+    const int PMAX_LOG2 = block_log2 <= 13 ? 6 : 3;
     const uint32_t himask = nbits >= 32 ? 0 : (((1u << nbits) - 1) & ~((1u << TB) - 1));
     uint32_t allout = 0, everyout = himask;
     for (auto &o : outs) {
@@ -224,6 +226,19 @@ int plan_loops(const HostPlan &hp, JtTask &tk, int nbits, int real_bits, const s
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+
+JtBlock jtp_make_block(const JtTask &tk, uint32_t task_index, uint32_t chunk) {
+    JtBlock b;
+    memset(&b, 0, sizeof b);
+    b.task = task_index;
+    for (int j = 0; j < tk.nF; ++j) {
+        if (!((chunk >> j) & 1u)) continue;
+        b.xF += tk.f_x[j];
+        for (int k = 0; k < JT_MAX_MSG; ++k) b.gbase[k] += tk.msg[k].f_w[j];
+        for (int k = 0; k < JT_MAX_OUT; ++k) b.pnum[k] += tk.msg[JT_MAX_IN + k].f_p[j];
+    }
+    return b;
+}
 
 int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     if (!d) FAIL(JTP_EINVAL, "null description");
@@ -470,10 +485,15 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     hp.arena_elems = 0;
     for (int c = 0; c < NP; ++c) {
         PNode &p = hp.pn[c];
-        if (p.real < 0 || p.owner != hp.rank) continue;
+        if (p.owner != hp.rank) continue;
         p.arena_off = hp.arena_elems;
         hp.arena_elems += (int64_t)1 << p.nbits;
         hp.arena_elems = (hp.arena_elems + 255) & ~(int64_t)255;
+        if (p.real < 0) {                               // virtual clique: a resident 0/1 table
+            int rb = 0;
+            for (int nb : p.nb) rb += nb;
+            hp.virtual_fills.push_back({p.arena_off, p.nbits, rb});
+        }
     }
     hp.pack.assign(N, JtPackDesc());
     for (int c = 0; c < N; ++c) {
@@ -528,8 +548,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             JtTask tk;
             memset(&tk, 0, sizeof tk);
             tk.pnode = c;
-            tk.psi_off = p.real >= 0 ? p.arena_off : -1;
-            if (p.real >= 0 && p.owner != hp.rank) tk.psi_off = 0;       // not executed here
+            tk.psi_off = p.owner == hp.rank ? p.arena_off : 0;          // other ranks' tasks are not executed here
             tk.bel_off = (phase == 1 && p.real >= 0) ? (p.owner == hp.rank ? p.arena_off : 0) : -1;
             std::vector<MsgView> ins, outs;
             if (phase == 1 && p.psep >= 0) ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
@@ -630,7 +649,9 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             if (p.owner != hp.rank) continue;
             int t = phase == 0 ? p.collect_task : p.distribute_task;
             if (t < 0) continue;
-            groups[hp.task_variant[t]].push_back(t);
+            int key = hp.task_variant[t];
+            if (!(hp.flags & JTP_SPLIT_VARIANTS)) key = phase == 0 ? JT_K_COLLECT_LEVEL : JT_K_DISTRIBUTE_LEVEL;
+            groups[key].push_back(t);
         }
         if (!groups.empty()) flush_comm();
         for (auto &g : groups) {
@@ -642,7 +663,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             L.blk_off = (int64_t)hp.blocks.size();
             for (int t : L.tasks) {
                 const JtTask &tk = hp.tasks[t];
-                for (uint32_t f = 0; f < (1u << tk.nF); ++f) hp.blocks.push_back({(uint32_t)t, f});
+                for (uint32_t f = 0; f < (1u << tk.nF); ++f) {
+                    hp.blocks.push_back(jtp_make_block(tk, (uint32_t)t, f));
+                    hp.block_chunk.push_back(f);
+                }
                 L.lds_bytes = std::max(L.lds_bytes, tk.lds_bytes);
                 L.alg_bytes += task_bytes[t];
             }
@@ -693,7 +717,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
 // ------------------------------------------------------------------------------------------
 
 int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
-                           JtTask &tk, int &out_bits, int &npart, std::vector<BlockRef> &blocks,
+                           JtTask &tk, int &out_bits, int &npart, std::vector<JtBlock> &blocks,
                            std::string &err) {
     const PNode &p = hp.pn[pnode];
     PSep s;
@@ -720,7 +744,7 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int>
     out_bits = bit;
     npart = tk.msg[JT_MAX_IN].npart;
     blocks.clear();
-    for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back({0u, f});
+    for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(tk, 0u, f));
     return JTP_OK;
 }
 
@@ -852,7 +876,11 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         o << "],\"blocks\":[";
         for (size_t b = 0; b < hp.blocks.size(); ++b) {
             if (b) o << ",";
-            o << "[" << hp.blocks[b].task << "," << hp.blocks[b].chunk << "]";
+            const JtBlock &k = hp.blocks[b];
+            o << "[" << k.task << "," << hp.block_chunk[b] << "," << k.xF;
+            for (int i = 0; i < JT_MAX_MSG; ++i) o << "," << k.gbase[i];
+            for (int i = 0; i < JT_MAX_OUT; ++i) o << "," << k.pnum[i];
+            o << "]";
         }
         o << "]";
     }

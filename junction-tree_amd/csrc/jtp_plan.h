@@ -55,7 +55,10 @@ struct Step {
     int first = 0, count = 0;        // launch index, or [first, first+count) in comm
 };
 
-struct BlockRef { uint32_t task, chunk; };
+struct VirtualFill { int64_t off; int nbits, real_bits; };   // all-ones table of a virtual clique
+
+// decode chunk number -> workgroup record (element base, message bases, partial numbers)
+JtBlock jtp_make_block(const JtTask &tk, uint32_t task_index, uint32_t chunk);
 
 struct HostPlan {
     // copy of the description
@@ -75,7 +78,9 @@ struct HostPlan {
     std::vector<JtTask> tasks;
     std::vector<int> task_variant;
     std::vector<Launch> launches;
-    std::vector<BlockRef> blocks;
+    std::vector<JtBlock> blocks;
+    std::vector<uint32_t> block_chunk;   // chunk number of each block (description/tests)
+    std::vector<VirtualFill> virtual_fills;
     std::vector<CommOp> comm;
     std::vector<Step> steps;
     std::vector<JtPackDesc> pack;    // per real clique (host order)
@@ -94,7 +99,7 @@ int jtp_build_plan(const jtp_tree_desc *desc, HostPlan &hp, std::string &err);
 // out_vars[0] slowest, padded to power-of-two bits).  The task writes `npart` partial copies of
 // 2^out_bits doubles at msg-arena offset `dst_off`.  Returns JTP_OK or error.
 int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
-                           JtTask &task, int &out_bits, int &npart, std::vector<BlockRef> &blocks,
+                           JtTask &task, int &out_bits, int &npart, std::vector<JtBlock> &blocks,
                            std::string &err);
 
 void jtp_plan_to_json(HostPlan &hp, bool with_tasks);

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libjtprop.so")
 JTP_OK, JTP_EINVAL, JTP_EHIP, JTP_ECOMM, JTP_ENOMEM, JTP_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 JTP_F32, JTP_F64 = 0, 1
 JTP_PLAN_ONLY = 1
-N_VARIANTS = 12
+JTP_SPLIT_VARIANTS = 2
+N_VARIANTS = 14
 
 
 class TreeDesc(C.Structure):
@@ -78,6 +79,7 @@ SYMBOLS = {
     "jtp_get_z": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "jtp_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "jtp_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "jtp_get_launch_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "jtp_kernel_name": (C.c_char_p, [C.c_int32]),
     "jtp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "jtp_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),

@@ -56,7 +56,7 @@ class Plan:
 
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
-                 layout_policy=0):
+                 layout_policy=0, split_variants=False):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
@@ -111,7 +111,7 @@ class Plan:
         d.n_batch = n_batch
         d.n_ranks = n_ranks
         d.rank = rank
-        d.flags = _capi.JTP_PLAN_ONLY if plan_only else 0
+        d.flags = (_capi.JTP_PLAN_ONLY if plan_only else 0) | (_capi.JTP_SPLIT_VARIANTS if split_variants else 0)
         d.lds_budget = lds_budget
         d.block_log2 = block_log2
         d.layout_policy = layout_policy
@@ -199,6 +199,18 @@ class Plan:
     def set_profiling(self, keep=1):
         """Record a hipEvent pair around every launch of the next `keep` propagates."""
         _capi.check(self._lib.jtp_set_profiling(self._handle, int(keep)))
+
+    def launch_ms(self):
+        """Mean device time of every launch of the schedule (ms), with its description."""
+        d = self.describe()
+        n = len(d["launches"])
+        buf = (C.c_double * max(n, 1))()
+        rc = self._lib.jtp_get_launch_ms(self._handle, buf, n)
+        if rc < 0:
+            _capi.check(rc)
+        return [dict(phase=L["phase"], level=L["level"], variant=L["variant"], nblocks=L["nblocks"],
+                     ntasks=len(L["tasks"]), alg_bytes=L["alg_bytes"], ms=buf[i])
+                for i, L in enumerate(d["launches"])]
 
     def stats(self):
         st = _capi.Stats()

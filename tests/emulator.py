@@ -47,6 +47,10 @@ class Emulator:
         self.psi = np.zeros(max(desc["arena_elems"], 1), dtype=np.float64)
         self.bel = np.zeros_like(self.psi)
         self.msg = np.full(max(desc["msg_doubles"], 1), np.nan)     # NaN = never written
+        for p in desc["pnodes"]:                                    # virtual cliques: resident 0/1 tables
+            if p["real"] < 0 and p["arena_off"] >= 0:
+                n = np.arange(1 << p["nbits"])
+                self.psi[p["arena_off"] + n] = (n < (1 << sum(p["nb"]))).astype(np.float64)
 
     # ---------------------------------------------------------------- layout conversion
     def _dev_index(self, pnode, host_vars, cards):
@@ -86,9 +90,8 @@ class Emulator:
         return (up * dn).reshape(cards)
 
     # ---------------------------------------------------------------- one workgroup
-    def _block(self, tk, chunk, variant):
+    def _block(self, tk, chunk, collect, record=None):
         VEC, EB = self.VEC, self.EB
-        collect = variant < 4
         n_in, n_out = tk["n_in"], tk["n_out"]
         ins, outs = tk["in"], tk["out"]
         xF = 0
@@ -101,6 +104,10 @@ class Emulator:
                 for k in range(n_out):
                     gb_out[k] += outs[k]["f_w"][j]
                     pnum[k] += outs[k]["f_p"][j]
+        if record is not None:      # the host-decoded workgroup record must agree with the bit decode
+            assert record[0] == xF
+            assert list(record[1:1 + n_in]) == gb_in and list(record[5:5 + n_out]) == gb_out
+            assert list(record[8:8 + n_out]) == pnum
         # staging
         subs = []
         for k, m in enumerate(ins):
@@ -151,11 +158,7 @@ class Emulator:
              + (tid * VEC)[None, None, :, None] + np.arange(VEC)[None, None, None, :]) & 0xFFFFFFFF
         assert x.max() < (1 << tk["nbits"])
         assert len(np.unique(x)) == x.size            # every element visited exactly once
-        virt = tk["psi_off"] < 0
-        if virt:
-            p = (x < (1 << tk["real_bits"])).astype(np.float64)
-        else:
-            p = self.psi[tk["psi_off"] + x]
+        p = self.psi[tk["psi_off"] + x]
         vals = []
         for k, m in enumerate(ins):
             slot = (oa_in[k][:, None, None, None] + or_in[k][None, :, None, None]
@@ -204,10 +207,13 @@ class Emulator:
             launch = d["launches"][first]
             blocks = d["blocks"][launch["blk_off"]:launch["blk_off"] + launch["nblocks"]]
             seen = set()
-            for t, chunk in blocks:
+            for blk in blocks:
+                t, chunk = blk[0], blk[1]
                 tk = d["tasks"][t]
-                assert t in launch["tasks"] and d["tasks"][t]["variant"] == launch["variant"]
+                assert t in launch["tasks"]
+                assert launch["variant"] in (tk["variant"], 12 + launch["phase"])      # per level or per shape
+                assert (tk["variant"] < 4) == (launch["phase"] == 0)
                 assert tk["lds_bytes"] <= launch["lds_bytes"]
                 seen.add((t, chunk))
-                self._block(tk, chunk, launch["variant"])
+                self._block(tk, chunk, launch["phase"] == 0, blk[2:])
             assert len(seen) == len(blocks) == sum(1 << d["tasks"][t]["nF"] for t in launch["tasks"])

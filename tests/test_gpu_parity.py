@@ -140,6 +140,7 @@ def test_refsafe_synthetic_trees_f64_and_f32(golden):
 @pytest.mark.parametrize("opts", [
     {}, {"block_log2": 10}, {"block_log2": 11, "lds_budget": 256}, {"layout_policy": 1},
     {"layout_policy": 1, "block_log2": 10, "lds_budget": 128}, {"block_log2": 12, "lds_budget": 2048},
+    {"split_variants": True}, {"split_variants": True, "block_log2": 10},
 ])
 def test_planner_options_do_not_change_results(opts):
     specs = [

@@ -151,7 +151,7 @@ def test_full_scale_configs_plan():
     assert d["n_messages"] == 510 and d["arena_elems"] == 256 << 20
     assert abs(d["alg_bytes"] / 1e9 - 3.22) < 0.03
     assert d["max_lds"] <= 64 * 1024
-    assert max(max(s["up_npart"], s["dn_npart"]) for s in d["pseps"]) <= 8
+    assert max(max(s["up_npart"], s["dn_npart"]) for s in d["pseps"]) <= 64
     plan.close()
     spec = synthetic.chain_tree(n_cliques=1000, card=64, width=3)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", plan_only=True)
