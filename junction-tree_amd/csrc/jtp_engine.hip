@@ -94,12 +94,10 @@ static int load() {
 
 // ------------------------------------------------------------------------------------------ plan object
 
-typedef void (*jt_kernel_f32)(const JtTask *, const JtBlock *, const float *, float *, double *);
-typedef void (*jt_kernel_f64)(const JtTask *, const JtBlock *, const double *, double *, double *);
 
 template <typename T>
 struct KernelTable {
-    typedef void (*fn)(const JtTask *, const JtBlock *, const T *, T *, double *);
+    typedef void (*fn)(const JtTask *, const JtBlock *, const int *, const T *, T *, double *);
     static fn get(int variant) {
         switch (variant) {
             case JT_K_COLLECT0: return jt_collect<T, 0>;
@@ -141,6 +139,7 @@ struct jtp_plan {
     std::vector<BatchBuffers> bufs;
     JtTask *d_tasks = nullptr;
     JtBlock *d_blocks = nullptr;
+    int *d_itab = nullptr;
     void *stage = nullptr;          // device staging buffer for host<->device conversion
     size_t stage_bytes = 0;
     int prof_steps = 0;             // 0: off; else ring of this many event sets
@@ -201,6 +200,7 @@ void jtp_plan_destroy(jtp_plan *pl) {
         }
         if (pl->d_tasks) (void)hipFree(pl->d_tasks);
         if (pl->d_blocks) (void)hipFree(pl->d_blocks);
+        if (pl->d_itab) (void)hipFree(pl->d_itab);
         if (pl->stage) (void)hipFree(pl->stage);
         for (auto e : pl->ev) (void)hipEventDestroy(e);
         for (auto s : pl->streams) (void)hipStreamDestroy(s);
@@ -276,6 +276,10 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     if (!hp.blocks.empty()) {
         CREATE_TRY(hipMalloc((void **)&pl->d_blocks, hp.blocks.size() * sizeof(JtBlock)));
         CREATE_TRY(hipMemcpy(pl->d_blocks, hp.blocks.data(), hp.blocks.size() * sizeof(JtBlock), hipMemcpyHostToDevice));
+    }
+    if (!hp.itab.empty()) {
+        CREATE_TRY(hipMalloc((void **)&pl->d_itab, hp.itab.size() * sizeof(int32_t)));
+        CREATE_TRY(hipMemcpy(pl->d_itab, hp.itab.data(), hp.itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     if (hp.max_lds > 64 * 1024) {
         for (int v = 0; v < JT_K_COUNT; ++v) {
@@ -374,13 +378,13 @@ int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double 
 // ------------------------------------------------------------------------------------------ compute
 
 static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipStream_t s, const JtTask *tasks,
-                          const JtBlock *blocks, void *psi, void *bel, double *msg) {
+                          const JtBlock *blocks, const int *itab, void *psi, void *bel, double *msg) {
     if (pl->hp.dtype == JTP_F32) {
         auto f = KernelTable<float>::get(variant);
-        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, (const float *)psi, (float *)bel, msg);
+        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const float *)psi, (float *)bel, msg);
     } else {
         auto f = KernelTable<double>::get(variant);
-        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, (const double *)psi, (double *)bel, msg);
+        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const double *)psi, (double *)bel, msg);
     }
     return JTP_OK;
 }
@@ -409,7 +413,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
             if (st.kind == 0) {
                 const Launch &L = hp.launches[st.first];
                 if (pb) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first], s));
-                launch_variant(pl, L.variant, L.nblocks, L.lds_bytes, s, pl->d_tasks, pl->d_blocks + L.blk_off, bb.psi, bb.bel, bb.msg);
+                launch_variant(pl, L.variant, L.nblocks, L.lds_bytes, s, pl->d_tasks, pl->d_blocks + L.blk_off, pl->d_itab, bb.psi, bb.bel, bb.msg);
                 if (pb) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first + 1], s));
             } else {
                 NCCL_TRY(rccl::GroupStart());
@@ -513,8 +517,9 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
     JtTask tk;
     int out_bits = 0, npart = 1;
     std::vector<JtBlock> blocks;
+    std::vector<int32_t> itab;
     std::string err;
-    rc = jtp_plan_marginal_task(hp, clique, ov, tk, out_bits, npart, blocks, err);
+    rc = jtp_plan_marginal_task(hp, clique, ov, tk, itab, out_bits, npart, blocks, err);
     if (rc) return set_err(rc, "%s", err.c_str());
     HIP_TRY(hipSetDevice(hp.device));
     hipStream_t s = pl->streams[batch % pl->streams.size()];
@@ -523,7 +528,10 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
     double *scratch = nullptr;
     JtTask *d_task = nullptr;
     JtBlock *d_blk = nullptr;
+    int *d_tab = nullptr;
     HIP_TRY(hipMalloc((void **)&scratch, (size_t)pstride * npart * 8));
+    HIP_TRY(hipMalloc((void **)&d_tab, itab.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(d_tab, itab.data(), itab.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMalloc((void **)&d_task, sizeof(JtTask)));
     HIP_TRY(hipMalloc((void **)&d_blk, blocks.size() * sizeof(JtBlock)));
     tk.msg[JT_MAX_IN].off = 0;
@@ -534,7 +542,7 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
         HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tk.lds_bytes));
     }
     // marginalise the BELIEF table: it is the "potential" argument of a childless collect
-    launch_variant(pl, JT_K_COLLECT0, (int)blocks.size(), tk.lds_bytes, s, d_task, d_blk, b.bel, b.bel, scratch);
+    launch_variant(pl, JT_K_COLLECT0, (int)blocks.size(), tk.lds_bytes, s, d_task, d_blk, d_tab, b.bel, b.bel, scratch);
     HIP_TRY(hipGetLastError());
     JtPackDesc d;
     memset(&d, 0, sizeof d);
@@ -570,6 +578,7 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
     (void)hipFree(scratch);
     (void)hipFree(d_task);
     (void)hipFree(d_blk);
+    (void)hipFree(d_tab);
     return rc;
 }
 

@@ -16,11 +16,14 @@
 #define JT_MAX_IN 4            // incoming messages per task (parent + 3 children)
 #define JT_MAX_OUT 3           // outgoing messages per task
 #define JT_MAX_MSG (JT_MAX_IN + JT_MAX_OUT)
-#define JT_NCOL 8              // increment-table columns: 0 = element offset, 1.. = messages
+#define JT_NCOL 8              // iteration-table columns: 0 = element offset, 1..4 = incoming slot
+                               // offsets, 5..7 = outgoing slot offsets (iteration i = a * 2^nR + r)
 #define JT_MAX_HI 22           // clique bits above the thread part
 #define JT_MAX_BITS 31         // max index bits of one clique table
 #define JT_MAX_FREE 13         // max log2(entries) of a staged message sub-box
 #define JT_THREADS 256
+#define JT_STAGE_SCRATCH 2048    // bytes of LDS for staging sums
+#define JT_MAX_ITER_LOG2 8       // a workgroup runs at most 2^8 loop iterations (offset table in LDS)
 #define JT_MAX_VARS 32         // variables per node
 
 struct JtMsg {
@@ -51,8 +54,10 @@ struct JtTask {
     int32_t real_bits;         // index bits actually used by variables (<= nbits; rest is padding)
     int32_t pad0;
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
-    int32_t dA[JT_MAX_HI][JT_NCOL];   // A-loop increments: going from a to a+1 adds dA[ctz(a+1)]
-    int32_t dR[JT_MAX_HI][JT_NCOL];   // R-loop increments
+    uint32_t first_x[4];       // element offsets of loop iterations 0..3 (relative to the chunk base)
+    int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer
+    int32_t total;             // loop iterations per workgroup = 2^(nA + nR), >= 4
+    int32_t itab_lds;          // byte offset of the iteration table in dynamic LDS
     JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing
 };
 

@@ -38,13 +38,11 @@ __device__ __forceinline__ double jt_shfl_xor(double v, int laneMask) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ int jt_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-
 // message-index bit of sub-box index bit b (free_pos[] packed four per word)
 #define JT_FPOS(fp, b) (((fp)[(b) >> 2] >> (8 * ((b) & 3))) & 0xffu)
 
 template <typename T, int NIN, int NOUT, int MODE>
-__device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
+__device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
                                         double *__restrict__ msg_arena) {
     constexpr int VEC = 16 / sizeof(T);
@@ -60,52 +58,31 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
     const int wave = tid >> 6;
 
     const uint32_t xF = bk.xF + (uint32_t)tid * VEC;
-    const bool wbel = (MODE == 1) && tk.bel_off >= 0;
     const T *psi = psi_arena + tk.psi_off;
-    T *bel = bel_arena + (wbel ? tk.bel_off : 0);
-    const int nA = 1 << tk.nA, nR = 1 << tk.nR;
-    const int total = nA * nR;
+    T *bel = bel_arena + (MODE == 1 ? tk.bel_off : 0);   // distribute always stores (virtual cliques: scratch)
+    const int total = tk.total;                       // loop iterations of this workgroup (>= U)
+    const int rmask = (1 << tk.nR) - 1;               // an outgoing-message epilogue follows every 2^nR
 
-    // ---- loop increment tables live in lanes: lane t < 32 holds row t of dR, lane 32 + t row t
-    //      of dA; a wave reads "row t, column c" with v_readlane (no memory access in the loops)
-    int dcol[1 + (NMSG > 0 ? NMSG : 1)];
+    // ---- element loads run U iterations ahead of their use.  Iteration i's offsets are row i of
+    //      the task's iteration table (host built, copied to LDS below): the loops do no index
+    //      arithmetic beyond one broadcast ds_read per row.
+    const int *gtab = itab + tk.itab_off;
+    const int *tab = reinterpret_cast<const int *>(smem + tk.itab_lds);
+    // the first U loads use offsets stored in the task record, so they leave immediately
+    VT q0 = *reinterpret_cast<const VT *>(psi + (xF + tk.first_x[0]));
+    VT q1 = *reinterpret_cast<const VT *>(psi + (xF + tk.first_x[1]));
+    VT q2 = *reinterpret_cast<const VT *>(psi + (xF + tk.first_x[2]));
+    VT q3 = *reinterpret_cast<const VT *>(psi + (xF + tk.first_x[3]));
     {
-        const int t = lane & 31;
-        const int32_t *row = (lane >= 32) ? tk.dA[t < JT_MAX_HI ? t : 0] : tk.dR[t < JT_MAX_HI ? t : 0];
-        const bool ok = t < JT_MAX_HI;
-        dcol[0] = ok ? row[0] : 0;
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) dcol[1 + k] = ok ? row[1 + k] : 0;
-#pragma unroll
-        for (int j = 0; j < NOUT; ++j) dcol[1 + NIN + j] = ok ? row[1 + JT_MAX_IN + j] : 0;
+        int *tabw = reinterpret_cast<int *>(smem + tk.itab_lds);
+        for (int i = tid; i < total * JT_NCOL; i += JT_THREADS) tabw[i] = gtab[i];
     }
 
-    // ---- element loads: a producer counter runs U iterations ahead of the consumer ---------
-    int pi = 0, pa = 0, pr = 0;
-    uint32_t pxa = 0, pxr = 0;
-    auto issue = [&](VT &slot) {
-        if (pi < total) {
-            slot = *reinterpret_cast<const VT *>(psi + (xF + pxa + pxr));
-            ++pi;
-            if (pr + 1 < nR) {
-                pxr += (uint32_t)jt_readlane(dcol[0], __builtin_ctz((unsigned)(pr + 1)));
-                ++pr;
-            } else {
-                pr = 0;
-                pxr = 0;
-                if (pa + 1 < nA) pxa += (uint32_t)jt_readlane(dcol[0], 32 + __builtin_ctz((unsigned)(pa + 1)));
-                ++pa;
-            }
-        }
-    };
-    VT q0 = VT(), q1 = VT(), q2 = VT(), q3 = VT();
-    issue(q0);
-    issue(q1);
-    issue(q2);
-    issue(q3);
-
     // ---- stage incoming sub-boxes (summing partial copies), zero outgoing sub-boxes -----
-    // (the first element loads are already in flight)
+    // (the first element loads are already in flight).  Sub-boxes smaller than the workgroup
+    // split their partial copies over 256/n thread groups so that all copies are fetched in
+    // one round of loads; group sums are combined through LDS in group order (deterministic).
+    double *scratch = reinterpret_cast<double *>(smem + tk.itab_lds - JT_STAGE_SCRATCH);
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         const JtMsg &m = tk.msg[k];
@@ -121,20 +98,39 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
 #pragma unroll
         for (int b = 0; b < 8; ++b)
             if (b < nfree) idx_t += ((tid >> b) & 1) << JT_FPOS(fp, b);
-        for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
-            int idx = idx_t;
-#pragma unroll
-            for (int b = 8; b < JT_MAX_FREE; ++b)
-                if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
+        auto sum_range = [&](int idx, int p0, int p1) {
             double sum = 0.0;
-            for (int p = 0; p < npart; p += 4) {          // four copies in flight, summed in copy order
-                const double c0 = src[(int64_t)p * ps + idx];
-                const double c1 = (p + 1 < npart) ? src[(int64_t)(p + 1) * ps + idx] : 0.0;
-                const double c2 = (p + 2 < npart) ? src[(int64_t)(p + 2) * ps + idx] : 0.0;
-                const double c3 = (p + 3 < npart) ? src[(int64_t)(p + 3) * ps + idx] : 0.0;
-                sum = (((sum + c0) + c1) + c2) + c3;
+            for (int p = p0; p < p1; p += 8) {            // eight copies in flight, summed in copy order
+                double c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c[u] = (p + u < p1) ? src[(int64_t)(p + u) * ps + idx] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += c[u];
             }
-            sub[s] = sum;
+            return sum;
+        };
+        if (nfree >= 8 || npart == 1) {
+            for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
+                int idx = idx_t;
+#pragma unroll
+                for (int b = 8; b < JT_MAX_FREE; ++b)
+                    if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
+                sub[s] = sum_range(idx, 0, npart);
+            }
+        } else {
+            const int groups = JT_THREADS >> nfree;       // >= 2
+            const int g = tid >> nfree;
+            const int per = (npart + groups - 1) / groups;
+            const int p0 = g * per;
+            const int p1 = (p0 + per < npart) ? p0 + per : npart;
+            scratch[tid] = sum_range(idx_t, p0, p1);
+            __syncthreads();
+            if (tid < n) {
+                double sum = 0.0;
+                for (int gg = 0; gg < groups; ++gg) sum += scratch[(gg << nfree) + tid];
+                sub[tid] = sum;
+            }
+            __syncthreads();
         }
     }
 #pragma unroll
@@ -151,6 +147,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
     const double *in_sub[NIN > 0 ? NIN : 1];
     double *out_sub[NOUT > 0 ? NOUT : 1];
     int in_ew0[NIN > 0 ? NIN : 1], in_ew1[NIN > 0 ? NIN : 1], in_edep[NIN > 0 ? NIN : 1];
+    // outgoing-message constants are read here, before the first store of the kernel: later
+    // loads of the task record could not use the scalar cache and would drain vmcnt
+    int o_rede[NOUT > 0 ? NOUT : 1], o_redl[NOUT > 0 ? NOUT : 1], o_redw[NOUT > 0 ? NOUT : 1];
+    int o_ew0[NOUT > 0 ? NOUT : 1], o_ew1[NOUT > 0 ? NOUT : 1];
 #pragma unroll
     for (int k = 0; k < NMSG; ++k) {
         const JtMsg &m = tk.msg[k < NIN ? k : JT_MAX_IN + (k - NIN)];
@@ -166,18 +166,16 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
             in_ew1[k < NIN ? k : 0] = m.e_w[1];
             in_edep[k < NIN ? k : 0] = m.e_dep;
         } else {
-            out_sub[k >= NIN ? k - NIN : 0] = reinterpret_cast<double *>(smem + m.lds_off);
+            const int j = k >= NIN ? k - NIN : 0;
+            out_sub[j] = reinterpret_cast<double *>(smem + m.lds_off);
+            o_rede[j] = m.red_e;
+            o_redl[j] = m.red_lane;
+            o_redw[j] = m.red_wave;
+            o_ew0[j] = m.e_w[0];
+            o_ew1[j] = m.e_w[1];
         }
     }
 
-    // ---- consumer state ------------------------------------------------------------------------
-    int ci = 0, ca = 0, cr = 0;
-    uint32_t xa = 0, xr = 0;
-    int oa[NMSG > 0 ? NMSG : 1], orr[NIN > 0 ? NIN : 1];
-#pragma unroll
-    for (int k = 0; k < NMSG; ++k) oa[k] = 0;
-#pragma unroll
-    for (int k = 0; k < NIN; ++k) orr[k] = 0;
     double acc[NOUT > 0 ? NOUT : 1][VEC];
 #pragma unroll
     for (int j = 0; j < NOUT; ++j)
@@ -185,11 +183,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
         for (int e = 0; e < VEC; ++e) acc[j][e] = 0.0;
 
     // fold this thread's sums of one A iteration into the outgoing sub-boxes
-    auto epilogue = [&]() {
+    auto epilogue = [&](const int (&oo)[NOUT > 0 ? NOUT : 1]) {
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
-            const JtMsg &m = tk.msg[JT_MAX_IN + j];
-            const int red_e = m.red_e, red_lane = m.red_lane, red_wave = m.red_wave;
+            const int red_e = o_rede[j], red_lane = o_redl[j], red_wave = o_redw[j];
             if constexpr (VEC == 4) {
                 if (red_e & 1) {
                     acc[j][0] += acc[j][1];
@@ -211,7 +208,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
                 }
             }
             const bool rep = (lane & red_lane) == 0;
-            const int slot = oa[NIN + j] + thr[NIN + j];
+            const int slot = oo[j] + thr[NIN + j];
             const int nph = 1 << __builtin_popcount((unsigned)red_wave);
             // waves that share slots (wave bits not in the message) take turns, in wave order
             int myph = 0;
@@ -223,7 +220,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         if ((e & red_e) == 0) {
-                            const int eo = ((e & 1) ? m.e_w[0] : 0) + ((e & 2) ? m.e_w[1] : 0);
+                            const int eo = ((e & 1) ? o_ew0[j] : 0) + ((e & 2) ? o_ew1[j] : 0);
                             out_sub[j][slot + eo] += acc[j][e];
                         }
                     }
@@ -235,103 +232,93 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
         }
     };
 
-    // one iteration: consume `slot`, refill it for iteration ci + U, multiply, accumulate
-    auto step = [&](VT &slot) {
-        if (ci < total) {
-            const VT v = slot;
-            issue(slot);
-            const uint32_t x = xF + xa + xr;
-            double p[VEC];
-            p[0] = (double)v.x;
-            p[1] = (double)v.y;
+    // one iteration: consume `slot`, refill it for iteration i + U, multiply, accumulate
+    auto step = [&](VT &slot, const int i) {
+        const VT v = slot;
+        {   // past the end the last row is loaded again (cache resident): the load stays unconditional,
+            // so the compiler counts loads in flight and waits with vmcnt(U) instead of draining
+            const int inext = (i + U < total) ? i + U : total - 1;
+            slot = *reinterpret_cast<const VT *>(psi + (xF + (uint32_t)tab[inext * JT_NCOL]));
+        }
+        const int4 r0 = *reinterpret_cast<const int4 *>(tab + i * JT_NCOL);        // x, in0, in1, in2
+        const int4 r1 = *reinterpret_cast<const int4 *>(tab + i * JT_NCOL + 4);    // in3, out0, out1, out2
+        const int ioff[4] = {r0.y, r0.z, r0.w, r1.x};
+        const int ooff[3] = {r1.y, r1.z, r1.w};
+        double p[VEC];
+        p[0] = (double)v.x;
+        p[1] = (double)v.y;
+        if constexpr (VEC == 4) {
+            p[2] = (double)v.z;
+            p[3] = (double)v.w;
+        }
+        double in[NIN > 0 ? NIN : 1][VEC];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int base = ioff[k] + thr[k];
+            if (in_edep[k]) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int eo = ((e & 1) ? in_ew0[k] : 0) + ((e & 2) ? in_ew1[k] : 0);
+                    in[k][e] = in_sub[k][base + eo];
+                }
+            } else {
+                const double t = in_sub[k][base];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) in[k][e] = t;
+            }
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double w = p[e];
+#pragma unroll
+                for (int k = 0; k < NIN; ++k) w *= in[k][e];
+                if constexpr (NOUT > 0) acc[0][e] += w;
+            }
+        } else {
+            double b[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double pre = p[e];
+#pragma unroll
+                for (int k = 0; k < NPAR; ++k) pre *= in[k][e];
+                // all-but-one products over the children: prefix * suffix
+                double suf[NOUT + 1];
+                suf[NOUT] = 1.0;
+#pragma unroll
+                for (int j = NOUT - 1; j >= 0; --j) suf[j] = suf[j + 1] * in[NPAR + j][e];
+                double pref = pre;
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) {
+                    acc[j][e] += pref * suf[j + 1];
+                    pref *= in[NPAR + j][e];
+                }
+                b[e] = pref;
+            }
+            VT o;
+            o.x = (T)b[0];
+            o.y = (T)b[1];
             if constexpr (VEC == 4) {
-                p[2] = (double)v.z;
-                p[3] = (double)v.w;
+                o.z = (T)b[2];
+                o.w = (T)b[3];
             }
-            double in[NIN > 0 ? NIN : 1][VEC];
+            *reinterpret_cast<VT *>(bel + (xF + (uint32_t)r0.x)) = o;
+        }
+        if constexpr (NOUT > 0) {
+            if ((i & rmask) == rmask) {
+                int oo[NOUT];
 #pragma unroll
-            for (int k = 0; k < NIN; ++k) {
-                const int base = oa[k] + orr[k] + thr[k];
-                if (in_edep[k]) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int eo = ((e & 1) ? in_ew0[k] : 0) + ((e & 2) ? in_ew1[k] : 0);
-                        in[k][e] = in_sub[k][base + eo];
-                    }
-                } else {
-                    const double t = in_sub[k][base];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) in[k][e] = t;
-                }
-            }
-            if constexpr (MODE == 0) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    double w = p[e];
-#pragma unroll
-                    for (int k = 0; k < NIN; ++k) w *= in[k][e];
-                    if constexpr (NOUT > 0) acc[0][e] += w;
-                }
-            } else {
-                double b[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    double pre = p[e];
-#pragma unroll
-                    for (int k = 0; k < NPAR; ++k) pre *= in[k][e];
-                    // all-but-one products over the children: prefix * suffix
-                    double suf[NOUT + 1];
-                    suf[NOUT] = 1.0;
-#pragma unroll
-                    for (int j = NOUT - 1; j >= 0; --j) suf[j] = suf[j + 1] * in[NPAR + j][e];
-                    double pref = pre;
-#pragma unroll
-                    for (int j = 0; j < NOUT; ++j) {
-                        acc[j][e] += pref * suf[j + 1];
-                        pref *= in[NPAR + j][e];
-                    }
-                    b[e] = pref;
-                }
-                if (wbel) {
-                    VT o;
-                    o.x = (T)b[0];
-                    o.y = (T)b[1];
-                    if constexpr (VEC == 4) {
-                        o.z = (T)b[2];
-                        o.w = (T)b[3];
-                    }
-                    *reinterpret_cast<VT *>(bel + x) = o;
-                }
-            }
-            ++ci;
-            if (cr + 1 < nR) {
-                const int t = __builtin_ctz((unsigned)(cr + 1));
-                xr += (uint32_t)jt_readlane(dcol[0], t);
-#pragma unroll
-                for (int k = 0; k < NIN; ++k) orr[k] += jt_readlane(dcol[1 + k], t);
-                ++cr;
-            } else {
-                if constexpr (NOUT > 0) epilogue();
-                cr = 0;
-                xr = 0;
-#pragma unroll
-                for (int k = 0; k < NIN; ++k) orr[k] = 0;
-                if (ca + 1 < nA) {
-                    const int t = 32 + __builtin_ctz((unsigned)(ca + 1));
-                    xa += (uint32_t)jt_readlane(dcol[0], t);
-#pragma unroll
-                    for (int k = 0; k < NMSG; ++k) oa[k] += jt_readlane(dcol[1 + k], t);
-                }
-                ++ca;
+                for (int j = 0; j < NOUT; ++j) oo[j] = ooff[j];
+                epilogue(oo);
             }
         }
     };
 
     for (int i0 = 0; i0 < total; i0 += U) {
-        step(q0);
-        step(q1);
-        step(q2);
-        step(q3);
+        step(q0, i0);
+        step(q1, i0 + 1);
+        step(q2, i0 + 2);
+        step(q3, i0 + 3);
     }
 
     // ---- flush outgoing sub-boxes as this chunk's partial copy ----------------------------------
@@ -364,54 +351,54 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk,
 // one tree level, whatever its number of neighbours: the workgroup dispatches on its task.
 template <typename T>
 __global__ __launch_bounds__(JT_THREADS) void jt_collect_level(const JtTask *__restrict__ tasks,
-                                                               const JtBlock *__restrict__ blk,
+                                                               const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                const T *__restrict__ psi, T *__restrict__ bel,
                                                                double *__restrict__ msg) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
     switch (tk.n_in) {
-        case 0: jt_pass<T, 0, 1, 0>(tk, bk, psi, bel, msg); break;
-        case 1: jt_pass<T, 1, 1, 0>(tk, bk, psi, bel, msg); break;
-        case 2: jt_pass<T, 2, 1, 0>(tk, bk, psi, bel, msg); break;
-        default: jt_pass<T, 3, 1, 0>(tk, bk, psi, bel, msg); break;
+        case 0: jt_pass<T, 0, 1, 0>(tk, bk, itab, psi, bel, msg); break;
+        case 1: jt_pass<T, 1, 1, 0>(tk, bk, itab, psi, bel, msg); break;
+        case 2: jt_pass<T, 2, 1, 0>(tk, bk, itab, psi, bel, msg); break;
+        default: jt_pass<T, 3, 1, 0>(tk, bk, itab, psi, bel, msg); break;
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(JT_THREADS) void jt_distribute_level(const JtTask *__restrict__ tasks,
-                                                                  const JtBlock *__restrict__ blk,
+                                                                  const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                   const T *__restrict__ psi, T *__restrict__ bel,
                                                                   double *__restrict__ msg) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
-        case 0: jt_pass<T, 0, 0, 1>(tk, bk, psi, bel, msg); break;
-        case 1: jt_pass<T, 1, 1, 1>(tk, bk, psi, bel, msg); break;
-        case 2: jt_pass<T, 2, 2, 1>(tk, bk, psi, bel, msg); break;
-        case 3: jt_pass<T, 3, 3, 1>(tk, bk, psi, bel, msg); break;
-        case 4: jt_pass<T, 1, 0, 1>(tk, bk, psi, bel, msg); break;
-        case 5: jt_pass<T, 2, 1, 1>(tk, bk, psi, bel, msg); break;
-        case 6: jt_pass<T, 3, 2, 1>(tk, bk, psi, bel, msg); break;
-        default: jt_pass<T, 4, 3, 1>(tk, bk, psi, bel, msg); break;
+        case 0: jt_pass<T, 0, 0, 1>(tk, bk, itab, psi, bel, msg); break;
+        case 1: jt_pass<T, 1, 1, 1>(tk, bk, itab, psi, bel, msg); break;
+        case 2: jt_pass<T, 2, 2, 1>(tk, bk, itab, psi, bel, msg); break;
+        case 3: jt_pass<T, 3, 3, 1>(tk, bk, itab, psi, bel, msg); break;
+        case 4: jt_pass<T, 1, 0, 1>(tk, bk, itab, psi, bel, msg); break;
+        case 5: jt_pass<T, 2, 1, 1>(tk, bk, itab, psi, bel, msg); break;
+        case 6: jt_pass<T, 3, 2, 1>(tk, bk, itab, psi, bel, msg); break;
+        default: jt_pass<T, 4, 3, 1>(tk, bk, itab, psi, bel, msg); break;
     }
 }
 
 // Per-shape entry points, used when the plan is built with JTP_SPLIT_VARIANTS (profiling aid:
 // one launch per (level, neighbour count), so rocprofv3 attributes time to each shape).
 template <typename T, int NCH>
-__global__ __launch_bounds__(JT_THREADS) void jt_collect(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+__global__ __launch_bounds__(JT_THREADS) void jt_collect(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                          const T *__restrict__ psi, T *__restrict__ bel,
                                                          double *__restrict__ msg) {
     const JtBlock &bk = blk[blockIdx.x];
-    jt_pass<T, NCH, 1, 0>(tasks[bk.task], bk, psi, bel, msg);
+    jt_pass<T, NCH, 1, 0>(tasks[bk.task], bk, itab, psi, bel, msg);
 }
 
 template <typename T, int HASP, int NCH>
-__global__ __launch_bounds__(JT_THREADS) void jt_distribute(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+__global__ __launch_bounds__(JT_THREADS) void jt_distribute(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                             const T *__restrict__ psi, T *__restrict__ bel,
                                                             double *__restrict__ msg) {
     const JtBlock &bk = blk[blockIdx.x];
-    jt_pass<T, HASP + NCH, NCH, 1>(tasks[bk.task], bk, psi, bel, msg);
+    jt_pass<T, HASP + NCH, NCH, 1>(tasks[bk.task], bk, itab, psi, bel, msg);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -65,8 +65,8 @@ MsgView make_view(const PNode &p, const PSep &s, int psep, bool up) {
 }
 
 // Choose the F / A / R split of the high bits and fill every index table of the task.
-int plan_loops(const HostPlan &hp, JtTask &tk, int nbits, int real_bits, const std::vector<MsgView> &ins,
-               const std::vector<MsgView> &outs, int block_log2, std::string &err) {
+int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int nbits, int real_bits,
+               const std::vector<MsgView> &ins, const std::vector<MsgView> &outs, int block_log2, std::string &err) {
     const int TB = hp.TB;
     const int budget = hp.lds_budget > 0 ? hp.lds_budget : 32 * 1024;
     // at most 8 partial copies per outgoing message; small levels (few cliques) may use up to 64
@@ -104,7 +104,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, int nbits, int real_bits, const s
         int best = -1;
         long best_lds = 0;
         int best_part = 0;
-        for (int b = TB; b < nbits; ++b) {
+        for (int b = TB; b < nbits && nbits - popc(F) > TB + 2; ++b) {
             if (F >> b & 1) continue;
             long l = lds_of(F | 1u << b);
             int pl = part_log2(F | 1u << b);
@@ -120,6 +120,8 @@ int plan_loops(const HostPlan &hp, JtTask &tk, int nbits, int real_bits, const s
     }
     // 2. Parallelism: split until a workgroup handles at most 2^block_log2 elements, preferring
     //    bits that every outgoing message contains (no partial copies), highest bit first.
+    block_log2 = std::max(block_log2, TB + 2);          // a workgroup always runs >= 4 iterations
+    block_log2 = std::min(block_log2, TB + JT_MAX_ITER_LOG2);   // and at most 2^JT_MAX_ITER_LOG2
     while (nbits - popc(F) > block_log2) {
         int best = -1;
         for (int b = nbits - 1; b >= TB; --b)
@@ -138,7 +140,8 @@ int plan_loops(const HostPlan &hp, JtTask &tk, int nbits, int real_bits, const s
                 for (auto &m : ins) nin += (m.mask >> b) & 1;
                 if (pl < best_pl || (pl == best_pl && nin > best_in)) best_pl = pl, best_in = nin, best = b;
             }
-            if (best < 0 || best_pl > PMAX_LOG2) break;
+            if (best < 0) break;
+            if (best_pl > PMAX_LOG2 && nbits - popc(F) <= TB + JT_MAX_ITER_LOG2) break;
         }
         F |= 1u << best;
     }
@@ -203,23 +206,29 @@ int plan_loops(const HostPlan &hp, JtTask &tk, int nbits, int real_bits, const s
     for (int k = tk.n_in; k < JT_MAX_IN; ++k) slotw.push_back(std::vector<int>(32, 0));
     for (int k = 0; k < tk.n_out; ++k) fill_msg(tk.msg[JT_MAX_IN + k], outs[k], true);
     for (int k = tk.n_out; k < JT_MAX_OUT; ++k) slotw.push_back(std::vector<int>(32, 0));
-    tk.lds_bytes = std::max(lds, 16);
 
-    auto fill_delta = [&](int32_t (*d)[JT_NCOL], const std::vector<int> &bits) {
-        std::vector<int64_t> run(JT_NCOL, 0);
-        for (size_t t = 0; t < bits.size(); ++t) {
-            int b = bits[t];
-            int64_t w[JT_NCOL];
-            w[0] = (int64_t)1 << b;
-            for (int c = 1; c < JT_NCOL; ++c) w[c] = slotw[c - 1][b];
-            for (int c = 0; c < JT_NCOL; ++c) {
-                d[t][c] = (int32_t)(uint32_t)(w[c] - run[c]);   // wraps mod 2^32 for column 0
-                run[c] += w[c];
+    // iteration table: row i = (a, r), r the fast counter; column 0 = element offset, 1..4 = slot
+    // offsets into the incoming sub-boxes, 5..7 = into the outgoing sub-boxes (A bits only)
+    tk.total = 1 << (tk.nA + tk.nR);
+    itab.assign((size_t)tk.total * JT_NCOL, 0);
+    for (int i = 0; i < tk.total; ++i) {
+        const int r = i & ((1 << tk.nR) - 1), a = i >> tk.nR;
+        int64_t row[JT_NCOL] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < tk.nR; ++t)
+            if (r >> t & 1) {
+                row[0] += (int64_t)1 << Rb[t];
+                for (int c = 1; c < JT_NCOL; ++c) row[c] += slotw[c - 1][Rb[t]];
             }
-        }
-    };
-    fill_delta(tk.dA, Ab);
-    fill_delta(tk.dR, Rb);
+        for (int t = 0; t < tk.nA; ++t)
+            if (a >> t & 1) {
+                row[0] += (int64_t)1 << Ab[t];
+                for (int c = 1; c < JT_NCOL; ++c) row[c] += slotw[c - 1][Ab[t]];
+            }
+        for (int c = 0; c < JT_NCOL; ++c) itab[(size_t)i * JT_NCOL + c] = (int32_t)(uint32_t)row[c];
+        if (i < 4) tk.first_x[i] = (uint32_t)row[0];
+    }
+    tk.itab_lds = ((lds + 15) & ~15) + JT_STAGE_SCRATCH;
+    tk.lds_bytes = tk.itab_lds + tk.total * JT_NCOL * 4;
     return JTP_OK;
 }
 
@@ -459,7 +468,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             bit += hp.vbits[v];
         }
         if (bit > JT_MAX_BITS) FAIL(JTP_EUNSUPPORTED, "clique %d needs %d index bits (max %d)", p.real, bit, JT_MAX_BITS);
-        p.nbits = std::max(bit, hp.TB);
+        p.nbits = std::max(bit, hp.TB + 2);             // >= 4 loop iterations per workgroup
         if (p.nbits - hp.TB > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
     }
     for (size_t s = 0; s < hp.ps.size(); ++s) {
@@ -549,7 +558,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             memset(&tk, 0, sizeof tk);
             tk.pnode = c;
             tk.psi_off = p.owner == hp.rank ? p.arena_off : 0;          // other ranks' tasks are not executed here
-            tk.bel_off = (phase == 1 && p.real >= 0) ? (p.owner == hp.rank ? p.arena_off : 0) : -1;
+            tk.bel_off = phase == 1 ? (p.owner == hp.rank ? p.arena_off : 0) : -1;   // virtual cliques too (scratch)
             std::vector<MsgView> ins, outs;
             if (phase == 1 && p.psep >= 0) ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
             for (int k : p.children) ins.push_back(make_view(p, hp.ps[hp.pn[k].psep], hp.pn[k].psep, true));
@@ -557,8 +566,11 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             else for (int k : p.children) outs.push_back(make_view(p, hp.ps[hp.pn[k].psep], hp.pn[k].psep, false));
             int real_bits = 0;
             for (int nb : p.nb) real_bits += nb;
-            int rc = plan_loops(hp, tk, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth), err);
+            std::vector<int32_t> itab;
+            int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth), err);
             if (rc != JTP_OK) return rc;
+            tk.itab_off = (int64_t)hp.itab.size();
+            hp.itab.insert(hp.itab.end(), itab.begin(), itab.end());
             int ti = (int)hp.tasks.size();
             if (phase == 0) {
                 p.collect_task = ti;
@@ -717,8 +729,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
 // ------------------------------------------------------------------------------------------
 
 int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
-                           JtTask &tk, int &out_bits, int &npart, std::vector<JtBlock> &blocks,
-                           std::string &err) {
+                           JtTask &tk, std::vector<int32_t> &itab, int &out_bits, int &npart,
+                           std::vector<JtBlock> &blocks, std::string &err) {
     const PNode &p = hp.pn[pnode];
     PSep s;
     s.vars.assign(out_vars.rbegin(), out_vars.rend());       // last requested variable = lowest bits
@@ -739,7 +751,8 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int>
     outs.push_back(make_view(p, s, -1, true));
     int real_bits = 0;
     for (int nb : p.nb) real_bits += nb;
-    int rc = plan_loops(hp, tk, p.nbits, real_bits, ins, outs, 14, err);
+    int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
+    tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
     out_bits = bit;
     npart = tk.msg[JT_MAX_IN].npart;
@@ -849,17 +862,14 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             o << "{\"pnode\":" << tk.pnode << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
               << ",\"nR\":" << tk.nR << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
-              << ",\"lds_bytes\":" << tk.lds_bytes << ",\"f_x\":";
+              << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
+            json_list(o, tk.first_x, tk.first_x + 4);
+            o << ",\"f_x\":";
             json_list(o, tk.f_x, tk.f_x + tk.nF);
-            o << ",\"dA\":[";
-            for (int a = 0; a < tk.nA; ++a) {
-                if (a) o << ",";
-                json_list(o, tk.dA[a], tk.dA[a] + JT_NCOL);
-            }
-            o << "],\"dR\":[";
-            for (int r = 0; r < tk.nR; ++r) {
-                if (r) o << ",";
-                json_list(o, tk.dR[r], tk.dR[r] + JT_NCOL);
+            o << ",\"total\":" << tk.total << ",\"itab_lds\":" << tk.itab_lds << ",\"itab\":[";
+            for (int i = 0; i < tk.total; ++i) {
+                if (i) o << ",";
+                json_list(o, hp.itab.begin() + tk.itab_off + (size_t)i * JT_NCOL, hp.itab.begin() + tk.itab_off + (size_t)(i + 1) * JT_NCOL);
             }
             o << "],\"in\":[";
             for (int k = 0; k < tk.n_in; ++k) {

@@ -79,6 +79,7 @@ struct HostPlan {
     std::vector<int> task_variant;
     std::vector<Launch> launches;
     std::vector<JtBlock> blocks;
+    std::vector<int32_t> itab;           // iteration tables of all tasks (JtTask::itab_off)
     std::vector<uint32_t> block_chunk;   // chunk number of each block (description/tests)
     std::vector<VirtualFill> virtual_fills;
     std::vector<CommOp> comm;
@@ -99,7 +100,7 @@ int jtp_build_plan(const jtp_tree_desc *desc, HostPlan &hp, std::string &err);
 // out_vars[0] slowest, padded to power-of-two bits).  The task writes `npart` partial copies of
 // 2^out_bits doubles at msg-arena offset `dst_off`.  Returns JTP_OK or error.
 int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
-                           JtTask &task, int &out_bits, int &npart, std::vector<JtBlock> &blocks,
+                           JtTask &task, std::vector<int32_t> &itab, int &out_bits, int &npart, std::vector<JtBlock> &blocks,
                            std::string &err);
 
 void jtp_plan_to_json(HostPlan &hp, bool with_tasks);

@@ -14,20 +14,6 @@ import numpy as np
 JT_MAX_IN = 4
 
 
-def _ctz(n):
-    return (n & -n).bit_length() - 1
-
-
-def _loop_offsets(delta_rows, col, count):
-    """offsets[i] after i increments, built incrementally as the kernel does (mod 2^32)."""
-    out = np.zeros(count, dtype=np.int64)
-    cur = 0
-    for i in range(1, count):
-        cur = (cur + delta_rows[_ctz(i)][col]) & 0xFFFFFFFF
-        out[i] = cur
-    return out
-
-
 def _signed(v):
     v = np.asarray(v, dtype=np.int64) & 0xFFFFFFFF
     return np.where(v >= 2 ** 31, v - 2 ** 32, v)
@@ -145,23 +131,25 @@ class Emulator:
         for m in ins:
             assert bool(m["e_dep"]) == any(m["e_w"][e] != 0 for e in range(EB))
 
-        xa = _loop_offsets(tk["dA"], 0, nA)
-        xr = _loop_offsets(tk["dR"], 0, nR)
-        oa_in = [_signed(_loop_offsets(tk["dA"], 1 + k, nA)) for k in range(n_in)]
-        or_in = [_signed(_loop_offsets(tk["dR"], 1 + k, nR)) for k in range(n_in)]
-        oa_out = [_signed(_loop_offsets(tk["dA"], 1 + JT_MAX_IN + j, nA)) for j in range(n_out)]
-        for j in range(n_out):      # R bits never belong to an outgoing message
-            assert not np.any(_loop_offsets(tk["dR"], 1 + JT_MAX_IN + j, nR))
-
+        itab = np.asarray(tk["itab"], dtype=np.int64).reshape(nA, nR, 8)      # row i = a * nR + r
+        assert tk["total"] == nA * nR and 4 <= tk["total"] <= 256
+        assert tk["itab_lds"] + tk["total"] * 32 == tk["lds_bytes"]
+        xoff = itab[:, :, 0] & 0xFFFFFFFF
+        for i in range(4):
+            assert tk["first_x"][i] == xoff.ravel()[i]
+        in_off = [_signed(itab[:, :, 1 + k]) for k in range(n_in)]
+        out_off = [_signed(itab[:, :, 1 + JT_MAX_IN + j]) for j in range(n_out)]
+        for j in range(n_out):      # the kernel reads outgoing offsets once per A iteration
+            assert np.all(out_off[j] == out_off[j][:, :1])
         # element index of every (a, r, tid, e)
-        x = (xF + xa[:, None, None, None] + xr[None, :, None, None]
+        x = (xF + xoff[:, :, None, None]
              + (tid * VEC)[None, None, :, None] + np.arange(VEC)[None, None, None, :]) & 0xFFFFFFFF
         assert x.max() < (1 << tk["nbits"])
         assert len(np.unique(x)) == x.size            # every element visited exactly once
         p = self.psi[tk["psi_off"] + x]
         vals = []
         for k, m in enumerate(ins):
-            slot = (oa_in[k][:, None, None, None] + or_in[k][None, :, None, None]
+            slot = (in_off[k][:, :, None, None]
                     + thread_off(m)[None, None, :, None] + e_off(m)[None, None, None, :])
             assert slot.min() >= 0 and slot.max() < len(subs[k])
             vals.append(subs[k][slot])
@@ -188,7 +176,7 @@ class Emulator:
             if tk["bel_off"] >= 0:
                 self.bel[tk["bel_off"] + x] = b
         for j, m in enumerate(outs):
-            slot = (oa_out[j][:, None, None, None] + np.zeros((1, nR, 1, 1), dtype=np.int64)
+            slot = (out_off[j][:, :, None, None]
                     + thread_off(m)[None, None, :, None] + e_off(m)[None, None, None, :])
             assert slot.min() >= 0 and slot.max() < len(osubs[j])
             np.add.at(osubs[j], slot.ravel(), contrib[j].ravel())
