@@ -130,15 +130,19 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
                 break;
             }
         if (best < 0) {
-            // otherwise: fewest partial copies, then the bit most incoming messages contain
-            // (smaller staged sub-boxes), then the highest
-            int best_pl = 1 << 30, best_in = -1;
+            // otherwise: a bit of SOME outgoing message first (left in the loops it would be an A
+            // bit, i.e. an epilogue per iteration, whereas bits of no outgoing message make the free
+            // register-summed R loop), then fewest partial copies, then the bit most incoming
+            // messages contain (smaller staged sub-boxes), then the highest
+            int best_pl = 1 << 30, best_in = -1, best_cls = 9;
             for (int b = nbits - 1; b >= TB; --b) {
                 if (F >> b & 1) continue;
                 int pl = part_log2(F | 1u << b);
+                int cls = (allout >> b & 1) ? 0 : 1;
                 int nin = 0;
                 for (auto &m : ins) nin += (m.mask >> b) & 1;
-                if (pl < best_pl || (pl == best_pl && nin > best_in)) best_pl = pl, best_in = nin, best = b;
+                if (cls < best_cls || (cls == best_cls && (pl < best_pl || (pl == best_pl && nin > best_in))))
+                    best_cls = cls, best_pl = pl, best_in = nin, best = b;
             }
             if (best < 0) break;
             if (best_pl > PMAX_LOG2 && nbits - popc(F) <= TB + JT_MAX_ITER_LOG2) break;
@@ -412,13 +416,15 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         if (hp.layout_policy == 1 || seps.empty()) {
             order.assign(host.rbegin(), host.rend());
         } else {
-            // Classes: priv = in no separator; part = in some but not all child separators (or
-            // only the parent's); allc = in every child separator (leaf: in the parent's).
-            // Target shape, low to high:  e bits <- priv | lane bits <- part | wave bits <- allc
-            // | rest of part, allc | rest of priv.  Outgoing-message bits in the thread part
-            // need no cross-lane sum; private bits up high become the register-summed R loop.
+            // Classes: priv = in no separator; ponly = only in the parent's; xorc = in some but not
+            // all child separators; allc = in every child separator (leaf: in the parent's).
+            // Target shape, low to high:  e bits <- priv | lane bits <- xorc | wave bits <- allc |
+            // rest of xorc, allc | ponly, priv.  Bits of outgoing messages that sit in the thread
+            // part need no cross-lane sum and no outer (A) loop; bits in every outgoing message can
+            // be fixed per workgroup (F) without partial copies; everything else up high becomes the
+            // register-summed R loop of the distribute pass, which moves twice the bytes of collect.
             int nchild = (int)p.children.size();
-            std::vector<int> priv, part, allc;
+            std::vector<int> priv, ponly, part, allc;
             for (size_t i = 0; i < host.size(); ++i) {
                 int v = host[i];
                 int in_parent = p.psep >= 0 && find_var(hp.ps[p.psep].vars, v) >= 0;
@@ -426,6 +432,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
                 for (int k : p.children) in_child += find_var(hp.ps[hp.pn[k].psep].vars, v) >= 0;
                 if (!in_parent && !in_child) priv.push_back(v);
                 else if ((nchild > 0 && in_child == nchild) || nchild == 0) allc.push_back(v);
+                else if (in_child == 0) ponly.push_back(v);
                 else part.push_back(v);
             }
             auto take = [&](std::vector<int> &from, int want_bits) {
@@ -438,24 +445,28 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
                 }
                 return got;
             };
-            int got = take(priv, hp.EB);
-            if (got < hp.EB) got += take(part, hp.EB - got);
-            if (got < hp.EB) got += take(allc, hp.EB - got);
             auto bits_of = [&](const std::vector<int> &l) {
                 int b = 0;
                 for (int v : l) b += hp.vbits[v];
                 return b;
             };
+            int got = take(priv, hp.EB);
+            if (got < hp.EB) got += take(ponly, hp.EB - got);
+            if (got < hp.EB) got += take(part, hp.EB - got);
+            if (got < hp.EB) got += take(allc, hp.EB - got);
             int lane = take(part, 6);
             // lanes prefer message bits (no shuffle sum) but leave two allc bits for the waves
             while (lane < 6 && !allc.empty() && bits_of(allc) - hp.vbits[allc.front()] >= 2) lane += take(allc, 1);
+            if (lane < 6) lane += take(ponly, 6 - lane);
             if (lane < 6) lane += take(priv, 6 - lane);
             if (lane < 6) lane += take(allc, 6 - lane);
             int wave = take(allc, 2);
             if (wave < 2) wave += take(part, 2 - wave);
+            if (wave < 2) wave += take(ponly, 2 - wave);
             if (wave < 2) wave += take(priv, 2 - wave);
             take(part, 1 << 20);
             take(allc, 1 << 20);
+            take(ponly, 1 << 20);
             take(priv, 1 << 20);
         }
         p.vars = order;
