@@ -89,6 +89,10 @@ def main():
     import ctypes as C
     from junctiontree_amd import _capi, engine, partition, synthetic
     lib = _capi.lib()                               # loads libjtprop.so (and its HIP runtime) first
+    ndev = _capi.device_count()
+    if ndev <= 0:
+        raise SystemExit("no HIP device visible: bench.py measures the GPU path only")
+    device = local_rank % ndev                      # one process per GPU (ranks > GPUs only in smoke runs)
 
     dist = None
     if world > 1:
@@ -100,7 +104,7 @@ def main():
             _capi.check(lib.jtp_comm_unique_id(buf))
             uid = [buf.raw]
         dist.broadcast_object_list(uid, src=0)
-        _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid[0]), local_rank))
+        _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid[0]), device))
 
     def barrier():
         if dist is not None:
@@ -113,7 +117,7 @@ def main():
     n = spec["n_cliques"]
     owner = partition.subtree_owners(spec["parent"], [1.0] * n, world)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=args.dtype,
-                       device=local_rank, n_ranks=world, rank=rank, owner=owner,
+                       device=device, n_ranks=world, rank=rank, owner=owner,
                        block_log2=args.block_log2, lds_budget=args.lds_budget,
                        layout_policy=args.layout_policy, split_variants=args.split_variants)
     plan.fill_synthetic(1, spec["scales"])

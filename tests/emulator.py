@@ -187,11 +187,16 @@ class Emulator:
             self.msg[dst] = osubs[j]
 
     # ---------------------------------------------------------------- whole schedule
-    def propagate(self):
+    def propagate(self, comm=None):
+        """Run the plan's step list.  `comm(ops, msg)` executes one exchange group (a list of the
+        plan's comm records) on the message arena `msg`; it is required for multi-rank plans."""
         d = self.d
         self.msg[:] = np.nan
         for kind, first, count in d["steps"]:
-            assert kind == 0, "the emulator runs single-rank plans"
+            if kind == 1:
+                assert comm is not None, "multi-rank plan needs a comm callback"
+                comm(d["comm"][first:first + count], self.msg)
+                continue
             launch = d["launches"][first]
             blocks = d["blocks"][launch["blk_off"]:launch["blk_off"] + launch["nblocks"]]
             seen = set()

@@ -1,0 +1,130 @@
+"""The N > 1 path on CPU: two processes (gloo), each holding one part of the tree.
+
+The partition (junctiontree_amd/partition.py), the per-rank plan and its exchange schedule
+(send/recv groups between level launches, emitted by the C planner) are the product's host
+logic; here each rank executes ITS plan with the CPU emulator of the task tables and moves the
+separator messages with torch.distributed (gloo) exactly where the GPU build calls
+ncclSend/ncclRecv.  Rank 0 then checks every belief against the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, recipe, kwargs, queue):
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (os.path.join(root, "junction-tree_amd"), os.path.join(root, "oracle"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from emulator import Emulator
+    from junctiontree_amd import engine, partition, synthetic
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = getattr(synthetic, recipe)(**kwargs)
+        n = spec["n_cliques"]
+        weights = [float(np.prod([spec["sizes"][v] for v in spec["node_vars"][c]])) for c in range(n)]
+        owner = partition.subtree_owners(spec["parent"], weights, world)
+        assert len(set(owner)) == world
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", plan_only=True,
+                           n_ranks=world, rank=rank, owner=owner, block_log2=12)
+        desc = plan.describe()
+        emu = Emulator(desc)
+        pots = synthetic.potentials_for(spec, seed=9)
+        for c in range(n):
+            if owner[c] == rank:
+                ids = [plan.var_id[v] for v in spec["node_vars"][c]]
+                emu.set_potential(c, ids, [spec["sizes"][v] for v in spec["node_vars"][c]], pots[c])
+
+        def comm(ops, msg):
+            reqs, recvs = [], []
+            for op in ops:
+                view = msg[op["off"]:op["off"] + op["count"]]
+                if op["send"]:
+                    assert not np.any(np.isnan(view)), "sending a message that was never computed"
+                    reqs.append(dist.isend(torch.from_numpy(view.copy()), dst=op["peer"]))
+                else:
+                    buf = torch.empty(op["count"], dtype=torch.float64)
+                    reqs.append(dist.irecv(buf, src=op["peer"]))
+                    recvs.append((view, buf))
+            for r in reqs:
+                r.wait()
+            for view, buf in recvs:
+                view[:] = buf.numpy()
+
+        emu.propagate(comm)
+        mine = {}
+        for c in range(n):
+            if owner[c] == rank:
+                ids = [plan.var_id[v] for v in spec["node_vars"][c]]
+                mine[c] = emu.belief(c, ids, [spec["sizes"][v] for v in spec["node_vars"][c]])
+        n_comm = len(desc["comm"])
+        gathered = [None] * world
+        dist.gather_object((mine, n_comm, owner), gathered if rank == 0 else None, dst=0)
+        if rank == 0:
+            import jt_oracle as oracle
+            want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
+            seen = {}
+            for part, _, _ in gathered:
+                seen.update(part)
+            assert sorted(seen) == list(range(n))
+            for c in range(n):
+                np.testing.assert_allclose(seen[c], want[c], rtol=1e-11, atol=1e-14)
+            cuts = sum(1 for c in range(1, n) if owner[c] != owner[spec["parent"][c]])
+            # every cut edge carries one message up and one down, seen once by each side
+            assert sum(g[1] for g in gathered) == 4 * cuts
+            queue.put(("ok", cuts))
+    except Exception as exc:                        # noqa: BLE001
+        queue.put(("error rank %d" % rank, repr(exc)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("recipe,kwargs", [
+    ("wide_binary_tree", {"n_cliques": 15, "width": 12, "sep": 6, "card": 2, "seed": 1}),
+    ("random_tree", {"n_cliques": 14, "width": 11, "sep": 5, "card": 2, "seed": 3}),
+])
+def test_two_rank_exchange_schedule(recipe, kwargs):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, recipe, kwargs, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("multi-rank worker hung")
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    status, cuts = queue.get(timeout=5)
+    assert status == "ok" and cuts >= 1
+
+
+def test_partition_is_balanced_for_the_benchmark_tree():
+    from junctiontree_amd import partition, synthetic
+    spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+    for world in (2, 4, 8):
+        owner = partition.subtree_owners(spec["parent"], [1.0] * 256, world)
+        loads = partition.part_weights(owner, [1.0] * 256, world)
+        assert max(loads) <= 256 / world * 1.25
+        cuts = sum(1 for c in range(1, 256) if owner[c] != owner[spec["parent"][c]])
+        assert cuts <= world          # shallow quotient tree: at most one cut per part
