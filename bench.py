@@ -18,8 +18,10 @@ plan's own stream during the timed steps.  `cpu_baseline` times the numpy restat
 reference's einsum sequence (oracle/jt_oracle.py: beliefs_refshaped) on one host core over a
 bounded sample of the same workload; it is a checker/baseline, never the measured path.
 
-torch is imported only for the rendezvous (gloo barrier / all-reduce of the timings) and only
-AFTER libjtprop.so is loaded, so the HIP runtime in the process is the one libjtprop links.
+No torch in this process: the launcher (torch.distributed.run) only provides RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT; the rendezvous (RCCL unique id, barrier, max of the
+timings) runs over plain sockets (junctiontree_amd/rendezvous.py), because importing torch next
+to libjtprop.so brings a second ROCm runtime into the process and RCCL's communicator init fails.
 """
 
 import argparse
@@ -94,21 +96,20 @@ def main():
         raise SystemExit("no HIP device visible: bench.py measures the GPU path only")
     device = local_rank % ndev                      # one process per GPU (ranks > GPUs only in smoke runs)
 
-    dist = None
+    from junctiontree_amd.rendezvous import Rendezvous
+    rdzv = Rendezvous(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                      int(os.environ.get("MASTER_PORT", "29500")) + 1)
     if world > 1:
-        import torch.distributed as dist            # rendezvous only (CPU, gloo)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        uid = [bytes(128)]
+        uid = None
         if rank == 0:
             buf = C.create_string_buffer(128)
             _capi.check(lib.jtp_comm_unique_id(buf))
-            uid = [buf.raw]
-        dist.broadcast_object_list(uid, src=0)
-        _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid[0]), device))
+            uid = buf.raw
+        uid = rdzv.broadcast(uid)
+        _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid), device))
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        rdzv.barrier()
 
     spec = synthetic.wide_binary_tree(n_cliques=args.cliques, width=args.width, sep=args.sep,
                                       card=args.card, seed=0)
@@ -134,12 +135,7 @@ def main():
         plan.propagate(sync=False)
     plan.sync()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = rdzv.allreduce_max(time.perf_counter() - t0)      # max over ranks
 
     stats = plan.stats()
     z = plan.z() if plan.owns(plan.root) else None
@@ -191,10 +187,10 @@ def main():
         print(json.dumps(out), flush=True)
 
     plan.close()
-    if dist is not None:
+    if world > 1:
         barrier()
         lib.jtp_comm_destroy()
-        dist.destroy_process_group()
+    rdzv.close()
 
 
 if __name__ == "__main__":

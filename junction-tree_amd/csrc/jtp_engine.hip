@@ -674,6 +674,32 @@ int jtp_comm_init(int32_t rank, int32_t n_ranks, const void *id128, int32_t devi
     return JTP_OK;
 }
 
+int jtp_comm_selftest(int32_t n) {
+    if (!rccl::comm) return set_err(JTP_ECOMM, "communicator not initialised");
+    if (n <= 0) return set_err(JTP_EINVAL, "n must be positive");
+    double *a = nullptr, *b = nullptr;
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void **)&a, (size_t)n * 8));
+    HIP_TRY(hipMalloc((void **)&b, (size_t)n * 8));
+    std::vector<double> h(n), back(n, -1.0);
+    for (int i = 0; i < n; ++i) h[i] = 0.5 * i + 1.0;
+    HIP_TRY(hipMemcpyAsync(a, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(b, 0, (size_t)n * 8, s));
+    NCCL_TRY(rccl::GroupStart());
+    NCCL_TRY(rccl::Send(a, (size_t)n, rccl::ncclFloat64, rccl::comm_rank, rccl::comm, s));
+    NCCL_TRY(rccl::Recv(b, (size_t)n, rccl::ncclFloat64, rccl::comm_rank, rccl::comm, s));
+    NCCL_TRY(rccl::GroupEnd());
+    HIP_TRY(hipMemcpyAsync(back.data(), b, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(a);
+    (void)hipFree(b);
+    (void)hipStreamDestroy(s);
+    for (int i = 0; i < n; ++i)
+        if (back[i] != h[i]) return set_err(JTP_ECOMM, "self send/recv mismatch at %d: %g vs %g", i, back[i], h[i]);
+    return JTP_OK;
+}
+
 int jtp_comm_destroy(void) {
     if (rccl::comm) {
         NCCL_TRY(rccl::CommDestroy(rccl::comm));

@@ -292,3 +292,23 @@ def test_full_size_c4_properties():
     assert abs(plan2.z() - 2 * z) <= 2e-6 * z
     plan.close()
     plan2.close()
+
+
+def test_rccl_binding_single_rank_selftest():
+    """One-rank RCCL communicator: unique id, init, grouped send/recv to self, destroy."""
+    import ctypes as C
+    from junctiontree_amd import _capi
+    lib = _capi.lib()
+    buf = C.create_string_buffer(128)
+    _capi.check(lib.jtp_comm_unique_id(buf))
+    _capi.check(lib.jtp_comm_init(0, 1, buf, 0))
+    try:
+        _capi.check(lib.jtp_comm_selftest(1024))
+        spec = synthetic.wide_binary_tree(n_cliques=7, width=12, sep=6, card=2, seed=1)
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", n_ranks=1, rank=0)
+        plan.fill_synthetic(3, spec["scales"])
+        plan.propagate()
+        assert np.isfinite(plan.z())
+        plan.close()
+    finally:
+        _capi.check(lib.jtp_comm_destroy())

@@ -128,3 +128,30 @@ def test_partition_is_balanced_for_the_benchmark_tree():
         assert max(loads) <= 256 / world * 1.25
         cuts = sum(1 for c in range(1, 256) if owner[c] != owner[spec["parent"][c]])
         assert cuts <= world          # shallow quotient tree: at most one cut per part
+
+
+def _rdzv_worker(rank, world, port, queue):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "junction-tree_amd"))
+    from junctiontree_amd.rendezvous import Rendezvous
+    z = Rendezvous(rank, world, "127.0.0.1", port)
+    payload = z.broadcast(b"x" * 128 if rank == 0 else None)
+    z.barrier()
+    m = z.allreduce_max(1.0 + rank)
+    z.close()
+    queue.put((rank, payload, m))
+
+
+def test_socket_rendezvous_used_by_bench():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, 3, port, queue)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=60)
+    got = sorted(queue.get(timeout=5) for _ in range(3))
+    assert [g[0] for g in got] == [0, 1, 2]
+    assert all(g[1] == b"x" * 128 and g[2] == 3.0 for g in got)
