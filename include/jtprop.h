@@ -138,9 +138,13 @@ int jtp_get_z(jtp_plan *plan, int32_t batch, double *z);
 
 /* ---- instrumentation ------------------------------------------------------------------ */
 
-/* hipEvent pair around every launch of the next `keep` propagates (ring; 0 switches it off).
- * jtp_get_stats then reports per-variant device time as the mean per propagate. */
+/* Device timing of the next `keep` propagates with hipEvents on the plan's stream (ring; 0
+ * switches it off).  per_launch = 0: three events per propagate (start, collect/distribute
+ * boundary, end) - cheap enough to stay on in a timed benchmark region; per_launch = 1: an event
+ * pair around every launch (about 4 us of idle GPU per event).  jtp_get_stats reports the mean
+ * per propagate. */
 int jtp_set_profiling(jtp_plan *plan, int32_t keep);
+int jtp_set_profiling_granularity(jtp_plan *plan, int32_t per_launch);
 int jtp_get_stats(jtp_plan *plan, jtp_stats *stats);
 /* Mean device time (ms) of each of the plan's launches, in schedule order; `n` = capacity of
  * `ms`.  Returns the number of launches (or a negative error).  Needs jtp_set_profiling. */

@@ -145,6 +145,7 @@ struct jtp_plan {
     int prof_steps = 0;             // 0: off; else ring of this many event sets
     std::vector<hipEvent_t> ev;     // prof_steps x (2 per launch)
     int prof_cursor = 0;            // propagates recorded since profiling was switched on
+    bool prof_per_launch = false;   // event pair per launch instead of three per propagate
     int esize = 4;
 };
 
@@ -396,25 +397,34 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
     if (batch_end <= batch_begin || batch_end > hp.n_batch) return set_err(JTP_EINVAL, "bad batch range [%d,%d)", batch_begin, batch_end);
     HIP_TRY(hipSetDevice(hp.device));
     const bool prof = pl->prof_steps > 0;
+    const size_t ev_per_step = pl->prof_per_launch ? 2 * hp.launches.size() : 3;
     if (prof) {
-        size_t need = 2 * hp.launches.size() * (size_t)pl->prof_steps;
+        size_t need = ev_per_step * (size_t)pl->prof_steps;
         while (pl->ev.size() < need) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
             pl->ev.push_back(e);
         }
     }
-    const size_t ev_base = prof ? 2 * hp.launches.size() * (size_t)(pl->prof_cursor % pl->prof_steps) : 0;
+    const size_t ev_base = prof ? ev_per_step * (size_t)(pl->prof_cursor % pl->prof_steps) : 0;
     for (int b = batch_begin; b < batch_end; ++b) {
         hipStream_t s = pl->streams[b % pl->streams.size()];
         BatchBuffers &bb = pl->bufs[b];
         const bool pb = prof && b == batch_begin;
+        const bool per_launch = pb && pl->prof_per_launch;
+        const bool per_phase = pb && !pl->prof_per_launch;
+        bool mid_done = false;
+        if (per_phase) HIP_TRY(hipEventRecord(pl->ev[ev_base + 0], s));
         for (const Step &st : hp.steps) {
             if (st.kind == 0) {
                 const Launch &L = hp.launches[st.first];
-                if (pb) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first], s));
+                if (per_phase && !mid_done && L.phase == 1) {
+                    HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
+                    mid_done = true;
+                }
+                if (per_launch) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first], s));
                 launch_variant(pl, L.variant, L.nblocks, L.lds_bytes, s, pl->d_tasks, pl->d_blocks + L.blk_off, pl->d_itab, bb.psi, bb.bel, bb.msg);
-                if (pb) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first + 1], s));
+                if (per_launch) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first + 1], s));
             } else {
                 NCCL_TRY(rccl::GroupStart());
                 for (int i = st.first; i < st.first + st.count; ++i) {
@@ -424,6 +434,10 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 }
                 NCCL_TRY(rccl::GroupEnd());
             }
+        }
+        if (per_phase) {
+            if (!mid_done) HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
+            HIP_TRY(hipEventRecord(pl->ev[ev_base + 2], s));
         }
         if (pb) pl->prof_cursor++;
     }
@@ -597,6 +611,13 @@ int jtp_set_profiling(jtp_plan *pl, int32_t on) {
     return JTP_OK;
 }
 
+int jtp_set_profiling_granularity(jtp_plan *pl, int32_t per_launch) {
+    if (!pl) return set_err(JTP_EINVAL, "null plan");
+    pl->prof_per_launch = per_launch != 0;
+    pl->prof_cursor = 0;
+    return JTP_OK;
+}
+
 int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     if (!pl || !st) return set_err(JTP_EINVAL, "null argument");
     HostPlan &hp = pl->hp;
@@ -614,16 +635,34 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     if (pl->device && pl->prof_steps > 0 && pl->prof_cursor > 0) {
         HIP_TRY(hipSetDevice(hp.device));
         const int kept = std::min(pl->prof_cursor, pl->prof_steps);
-        for (int k = 0; k < kept; ++k) {
-            const size_t base = 2 * hp.launches.size() * (size_t)k;
-            for (size_t i = 0; i < hp.launches.size(); ++i) {
-                const Launch &L = hp.launches[i];
-                HIP_TRY(hipEventSynchronize(pl->ev[base + 2 * i + 1]));
-                float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, pl->ev[base + 2 * i], pl->ev[base + 2 * i + 1]));
-                st->kernel_ms[L.variant] += ms / kept;      // mean per propagate
-                if (L.phase == 0) st->collect_ms += ms / kept;
-                else st->distribute_ms += ms / kept;
+        if (pl->prof_per_launch) {
+            for (int k = 0; k < kept; ++k) {
+                const size_t base = 2 * hp.launches.size() * (size_t)k;
+                for (size_t i = 0; i < hp.launches.size(); ++i) {
+                    const Launch &L = hp.launches[i];
+                    HIP_TRY(hipEventSynchronize(pl->ev[base + 2 * i + 1]));
+                    float ms = 0;
+                    HIP_TRY(hipEventElapsedTime(&ms, pl->ev[base + 2 * i], pl->ev[base + 2 * i + 1]));
+                    st->kernel_ms[L.variant] += ms / kept;      // mean per propagate
+                    if (L.phase == 0) st->collect_ms += ms / kept;
+                    else st->distribute_ms += ms / kept;
+                }
+            }
+        } else {
+            for (int k = 0; k < kept; ++k) {
+                const size_t base = 3 * (size_t)k;
+                HIP_TRY(hipEventSynchronize(pl->ev[base + 2]));
+                float c = 0, d = 0;
+                HIP_TRY(hipEventElapsedTime(&c, pl->ev[base + 0], pl->ev[base + 1]));
+                HIP_TRY(hipEventElapsedTime(&d, pl->ev[base + 1], pl->ev[base + 2]));
+                st->collect_ms += c / kept;
+                st->distribute_ms += d / kept;
+            }
+            // with one kernel per phase (the default), the phase time is that kernel's time over
+            // its back-to-back launches (gaps included)
+            if (!(hp.flags & JTP_SPLIT_VARIANTS)) {
+                st->kernel_ms[JT_K_COLLECT_LEVEL] = st->collect_ms;
+                st->kernel_ms[JT_K_DISTRIBUTE_LEVEL] = st->distribute_ms;
             }
         }
     }
@@ -634,7 +673,8 @@ int jtp_get_launch_ms(jtp_plan *pl, double *out, int32_t n) {
     if (!pl) return set_err(JTP_EINVAL, "null plan");
     HostPlan &hp = pl->hp;
     const int nl = (int)hp.launches.size();
-    if (!(pl->device && pl->prof_steps > 0 && pl->prof_cursor > 0)) return set_err(JTP_EINVAL, "profiling is off or nothing was recorded");
+    if (!(pl->device && pl->prof_steps > 0 && pl->prof_cursor > 0 && pl->prof_per_launch))
+        return set_err(JTP_EINVAL, "per-launch profiling is off or nothing was recorded");
     HIP_TRY(hipSetDevice(hp.device));
     const int kept = std::min(pl->prof_cursor, pl->prof_steps);
     for (int i = 0; i < nl && i < n; ++i) out[i] = 0.0;

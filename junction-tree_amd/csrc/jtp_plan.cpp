@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <sstream>
@@ -547,9 +548,13 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     }
     auto block_log2_for = [&](int phase, int level) {
         if (hp.block_log2 > 0) return std::max(hp.block_log2, hp.TB);
-        double want = lvl_elems[phase][level] / 2048.0;
-        int lg = 13;
-        while (lg < 16 && (double)(1 << (lg + 1)) <= want) ++lg;
+        // aim at ~2048 workgroups per launch (8 per CU), each streaming 32 KiB .. 256 KiB
+        static const double target = getenv("JTP_TARGET_BLOCKS") ? atof(getenv("JTP_TARGET_BLOCKS")) : 2048.0;
+        static const int lgmin = getenv("JTP_MIN_BLOCK_LOG2") ? atoi(getenv("JTP_MIN_BLOCK_LOG2")) : 13;
+        static const int lgmax = getenv("JTP_MAX_BLOCK_LOG2") ? atoi(getenv("JTP_MAX_BLOCK_LOG2")) : 16;
+        double want = lvl_elems[phase][level] / target;
+        int lg = lgmin;
+        while (lg < lgmax && (double)(1 << (lg + 1)) <= want) ++lg;
         return std::max(lg, hp.TB);
     };
 

@@ -196,8 +196,10 @@ class Plan:
         return val.value
 
     # ------------------------------------------------------------------ instrumentation
-    def set_profiling(self, keep=1):
-        """Record a hipEvent pair around every launch of the next `keep` propagates."""
+    def set_profiling(self, keep=1, per_launch=False):
+        """Time the next `keep` propagates with hipEvents on the plan's stream: three events per
+        propagate (phase times), or with `per_launch` a pair around every launch."""
+        _capi.check(self._lib.jtp_set_profiling_granularity(self._handle, 1 if per_launch else 0))
         _capi.check(self._lib.jtp_set_profiling(self._handle, int(keep)))
 
     def launch_ms(self):
