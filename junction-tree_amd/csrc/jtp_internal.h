@@ -52,7 +52,7 @@ struct JtTask {
     int32_t lds_bytes;
     int32_t pnode;             // planner node this task belongs to
     int32_t real_bits;         // index bits actually used by variables (<= nbits; rest is padding)
-    int32_t pad0;
+    int32_t debug;             // timing experiments only (JTP_DEBUG): 1 = skip epilogues and flush
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
     uint32_t first_x[4];       // element offsets of loop iterations 0..3 (relative to the chunk base)
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer

@@ -160,6 +160,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     }
     tk.nbits = nbits;
     tk.real_bits = real_bits;
+    tk.debug = getenv("JTP_DEBUG") ? atoi(getenv("JTP_DEBUG")) : 0;
     tk.nF = (int)Fb.size();
     tk.nA = (int)Ab.size();
     tk.nR = (int)Rb.size();

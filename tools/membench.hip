@@ -45,6 +45,38 @@ __global__ __launch_bounds__(256) void read_strided(const float4* __restrict__ i
     }
     if (a0 + a1 + a2 + a3 == 12345.678) out[0] = a0;
 }
+// the jt_pass loop skeleton: iteration offsets from an LDS table, 4 static load slots,
+// fp64 accumulation; VARIANT 0 = as in the kernel, 1 = offsets computed (no LDS table)
+template <int VARIANT>
+__global__ __launch_bounds__(256) void jt_like(const float* __restrict__ in, double* __restrict__ out, int total, const int* __restrict__ gtab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* tabw = reinterpret_cast<int*>(smem);
+    const int tid = threadIdx.x;
+    const unsigned xF = (blockIdx.x / 4) * 262144u + (blockIdx.x % 4) * 1024u + tid * 4u;
+    float4 q0 = *reinterpret_cast<const float4*>(in + xF + 0 * 4096u);
+    float4 q1 = *reinterpret_cast<const float4*>(in + xF + 1 * 4096u);
+    float4 q2 = *reinterpret_cast<const float4*>(in + xF + 2 * 4096u);
+    float4 q3 = *reinterpret_cast<const float4*>(in + xF + 3 * 4096u);
+    for (int i = tid; i < total * 8; i += 256) tabw[i] = gtab[i];
+    __syncthreads();
+    const int* tab = tabw;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    auto step = [&](float4& slot, int i) {
+        const float4 v = slot;
+        const int inext = (i + 4 < total) ? i + 4 : total - 1;
+        unsigned xo;
+        if (VARIANT == 0) xo = (unsigned)tab[inext * 8];
+        else xo = (unsigned)inext * 4096u;
+        slot = *reinterpret_cast<const float4*>(in + (xF + xo));
+        if (VARIANT == 0) {
+            const int4 r0 = *reinterpret_cast<const int4*>(tab + i * 8);
+            if (r0.y == 12345) a0 += 1.0;
+        }
+        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    };
+    for (int i0 = 0; i0 < total; i0 += 4) { step(q0, i0); step(q1, i0 + 1); step(q2, i0 + 2); step(q3, i0 + 3); }
+    if (a0 + a1 + a2 + a3 == 12345.678) out[0] = a0;
+}
 int main() {
     const size_t bytes = (size_t)1 << 30;
     float4 *a, *b; double* o;
@@ -87,6 +119,24 @@ int main() {
             CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) printf("read_strided<1> same: %.1f GB/s\n", 10.0 * bytes / ms / 1e6);
             // 16 pieces per block at stride 64 KiB (16 blocks interleave)
+        }
+    }
+    {
+        std::vector<int> tab(64 * 8, 0);
+        for (int i = 0; i < 64; ++i) tab[i * 8] = i * 4096;
+        int* dtab; CK(hipMalloc(&dtab, tab.size() * 4)); CK(hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        for (int blocks : {2048, 4096}) for (int rep = 0; rep < 2; ++rep) {
+            float ms;
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(jt_like<0>, dim3(blocks), dim3(256), 6144, 0, (const float*)a, o, 64, dtab);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("jt_like<0> (LDS table) blocks %d: %.1f GB/s\n", blocks, 10.0 * blocks * 262144.0 / ms / 1e6);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(jt_like<1>, dim3(blocks), dim3(256), 6144, 0, (const float*)a, o, 64, dtab);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("jt_like<1> (computed offsets) blocks %d: %.1f GB/s\n", blocks, 10.0 * blocks * 262144.0 / ms / 1e6);
         }
     }
     return 0;
