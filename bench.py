@@ -71,7 +71,8 @@ def main():
     ap.add_argument("--sep", type=int, default=10)
     ap.add_argument("--card", type=int, default=2)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--cpu-sample", type=int, default=63, help="cliques in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=256,
+                    help="cliques in the CPU baseline tree (default: the full workload, ~10-25 s on one core; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="no hipEvent pairs in the timed region")
     ap.add_argument("--block-log2", type=int, default=0)
     ap.add_argument("--lds-budget", type=int, default=0)
@@ -174,9 +175,17 @@ def main():
             per_launch_bytes = k["bytes"] / k["launches"]
             per_launch_ms = k["ms"] / k["launches"]
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            traffic = None                 # HBM bytes per launch from the committed PMC passes (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
+                    prof = json.load(fh)["kernels"]
+                if args.cliques == 256 and args.width == 20 and world == 1 and args.dtype == "f32":
+                    traffic = prof["void " + name]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "launches_per_step": k["launches"], "avg_launch_ms": per_launch_ms,
                 "algorithmic_bytes_per_launch": per_launch_bytes,
                 "rank0_kernels": {kn: {"ms_per_step": kv["ms"], "launches": kv["launches"],
