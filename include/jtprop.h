@@ -149,6 +149,8 @@ int jtp_get_stats(jtp_plan *plan, jtp_stats *stats);
 /* Mean device time (ms) of each of the plan's launches, in schedule order; `n` = capacity of
  * `ms`.  Returns the number of launches (or a negative error).  Needs jtp_set_profiling. */
 int jtp_get_launch_ms(jtp_plan *plan, double *ms, int32_t n);
+/* Diagnostic: copy `n` doubles at offset `off` of evidence set `batch`'s message arena to the host. */
+int jtp_debug_read_msg(jtp_plan *plan, int32_t batch, int64_t off, int64_t n, double *host);
 /* Name of kernel variant i as it appears in rocprofv3 traces, or NULL past the last one. */
 const char *jtp_kernel_name(int32_t variant);
 

@@ -669,6 +669,15 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     return JTP_OK;
 }
 
+int jtp_debug_read_msg(jtp_plan *pl, int32_t batch, int64_t off, int64_t n, double *host) {
+    int rc = check_ready(pl, batch);
+    if (rc) return rc;
+    if (off < 0 || n < 0 || off + n > pl->hp.msg_doubles) return set_err(JTP_EINVAL, "range outside the message arena");
+    HIP_TRY(hipSetDevice(pl->hp.device));
+    HIP_TRY(hipMemcpy(host, pl->bufs[batch].msg + off, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return JTP_OK;
+}
+
 int jtp_get_launch_ms(jtp_plan *pl, double *out, int32_t n) {
     if (!pl) return set_err(JTP_EINVAL, "null plan");
     HostPlan &hp = pl->hp;

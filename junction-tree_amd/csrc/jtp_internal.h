@@ -22,8 +22,10 @@
 #define JT_MAX_BITS 31         // max index bits of one clique table
 #define JT_MAX_FREE 13         // max log2(entries) of a staged message sub-box
 #define JT_THREADS 256
+#define JT_RING_BYTES 16384      // LDS bytes at offset 0: per wave a ring of 4 x 1 KiB element slots (LDS-DMA)
 #define JT_STAGE_SCRATCH 2048    // bytes of LDS for staging sums
-#define JT_MAX_ITER_LOG2 8       // a workgroup runs at most 2^8 loop iterations (offset table in LDS)
+#define JT_MAX_ITER_LOG2 6       // a workgroup runs at most 64 loop iterations: its offset table lives in
+                                 // registers, row r in lane r
 #define JT_MAX_VARS 32         // variables per node
 
 struct JtMsg {
@@ -54,19 +56,24 @@ struct JtTask {
     int32_t real_bits;         // index bits actually used by variables (<= nbits; rest is padding)
     int32_t debug;             // timing experiments only (JTP_DEBUG): 1 = skip epilogues and flush
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
-    uint32_t first_x[4];       // element offsets of loop iterations 0..3 (relative to the chunk base)
+    uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base)
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer
-    int32_t total;             // loop iterations per workgroup = 2^(nA + nR), >= 4
+    int32_t total;             // loop iterations per workgroup = 2^(nA + nR), >= 8
     int32_t itab_lds;          // byte offset of the iteration table in dynamic LDS
+    int64_t dbg_off;           // JTP_DEBUG & 2: msg-arena offset of 8 time stamps per workgroup (diagnostic builds)
     JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing
 };
 
 // one workgroup: which task, and the chunk's decoded bases (so the kernel does no bit decode)
-struct JtBlock {
+struct JtBlock {               // 96 bytes; everything the first element loads need is in here, so
+                               // they leave after ONE dependent load (the task record follows)
     uint32_t task;             // index into the task table
     uint32_t xF;               // element offset of the chunk (F bits deposited)
     int32_t gbase[JT_MAX_MSG]; // per message: global-index base of the chunk's sub-box
     int32_t pnum[JT_MAX_OUT];  // per outgoing message: partial-copy number written by this chunk
+    int64_t psi_x0;            // arena element offset of the chunk: task psi_off + xF
+    uint32_t first_x[8];       // copy of the task's first_x
+    uint32_t pad[2];
 };
 
 // host <-> device layout conversion of one table (pack / unpack / synthetic fill)

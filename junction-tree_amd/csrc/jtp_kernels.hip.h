@@ -25,11 +25,32 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "jtp_internal.h"
+
+#ifndef JT_U
+#define JT_U 4                  // loop iterations whose element loads are in flight
+#endif
 
 template <typename T> struct JtVec;
 template <> struct JtVec<float> { using type = float4; };
 template <> struct JtVec<double> { using type = double2; };
+
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS at `lds_dst` + lane * 16
+// (wave-uniform byte address).  Not tracked by the compiler's s_waitcnt insertion: callers count
+// vmcnt themselves (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void jt_dma16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void jt_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 __device__ __forceinline__ double jt_shfl_xor(double v, int laneMask) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -49,7 +70,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     constexpr int EB = (VEC == 4) ? 2 : 1;
     constexpr int NMSG = NIN + NOUT;
     constexpr int NPAR = NIN - NOUT * (MODE == 1);   // distribute: leading inputs that are not children
-    constexpr int U = 4;                             // element loads in flight per wave
+    constexpr int U = JT_U;                          // element loads in flight per wave
     using VT = typename JtVec<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -57,6 +78,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
+    // diagnostic time stamps (JTP_DEBUG=2): 100 MHz wall clock at stage boundaries, lane 0 only
+    uint64_t stamp[6];
+    stamp[0] = __builtin_amdgcn_s_memrealtime();
     const uint32_t xF = bk.xF + (uint32_t)tid * VEC;
     const T *psi = psi_arena + tk.psi_off;
     T *bel = bel_arena + (MODE == 1 ? tk.bel_off : 0);   // distribute always stores (virtual cliques: scratch)
@@ -68,71 +92,101 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     //      the task's iteration table (host built, copied to LDS below): the loops do no index
     //      arithmetic beyond one broadcast ds_read per row.
     const int *gtab = itab + tk.itab_off;
-    const int *tab = reinterpret_cast<const int *>(smem + tk.itab_lds);
     // the first U loads use offsets stored in the task record, so they leave immediately
-    VT q0 = *reinterpret_cast<const VT *>(psi + (xF + tk.first_x[0]));
-    VT q1 = *reinterpret_cast<const VT *>(psi + (xF + tk.first_x[1]));
-    VT q2 = *reinterpret_cast<const VT *>(psi + (xF + tk.first_x[2]));
-    VT q3 = *reinterpret_cast<const VT *>(psi + (xF + tk.first_x[3]));
+    // (addresses come from the workgroup record alone: one dependent load after launch)
+    // Element vectors travel global -> LDS by LDS-DMA into a wave-private ring of U slots of 1 KiB
+    // and are read back with ds_read_b128: no register is a load destination, so the U loads stay
+    // in flight across loop iterations whatever the register allocator does; waits are counted by
+    // hand (vmcnt counts loads and stores in issue order on CDNA4).
+    const T *psi0 = psi_arena + bk.psi_x0 + (uint32_t)tid * VEC;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + (uint32_t)wave * (U * 1024);
+    const char *ring = smem + wave * (U * 1024) + lane * 16;
+#pragma unroll
+    for (int u = 0; u < U; ++u) jt_dma16(psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
+    // The workgroup's iteration table (<= 64 rows of JT_NCOL ints, host built) lives in registers,
+    // row r in lane r; a step reads "row i, column c" with v_readlane: no memory latency on the
+    // critical path of a step except the message entries themselves.
+    int trow[JT_NCOL];
     {
-        int *tabw = reinterpret_cast<int *>(smem + tk.itab_lds);
-        for (int i = tid; i < total * JT_NCOL; i += JT_THREADS) tabw[i] = gtab[i];
+        const int r = lane < total ? lane : total - 1;
+        const int4 a = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL);
+        const int4 b = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL + 4);
+        trow[0] = a.x; trow[1] = a.y; trow[2] = a.z; trow[3] = a.w;
+        trow[4] = b.x; trow[5] = b.y; trow[6] = b.z; trow[7] = b.w;
     }
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- stage incoming sub-boxes (summing partial copies), zero outgoing sub-boxes -----
     // (the first element loads are already in flight).  Sub-boxes smaller than the workgroup
-    // split their partial copies over 256/n thread groups so that all copies are fetched in
-    // one round of loads; group sums are combined through LDS in group order (deterministic).
-    double *scratch = reinterpret_cast<double *>(smem + tk.itab_lds - JT_STAGE_SCRATCH);
+    // split their partial copies over 256/n thread groups; the loads of ALL such messages are
+    // issued together (one round trip to L2 for the whole staging), group sums are combined
+    // through LDS in group order (deterministic).  Larger sub-boxes: one thread per entry.
+    double *scratch = reinterpret_cast<double *>(smem + tk.itab_lds - JT_STAGE_SCRATCH * JT_MAX_IN);
+    {
+        const double *src[NIN > 0 ? NIN : 1];
+        int idx_t[NIN > 0 ? NIN : 1], gp0[NIN > 0 ? NIN : 1], gp1[NIN > 0 ? NIN : 1];
+        int64_t ps[NIN > 0 ? NIN : 1];
+        bool grouped[NIN > 0 ? NIN : 1];
+        double psum[NIN > 0 ? NIN : 1];
+        int maxper = 0;
 #pragma unroll
-    for (int k = 0; k < NIN; ++k) {
-        const JtMsg &m = tk.msg[k];
-        double *sub = reinterpret_cast<double *>(smem + m.lds_off);
-        const double *src = msg_arena + m.off + bk.gbase[k];
-        const int nfree = m.nfree;
-        const int n = 1 << nfree;
-        const int npart = m.npart;
-        const int64_t ps = m.pstride;
-        const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
-        const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
-        int idx_t = 0;
+        for (int k = 0; k < NIN; ++k) {
+            const JtMsg &m = tk.msg[k];
+            const int nfree = m.nfree;
+            const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+            const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
+            src[k] = msg_arena + m.off + bk.gbase[k];
+            ps[k] = m.pstride;
+            idx_t[k] = 0;
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
-            if (b < nfree) idx_t += ((tid >> b) & 1) << JT_FPOS(fp, b);
-        auto sum_range = [&](int idx, int p0, int p1) {
-            double sum = 0.0;
-            for (int p = p0; p < p1; p += 8) {            // eight copies in flight, summed in copy order
-                double c[8];
+            for (int b = 0; b < 8; ++b)
+                if (b < nfree) idx_t[k] += ((tid >> b) & 1) << JT_FPOS(fp, b);
+            grouped[k] = nfree < 8 && m.npart > 1;
+            psum[k] = 0.0;
+            gp0[k] = gp1[k] = 0;
+            if (grouped[k]) {
+                const int groups = JT_THREADS >> nfree;   // >= 2
+                const int per = (m.npart + groups - 1) / groups;
+                gp0[k] = (tid >> nfree) * per;
+                gp1[k] = (gp0[k] + per < m.npart) ? gp0[k] + per : m.npart;
+                maxper = per > maxper ? per : maxper;
+            } else {
+                // one thread per entry, all copies (eight loads in flight)
+                double *sub = reinterpret_cast<double *>(smem + m.lds_off);
+                const int n = 1 << nfree;
+                for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
+                    int idx = idx_t[k];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) c[u] = (p + u < p1) ? src[(int64_t)(p + u) * ps + idx] : 0.0;
+                    for (int b = 8; b < JT_MAX_FREE; ++b)
+                        if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
+                    double sum = 0.0;
+                    for (int p = 0; p < m.npart; p += 8) {
+                        double c[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sum += c[u];
+                        for (int u = 0; u < 8; ++u) c[u] = (p + u < m.npart) ? src[k][(int64_t)(p + u) * ps[k] + idx] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) sum += c[u];
+                    }
+                    sub[s] = sum;
+                }
             }
-            return sum;
-        };
-        if (nfree >= 8 || npart == 1) {
-            for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
-                int idx = idx_t;
-#pragma unroll
-                for (int b = 8; b < JT_MAX_FREE; ++b)
-                    if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
-                sub[s] = sum_range(idx, 0, npart);
-            }
-        } else {
-            const int groups = JT_THREADS >> nfree;       // >= 2
-            const int g = tid >> nfree;
-            const int per = (npart + groups - 1) / groups;
-            const int p0 = g * per;
-            const int p1 = (p0 + per < npart) ? p0 + per : npart;
-            scratch[tid] = sum_range(idx_t, p0, p1);
-            __syncthreads();
-            if (tid < n) {
-                double sum = 0.0;
-                for (int gg = 0; gg < groups; ++gg) sum += scratch[(gg << nfree) + tid];
-                sub[tid] = sum;
-            }
-            __syncthreads();
         }
+        // grouped messages: every thread sums its range of copies of its entry, all messages at once
+        for (int p = 0; p < maxper; p += 8) {
+            double c[NIN > 0 ? NIN : 1][8];
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    c[k][u] = (grouped[k] && gp0[k] + p + u < gp1[k]) ? src[k][(int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) psum[k] += c[k][u];
+        }
+#pragma unroll
+        for (int k = 0; k < NIN; ++k)
+            if (grouped[k]) scratch[k * JT_THREADS + tid] = psum[k];
     }
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) {
@@ -142,7 +196,20 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         for (int s = tid; s < n; s += JT_THREADS) sub[s] = 0.0;
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const JtMsg &m = tk.msg[k];
+        const int nfree = m.nfree;
+        if (nfree < 8 && m.npart > 1 && tid < (1 << nfree)) {
+            const int groups = JT_THREADS >> nfree;
+            double sum = 0.0;
+            for (int g = 0; g < groups; ++g) sum += scratch[k * JT_THREADS + (g << nfree) + tid];
+            reinterpret_cast<double *>(smem + m.lds_off)[tid] = sum;
+        }
+    }
+    __syncthreads();
 
+    stamp[2] = __builtin_amdgcn_s_memrealtime();
     // ---- per-thread constants ---------------------------------------------------------------
     int thr[NMSG > 0 ? NMSG : 1];
     const double *in_sub[NIN > 0 ? NIN : 1];
@@ -233,18 +300,19 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         }
     };
 
+    // make the table rows "arrived" for the compiler before the loop (they came by vector loads;
+    // otherwise every use inside the loop would be guarded by a vmcnt(0) wait)
+#pragma unroll
+    for (int c = 0; c < JT_NCOL; ++c) asm volatile("" : "+v"(trow[c]));
+
     // one iteration: consume `slot`, refill it for iteration i + U, multiply, accumulate
-    auto step = [&](VT &slot, const int i) {
-        const VT v = slot;
-        {   // past the end the last row is loaded again (cache resident): the load stays unconditional,
-            // so the compiler counts loads in flight and waits with vmcnt(U) instead of draining
-            const int inext = (i + U < total) ? i + U : total - 1;
-            slot = *reinterpret_cast<const VT *>(psi + (xF + (uint32_t)tab[inext * JT_NCOL]));
-        }
-        const int4 r0 = *reinterpret_cast<const int4 *>(tab + i * JT_NCOL);        // x, in0, in1, in2
-        const int4 r1 = *reinterpret_cast<const int4 *>(tab + i * JT_NCOL + 4);    // in3, out0, out1, out2
-        const int ioff[4] = {r0.y, r0.z, r0.w, r1.x};
-        const int ooff[3] = {r1.y, r1.z, r1.w};
+    // SLOT = i mod U (static), YOUNGER = vector-memory operations issued after the DMA of iteration i
+    // that may still be outstanding when iteration i is consumed
+    auto step = [&](auto slot_tag, auto younger_tag, const int i) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int YOUNGER = decltype(younger_tag)::value;
+        jt_wait_vmcnt<YOUNGER>();
+        const VT v = *reinterpret_cast<const VT *>(ring + SLOT * 1024);
         double p[VEC];
         p[0] = (double)v.x;
         p[1] = (double)v.y;
@@ -252,6 +320,21 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             p[2] = (double)v.z;
             p[3] = (double)v.w;
         }
+        {   // refill the slot for iteration i + U (the ds_read above has returned: `v` was converted).
+            // Past the end the last row is loaded again (cache resident) so that the count of
+            // operations in flight stays the same in every step.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int inext = (i + U < total) ? i + U : total - 1;
+            jt_dma16(psi + (xF + (uint32_t)__builtin_amdgcn_readlane(trow[0], inext)),
+                     __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
+        }
+        const int li = i;
+        const uint32_t xoff = (uint32_t)__builtin_amdgcn_readlane(trow[0], li);
+        int ioff[4], ooff[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ioff[k] = k < NIN ? __builtin_amdgcn_readlane(trow[1 + k], li) : 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ooff[j] = j < NOUT ? __builtin_amdgcn_readlane(trow[1 + JT_MAX_IN + j], li) : 0;
         double in[NIN > 0 ? NIN : 1][VEC];
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
@@ -303,7 +386,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 o.z = (T)b[2];
                 o.w = (T)b[3];
             }
-            *reinterpret_cast<VT *>(bel + (xF + (uint32_t)r0.x)) = o;
+            *reinterpret_cast<VT *>(bel + (xF + xoff)) = o;
         }
         if constexpr (NOUT > 0) {
             if ((i & rmask) == rmask && !(dbg & 1)) {
@@ -315,12 +398,26 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         }
     };
 
-    for (int i0 = 0; i0 < total; i0 += U) {
-        step(q0, i0);
-        step(q1, i0 + 1);
-        step(q2, i0 + 2);
-        step(q3, i0 + 3);
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    // Younger operations when iteration i is consumed: the U-1 later element loads, plus (distribute)
+    // one belief store per step already executed since that load was issued: U of them in steady
+    // state, u in the first group (its loads were issued in the prologue, before any store).
+    constexpr int ST = (MODE == 1) ? 1 : 0;
+    using std::integral_constant;
+    {
+        step(integral_constant<int, 0>{}, integral_constant<int, U - 1 + 0 * ST>{}, 0);
+        step(integral_constant<int, 1>{}, integral_constant<int, U - 1 + 1 * ST>{}, 1);
+        step(integral_constant<int, 2>{}, integral_constant<int, U - 1 + 2 * ST>{}, 2);
+        step(integral_constant<int, 3>{}, integral_constant<int, U - 1 + 3 * ST>{}, 3);
     }
+    for (int i0 = U; i0 < total; i0 += U) {
+        step(integral_constant<int, 0>{}, integral_constant<int, U - 1 + U * ST>{}, i0);
+        step(integral_constant<int, 1>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 1);
+        step(integral_constant<int, 2>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 2);
+        step(integral_constant<int, 3>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 3);
+    }
+    if (dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[4] = __builtin_amdgcn_s_memrealtime();
 
     // ---- flush outgoing sub-boxes as this chunk's partial copy ----------------------------------
     if constexpr (NOUT > 0) {
@@ -348,6 +445,14 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                     if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
                 dst[idx] = out_sub[j][s];
             }
+        }
+    }
+    if (dbg & 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[5] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            double *o = msg_arena + tk.dbg_off + (int64_t)blockIdx.x * 8;
+            for (int i = 0; i < 6; ++i) o[i] = (double)stamp[i];
         }
     }
 }

@@ -105,7 +105,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
         int best = -1;
         long best_lds = 0;
         int best_part = 0;
-        for (int b = TB; b < nbits && nbits - popc(F) > TB + 2; ++b) {
+        for (int b = TB; b < nbits && nbits - popc(F) > TB + 3; ++b) {
             if (F >> b & 1) continue;
             long l = lds_of(F | 1u << b);
             int pl = part_log2(F | 1u << b);
@@ -121,7 +121,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     }
     // 2. Parallelism: split until a workgroup handles at most 2^block_log2 elements, preferring
     //    bits that every outgoing message contains (no partial copies), highest bit first.
-    block_log2 = std::max(block_log2, TB + 2);          // a workgroup always runs >= 4 iterations
+    block_log2 = std::max(block_log2, TB + 3);          // a workgroup always runs >= 8 iterations
     block_log2 = std::min(block_log2, TB + JT_MAX_ITER_LOG2);   // and at most 2^JT_MAX_ITER_LOG2
     while (nbits - popc(F) > block_log2) {
         int best = -1;
@@ -169,7 +169,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     if (tk.nA > JT_MAX_HI || tk.nR > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "too many loop bits");
     for (int j = 0; j < tk.nF; ++j) tk.f_x[j] = 1u << Fb[j];
 
-    int lds = 0;
+    int lds = JT_RING_BYTES;                    // the element ring sits at LDS offset 0
     // per-message tables
     std::vector<std::vector<int>> slotw;      // [msg][clique bit] -> sub-box slot weight
     auto fill_msg = [&](JtMsg &jm, const MsgView &mv, bool is_out) {
@@ -231,10 +231,10 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
                 for (int c = 1; c < JT_NCOL; ++c) row[c] += slotw[c - 1][Ab[t]];
             }
         for (int c = 0; c < JT_NCOL; ++c) itab[(size_t)i * JT_NCOL + c] = (int32_t)(uint32_t)row[c];
-        if (i < 4) tk.first_x[i] = (uint32_t)row[0];
+        if (i < 8) tk.first_x[i] = (uint32_t)row[0];
     }
-    tk.itab_lds = ((lds + 15) & ~15) + JT_STAGE_SCRATCH;
-    tk.lds_bytes = tk.itab_lds + tk.total * JT_NCOL * 4;
+    tk.itab_lds = ((lds + 15) & ~15) + JT_STAGE_SCRATCH * JT_MAX_IN;      // sub-boxes, staging scratch per incoming message
+    tk.lds_bytes = tk.itab_lds;                           // (the iteration table is register resident)
     return JTP_OK;
 }
 
@@ -252,6 +252,8 @@ JtBlock jtp_make_block(const JtTask &tk, uint32_t task_index, uint32_t chunk) {
         for (int k = 0; k < JT_MAX_MSG; ++k) b.gbase[k] += tk.msg[k].f_w[j];
         for (int k = 0; k < JT_MAX_OUT; ++k) b.pnum[k] += tk.msg[JT_MAX_IN + k].f_p[j];
     }
+    b.psi_x0 = tk.psi_off + (int64_t)b.xF;
+    for (int i = 0; i < 8; ++i) b.first_x[i] = tk.first_x[i];
     return b;
 }
 
@@ -481,7 +483,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             bit += hp.vbits[v];
         }
         if (bit > JT_MAX_BITS) FAIL(JTP_EUNSUPPORTED, "clique %d needs %d index bits (max %d)", p.real, bit, JT_MAX_BITS);
-        p.nbits = std::max(bit, hp.TB + 2);             // >= 4 loop iterations per workgroup
+        p.nbits = std::max(bit, hp.TB + 3);             // >= 8 loop iterations per workgroup
         if (p.nbits - hp.TB > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
     }
     for (size_t s = 0; s < hp.ps.size(); ++s) {
@@ -737,6 +739,12 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         }
     }
     flush_comm();
+    if (getenv("JTP_DEBUG") && (atoi(getenv("JTP_DEBUG")) & 2)) {     // time-stamp region, 8 doubles per workgroup
+        hp.dbg_base = hp.msg_doubles;
+        hp.msg_doubles += (int64_t)hp.blocks.size() * 8;
+        for (const Launch &L : hp.launches)
+            for (int t : L.tasks) hp.tasks[t].dbg_off = hp.dbg_base + L.blk_off * 8;
+    }
     hp.n_messages = 0;
     for (int c = 0; c < N; ++c)
         if (c != hp.root && hp.owner[c] == hp.rank) hp.n_messages += 2;
@@ -815,7 +823,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
     o << "{\"version\":1,\"dtype\":" << hp.dtype << ",\"VEC\":" << hp.VEC << ",\"EB\":" << hp.EB << ",\"TB\":" << hp.TB
       << ",\"n_cliques\":" << hp.n_cliques << ",\"n_ranks\":" << hp.n_ranks << ",\"rank\":" << hp.rank
       << ",\"root\":" << hp.root << ",\"arena_elems\":" << hp.arena_elems << ",\"msg_doubles\":" << hp.msg_doubles
-      << ",\"max_lds\":" << hp.max_lds << ",\"alg_bytes\":" << (long long)hp.alg_bytes
+      << ",\"dbg_base\":" << hp.dbg_base << ",\"max_lds\":" << hp.max_lds << ",\"alg_bytes\":" << (long long)hp.alg_bytes
       << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
       << ",\"n_blocks\":" << hp.blocks.size();
     o << ",\"pnodes\":[";
@@ -880,7 +888,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
               << ",\"nR\":" << tk.nR << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
-            json_list(o, tk.first_x, tk.first_x + 4);
+            json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";
             json_list(o, tk.f_x, tk.f_x + tk.nF);
             o << ",\"total\":" << tk.total << ",\"itab_lds\":" << tk.itab_lds << ",\"itab\":[";
@@ -907,6 +915,8 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             o << "[" << k.task << "," << hp.block_chunk[b] << "," << k.xF;
             for (int i = 0; i < JT_MAX_MSG; ++i) o << "," << k.gbase[i];
             for (int i = 0; i < JT_MAX_OUT; ++i) o << "," << k.pnum[i];
+            o << "," << k.psi_x0;
+            for (int i = 0; i < 8; ++i) o << "," << k.first_x[i];
             o << "]";
         }
         o << "]";

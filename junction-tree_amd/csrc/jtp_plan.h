@@ -87,6 +87,7 @@ struct HostPlan {
     std::vector<JtPackDesc> pack;    // per real clique (host order)
     int64_t arena_elems = 0;         // potential arena == belief arena size (elements)
     int64_t msg_doubles = 0;
+    int64_t dbg_base = -1;           // JTP_DEBUG & 2: time-stamp region inside the message arena
     int max_lds = 0;
     double alg_bytes = 0;
     int n_messages = 0;

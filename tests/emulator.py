@@ -91,7 +91,8 @@ class Emulator:
                     gb_out[k] += outs[k]["f_w"][j]
                     pnum[k] += outs[k]["f_p"][j]
         if record is not None:      # the host-decoded workgroup record must agree with the bit decode
-            assert record[0] == xF
+            assert record[0] == xF and record[11] == tk["psi_off"] + xF
+            assert list(record[12:20]) == list(tk["first_x"])
             assert list(record[1:1 + n_in]) == gb_in and list(record[5:5 + n_out]) == gb_out
             assert list(record[8:8 + n_out]) == pnum
         # staging
@@ -132,10 +133,9 @@ class Emulator:
             assert bool(m["e_dep"]) == any(m["e_w"][e] != 0 for e in range(EB))
 
         itab = np.asarray(tk["itab"], dtype=np.int64).reshape(nA, nR, 8)      # row i = a * nR + r
-        assert tk["total"] == nA * nR and 4 <= tk["total"] <= 256
-        assert tk["itab_lds"] + tk["total"] * 32 == tk["lds_bytes"]
+        assert tk["total"] == nA * nR and 8 <= tk["total"] <= 64
         xoff = itab[:, :, 0] & 0xFFFFFFFF
-        for i in range(4):
+        for i in range(8):
             assert tk["first_x"][i] == xoff.ravel()[i]
         in_off = [_signed(itab[:, :, 1 + k]) for k in range(n_in)]
         out_off = [_signed(itab[:, :, 1 + JT_MAX_IN + j]) for j in range(n_out)]

@@ -1,0 +1,26 @@
+"""Diagnostic: JTP_DEBUG=2 python tools/stamps.py  -> per-level stage timings of one propagate."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
+from junctiontree_amd import _capi, engine, synthetic
+spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
+plan.fill_synthetic(1, spec["scales"])
+for _ in range(3):
+    plan.propagate()
+d = plan.describe()
+base, nb = d["dbg_base"], d["n_blocks"]
+buf = np.empty(nb * 8)
+_capi.check(plan._lib.jtp_debug_read_msg(plan._handle, 0, base, nb * 8, buf.ctypes.data_as(C.POINTER(C.c_double))))
+st = buf.reshape(nb, 8)[:, :6] * 0.01      # 100 MHz ticks -> microseconds
+for L in d["launches"]:
+    s = st[L["blk_off"]:L["blk_off"] + L["nblocks"]]
+    t0 = s[:, 0].min()
+    rel = s - t0
+    names = ["entry", "loads issued", "staged", "consts", "loop done", "flushed"]
+    print("%s level %d (%d blocks): kernel span %.1f us; first/last block start %.1f/%.1f" % (
+        "collect" if L["phase"] == 0 else "distrib", L["level"], L["nblocks"], rel[:, 5].max(), rel[:, 0].min(), rel[:, 0].max()))
+    dur = np.diff(s, axis=1)
+    print("     median stage us: " + "  ".join("%s %.2f" % (n, v) for n, v in zip(
+        ["rec+issue", "table+staging", "consts", "loop", "epilogue+flush"], np.median(dur, axis=0))) +
+        "   block total median %.2f max %.2f" % (np.median(s[:, 5] - s[:, 0]), (s[:, 5] - s[:, 0]).max()))
