@@ -107,6 +107,22 @@ const char *jtp_plan_describe(jtp_plan *plan);
 int jtp_set_potential(jtp_plan *plan, int32_t batch, int32_t node, const void *host,
                       const int64_t *shape, int32_t host_dtype);
 
+/* One factor table handed to jtp_set_potential_product. */
+typedef struct jtp_factor {
+    const void *host;               /* C-order table over `var_ids`                           */
+    int32_t n_vars;
+    int32_t dtype;                  /* JTP_F32 or JTP_F64                                     */
+    const int32_t *var_ids;         /* [n_vars] variables (a subset of the clique's)          */
+    const int64_t *shape;           /* [n_vars] actual axis lengths: cardinality, or 1        */
+} jtp_factor;
+
+/* Clique potential = product of the factor tables assigned to the clique, formed ON THE DEVICE
+ * in the clique's layout: CliqueGraph.evaluate for one clique (junctiontree.py:203-226, helper
+ * einsum :34-80).  Only the factor tables cross PCIe; variables no factor covers are constant
+ * axes (the reference leaves them length 1).  n_factors = 0 gives all ones. */
+int jtp_set_potential_product(jtp_plan *plan, int32_t batch, int32_t clique, int32_t n_factors,
+                              const jtp_factor *factors);
+
 /* Fill every clique potential on the device with the counter-based synthetic values of
  * junctiontree_amd/synthetic.py: psi[i] = (0.5 + u(seed, node, i)) * scale[node], i the
  * C-order host index.  For benchmarks (no host transfer). */

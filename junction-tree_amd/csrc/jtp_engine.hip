@@ -345,6 +345,78 @@ int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *hos
     return JTP_OK;
 }
 
+int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32_t n_factors, const jtp_factor *factors) {
+    int rc = check_ready(pl, batch);
+    if (rc) return rc;
+    HostPlan &hp = pl->hp;
+    if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
+    if (hp.pn[clique].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
+    if (n_factors < 0 || (n_factors > 0 && !factors)) return set_err(JTP_EINVAL, "bad factor list");
+    const std::vector<int> &cvars = hp.node_vars[clique];
+    // lay the tables out in the staging buffer (8-byte slots so that f32 and f64 tables can mix)
+    std::vector<int64_t> offs(n_factors);
+    std::vector<int64_t> elems(n_factors);
+    size_t bytes = 0;
+    for (int f = 0; f < n_factors; ++f) {
+        const jtp_factor &ft = factors[f];
+        if (ft.n_vars < 0 || ft.n_vars > JT_MAX_VARS) return set_err(JTP_EINVAL, "factor %d: bad variable count", f);
+        if (ft.dtype != JTP_F32 && ft.dtype != JTP_F64) return set_err(JTP_EINVAL, "factor %d: bad dtype", f);
+        int64_t n = 1;
+        for (int j = 0; j < ft.n_vars; ++j) {
+            const int v = ft.var_ids[j];
+            bool found = false;
+            for (int cv : cvars) found = found || cv == v;
+            if (!found) return set_err(JTP_EINVAL, "factor %d: variable %d is not in clique %d", f, v, clique);
+            const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
+            if (len != hp.card[v] && len != 1) return set_err(JTP_EINVAL, "factor %d axis %d has length %lld, expected %d or 1", f, j, (long long)len, hp.card[v]);
+            n *= len;
+        }
+        elems[f] = n;
+        offs[f] = (int64_t)(bytes / 8);
+        bytes += (size_t)((n * (ft.dtype == JTP_F32 ? 4 : 8) + 7) / 8) * 8;
+    }
+    HIP_TRY(hipSetDevice(hp.device));
+    rc = ensure_stage(pl, std::max<size_t>(bytes, 8));
+    if (rc) return rc;
+    hipStream_t s = pl->streams[batch % pl->streams.size()];
+    BatchBuffers &b = pl->bufs[batch];
+    for (int f = 0; f < n_factors; ++f)
+        HIP_TRY(hipMemcpyAsync((char *)pl->stage + offs[f] * 8, factors[f].host, (size_t)elems[f] * (factors[f].dtype == JTP_F32 ? 4 : 8), hipMemcpyHostToDevice, s));
+    const int64_t n = (int64_t)1 << hp.pack[clique].nbits;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    int done = 0;
+    do {
+        JtEvalDesc d;
+        memset(&d, 0, sizeof d);
+        d.clique = hp.pack[clique];
+        d.accumulate = done > 0;
+        d.nf = std::min(n_factors - done, JT_EVAL_MAX_F);
+        for (int k = 0; k < d.nf; ++k) {
+            const jtp_factor &ft = factors[done + k];
+            JtEvalFactor &e = d.f[k];
+            e.nv = ft.n_vars;
+            e.is_f64 = ft.dtype == JTP_F64;
+            e.off = ft.dtype == JTP_F64 ? offs[done + k] : offs[done + k] * 2;     // in elements of its own type
+            int64_t stride = 1;
+            for (int j = ft.n_vars - 1; j >= 0; --j) {
+                const int v = ft.var_ids[j];
+                int pos = 0;
+                while (cvars[pos] != v) ++pos;
+                e.cvar[j] = (uint8_t)pos;
+                const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
+                e.stride[j] = (len == 1) ? 0 : (int32_t)stride;
+                stride *= len;
+            }
+        }
+        if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_product<float>), dim3(grid), dim3(256), 0, s, d, (const char *)pl->stage, (float *)b.psi);
+        else hipLaunchKernelGGL((jt_eval_product<double>), dim3(grid), dim3(256), 0, s, d, (const char *)pl->stage, (double *)b.psi);
+        done += d.nf;
+    } while (done < n_factors);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));      // the staging buffer is reused by the next call
+    return JTP_OK;
+}
+
 static uint64_t host_splitmix64(uint64_t x) {
     uint64_t z = x + 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

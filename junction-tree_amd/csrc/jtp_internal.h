@@ -88,6 +88,22 @@ struct JtPackDesc {
     int64_t hstride[JT_MAX_VARS]; // host C-order stride in elements (0: broadcast axis)
 };
 
+// clique potential = product of factor tables (jt_eval_product)
+#define JT_EVAL_MAX_F 8
+struct JtEvalFactor {
+    int64_t off;               // element offset of the table in the staging buffer
+    int32_t nv;
+    int32_t is_f64;
+    uint8_t cvar[JT_MAX_VARS]; // position of factor variable j in the clique's host variable list
+    int32_t stride[JT_MAX_VARS]; // C-order stride of factor variable j (0: broadcast axis)
+};
+struct JtEvalDesc {
+    JtPackDesc clique;
+    int32_t nf;
+    int32_t accumulate;        // 1: multiply into the table already in the arena
+    JtEvalFactor f[JT_EVAL_MAX_F];
+};
+
 // kernel variant ids: collect with n children; distribute with (has_parent, n children)
 enum {
     JT_K_COLLECT0 = 0, JT_K_COLLECT1, JT_K_COLLECT2, JT_K_COLLECT3,

@@ -567,6 +567,41 @@ __global__ __launch_bounds__(256) void jt_fill_ones(T *__restrict__ arena, int64
         arena[off + x] = (T)(x < lim ? 1.0 : 0.0);
 }
 
+// clique potential = product of factor tables, written in the clique's device layout
+// (CliqueGraph.evaluate for one clique, junctiontree/junctiontree.py:203-226)
+template <typename T>
+__global__ __launch_bounds__(256) void jt_eval_product(JtEvalDesc d, const char *__restrict__ stage, T *__restrict__ arena) {
+    const JtPackDesc &c = d.clique;
+    const int64_t n = (int64_t)1 << c.nbits;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
+        bool valid = true;
+        int used = 0;
+        for (int i = 0; i < c.nvars; ++i) {
+            const int digit = (int)(((uint32_t)x >> c.pos[i]) & ((1u << c.nb[i]) - 1u));
+            valid = valid && (digit < c.card[i]);
+            used += c.nb[i];
+        }
+        if (used < 32 && ((uint32_t)x >> used) != 0) valid = false;
+        double v = d.accumulate ? (double)arena[c.dev_off + x] : 1.0;
+        if (valid) {
+            for (int f = 0; f < d.nf; ++f) {
+                const JtEvalFactor &ff = d.f[f];
+                int64_t idx = 0;
+                for (int j = 0; j < ff.nv; ++j) {
+                    const int cv = ff.cvar[j];
+                    const int digit = (int)(((uint32_t)x >> c.pos[cv]) & ((1u << c.nb[cv]) - 1u));
+                    idx += (int64_t)digit * ff.stride[j];
+                }
+                v *= ff.is_f64 ? reinterpret_cast<const double *>(stage)[ff.off + idx]
+                               : (double)reinterpret_cast<const float *>(stage)[ff.off + idx];
+            }
+        } else {
+            v = 0.0;
+        }
+        arena[c.dev_off + x] = (T)v;
+    }
+}
+
 // host index -> device index
 __device__ __forceinline__ uint32_t jt_host_to_dev(const JtPackDesc &d, int64_t h) {
     uint32_t x = 0;

@@ -41,6 +41,16 @@ class TreeDesc(C.Structure):
     ]
 
 
+class Factor(C.Structure):
+    _fields_ = [
+        ("host", C.c_void_p),
+        ("n_vars", C.c_int32),
+        ("dtype", C.c_int32),
+        ("var_ids", C.POINTER(C.c_int32)),
+        ("shape", C.POINTER(C.c_int64)),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32),
@@ -70,6 +80,7 @@ SYMBOLS = {
     "jtp_plan_describe": (C.c_char_p, [C.c_void_p]),
     "jtp_set_potential": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                     C.POINTER(C.c_int64), C.c_int32]),
+    "jtp_set_potential_product": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Factor)]),
     "jtp_fill_synthetic": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_double)]),
     "jtp_propagate": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "jtp_sync": (C.c_int, [C.c_void_p]),

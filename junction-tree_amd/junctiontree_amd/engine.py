@@ -152,6 +152,29 @@ class Plan:
         _capi.check(self._lib.jtp_set_potential(self._handle, batch, self.abi_of[node],
                                                 arr.ctypes.data_as(C.c_void_p), shape, host_dtype))
 
+    def set_potential_product(self, node, arrays, var_lists, batch=0):
+        """Potential of clique `node` = product of factor tables, formed on the device in the clique's
+        layout (`CliqueGraph.evaluate` for one clique, `junctiontree.py:203-226`): only the factor
+        tables are uploaded.  `var_lists[i]` labels the axes of `arrays[i]`; an axis may have length
+        1 to broadcast.  No factors gives an all-ones potential."""
+        keep, recs = [], (_capi.Factor * max(len(arrays), 1))()
+        for i, (arr, labels) in enumerate(zip(arrays, var_lists)):
+            a = np.asarray(arr)
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float64)
+            a = np.ascontiguousarray(a).reshape(a.shape)
+            if a.ndim != len(labels):
+                raise ValueError("factor %d has %d axes but %d variables" % (i, a.ndim, len(labels)))
+            ids = _int_array([self.var_id[lab] for lab in labels])
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            keep += [a, ids, shape]
+            recs[i].host = a.ctypes.data_as(C.c_void_p)
+            recs[i].n_vars = a.ndim
+            recs[i].dtype = _capi.JTP_F32 if a.dtype == np.float32 else _capi.JTP_F64
+            recs[i].var_ids = C.cast(ids, C.POINTER(C.c_int32))
+            recs[i].shape = C.cast(shape, C.POINTER(C.c_int64))
+        _capi.check(self._lib.jtp_set_potential_product(self._handle, batch, self.abi_of[node], len(arrays), recs))
+
     def fill_synthetic(self, seed, scales=None, batch=0):
         """Device-side counter-based potentials (see synthetic.synth_values).  `scales` is
         indexed by the caller's clique index."""

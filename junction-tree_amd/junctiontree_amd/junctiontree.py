@@ -6,9 +6,9 @@ Same public names and data model as the reference's `junctiontree/junctiontree.p
 marginals.  Structure classes are plain Python; all numeric work of `propagate` after the
 factor product runs on the GPU through `engine.Plan`:
 
-    values --evaluate (factor products, host)--> clique potentials --H2D--> collect +
-    distribute on the device (computation.py:37-246 in one plan) --> per-factor marginals
-    computed on the device (junctiontree.py:264-274) --D2H--> list shaped like `values`.
+    values --H2D (factor tables only)--> clique potentials formed on the device (evaluate,
+    junctiontree.py:203-226) --> collect + distribute (computation.py:37-246 in one plan) -->
+    per-factor marginals on the device (junctiontree.py:264-274) --D2H--> list shaped like `values`.
 """
 
 from dataclasses import dataclass, field
@@ -147,11 +147,11 @@ class JunctionTree:
         """Belief propagation: factor values in, unnormalised factor marginals out (same
         list length and array shapes as `xs`; float64)."""
         ct = self.clique_tree
-        psi = ct.evaluate(xs)
         all_f32 = all(isinstance(x, np.ndarray) and x.dtype == np.float32 for x in xs)
         plan = self.plan("f32" if all_f32 else "f64")
-        for c, p in enumerate(psi):
-            plan.set_potential(c, p)
+        # evaluate (junctiontree.py:203-226) on the device: only factor tables cross PCIe
+        for c, members in enumerate(ct._members()):
+            plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
         plan.propagate()
         return [plan.marginal(mc, list(fvars))
                 for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)]
