@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", choices=["c4", "c2"],
+                    help="c4 = BASELINE configs[3] (default, the metric's workload); c2 = configs[1]: chain of "
+                         "1000 cliques, width 3, cardinality 64, float64 (latency-bound, reported in DESIGN.md)")
     ap.add_argument("--cliques", type=int, default=256)
     ap.add_argument("--width", type=int, default=20)
     ap.add_argument("--sep", type=int, default=10)
@@ -114,8 +117,12 @@ def main():
     def barrier():
         rdzv.barrier()
 
-    spec = synthetic.wide_binary_tree(n_cliques=args.cliques, width=args.width, sep=args.sep,
-                                      card=args.card, seed=0)
+    if args.config == "c2":
+        args.dtype, args.cpu_sample = "f64", 0
+        spec = synthetic.chain_tree(n_cliques=1000 if args.cliques == 256 else args.cliques, card=64, width=3)
+    else:
+        spec = synthetic.wide_binary_tree(n_cliques=args.cliques, width=args.width, sep=args.sep,
+                                          card=args.card, seed=0)
     itemsize = 4 if args.dtype == "f32" else 8
     alg = synthetic.algorithmic_bytes(spec, itemsize)
     n = spec["n_cliques"]
@@ -162,7 +169,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[3]: %d cliques, width %d, cardinality %d (2^%d-entry %s "
+                "workload": ("BASELINE.json configs[1]: chain of %d cliques, width 3, cardinality 64, float64" % n)
+                            if args.config == "c2" else
+                            "BASELINE.json configs[3]: %d cliques, width %d, cardinality %d (2^%d-entry %s "
                             "potentials), %d shared variables per edge, balanced binary tree"
                             % (n, args.width, args.card, args.width, args.dtype, args.sep),
                 "algorithmic_bytes_per_step": alg["total"], "messages_per_step": alg["messages"],
@@ -179,7 +188,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
                     prof = json.load(fh)["kernels"]
-                if args.cliques == 256 and args.width == 20 and world == 1 and args.dtype == "f32":
+                if args.config == "c4" and args.cliques == 256 and args.width == 20 and world == 1 and args.dtype == "f32":
                     traffic = prof["void " + name]["hbm_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass

@@ -36,6 +36,8 @@ extern "C" {
 #define JTP_F64 1           /* clique tables stored as double                           */
 
 #define JTP_PLAN_ONLY 1u    /* jtp_tree_desc.flags: plan on the host only, touch no GPU  */
+#define JTP_KEEP_ROOT 4u    /* do not re-root the tree at its centre (default: re-root when n_ranks == 1;
+                               beliefs do not depend on the root, the number of levels does)     */
 #define JTP_SPLIT_VARIANTS 2u /* one launch per (level, neighbour count) instead of per level:
                                profiling aid, attributes device time to each clique shape   */
 
@@ -62,7 +64,7 @@ typedef struct jtp_tree_desc {
     int32_t n_ranks;                /* processes sharing the tree (1 = single GPU)           */
     int32_t rank;                   /* this process                                          */
     const int32_t *clique_owner;    /* [n_cliques] owning rank, or NULL (all rank 0)         */
-    uint32_t flags;                 /* JTP_PLAN_ONLY | JTP_SPLIT_VARIANTS                    */
+    uint32_t flags;                 /* JTP_PLAN_ONLY | JTP_SPLIT_VARIANTS | JTP_KEEP_ROOT                   */
     int32_t lds_budget;             /* bytes of LDS per workgroup the planner may use, 0=default */
     int32_t block_log2;             /* log2 of target elements per workgroup, 0 = automatic  */
     int32_t layout_policy;          /* 0 = default heuristic, 1 = keep host axis order       */

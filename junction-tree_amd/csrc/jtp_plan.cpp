@@ -356,6 +356,52 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         if ((int)q.size() != N) FAIL(JTP_EINVAL, "parent pointers do not form a tree");
     }
 
+    // ---- re-root at the tree's centre (single rank): results do not depend on the root (every
+    //      belief is psi times ALL incoming messages), but the number of levels = dependent launches
+    //      does: a chain of N cliques needs N/2 levels per phase instead of N.
+    if (hp.n_ranks == 1 && !(hp.flags & JTP_KEEP_ROOT) && N > 2) {
+        std::vector<std::vector<std::pair<int, int>>> adj(N);      // (neighbour, psep)
+        for (int c = 0; c < N; ++c)
+            if (c != hp.root) {
+                adj[c].push_back({hp.pn[c].parent, hp.pn[c].psep});
+                adj[hp.pn[c].parent].push_back({c, hp.pn[c].psep});
+            }
+        auto bfs = [&](int src, std::vector<int> &dist, std::vector<int> &prev) {
+            dist.assign(N, -1);
+            prev.assign(N, -1);
+            std::vector<int> q{src};
+            dist[src] = 0;
+            for (size_t i = 0; i < q.size(); ++i)
+                for (auto &e : adj[q[i]])
+                    if (dist[e.first] < 0) dist[e.first] = dist[q[i]] + 1, prev[e.first] = q[i], q.push_back(e.first);
+            return q.back();                                       // a farthest clique
+        };
+        std::vector<int> d1, d2, p1, p2;
+        const int a = bfs(hp.root, d1, p1);
+        const int b = bfs(a, d2, p2);                              // a..b is a diameter
+        int centre = b;
+        for (int steps = d2[b] / 2; steps > 0; --steps) centre = p2[centre];
+        if (d2[b] > 0 && centre != hp.root) {
+            std::vector<int> order{centre};
+            std::vector<int> np(N, -2), nsep(N, -1);
+            np[centre] = -1;
+            for (size_t i = 0; i < order.size(); ++i)
+                for (auto &e : adj[order[i]])
+                    if (np[e.first] == -2) np[e.first] = order[i], nsep[e.first] = e.second, order.push_back(e.first);
+            for (int c = 0; c < N; ++c) {
+                hp.pn[c].parent = np[c];
+                hp.pn[c].psep = nsep[c];
+                hp.pn[c].children.clear();
+            }
+            for (int c : order)
+                if (np[c] >= 0) {
+                    hp.pn[np[c]].children.push_back(c);
+                    hp.ps[nsep[c]].child = c;
+                    hp.ps[nsep[c]].parent = np[c];
+                }
+            hp.root = centre;
+        }
+    }
     // ---- binarise: at most 3 children per node, via virtual all-ones cliques ---------------
     for (int c = 0; c < (int)hp.pn.size(); ++c) {
         while (hp.pn[c].children.size() > 3) {

@@ -14,6 +14,7 @@ JTP_OK, JTP_EINVAL, JTP_EHIP, JTP_ECOMM, JTP_ENOMEM, JTP_EUNSUPPORTED = 0, -1, -
 JTP_F32, JTP_F64 = 0, 1
 JTP_PLAN_ONLY = 1
 JTP_SPLIT_VARIANTS = 2
+JTP_KEEP_ROOT = 4
 N_VARIANTS = 14
 
 

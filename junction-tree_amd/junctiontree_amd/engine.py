@@ -56,7 +56,7 @@ class Plan:
 
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
-                 layout_policy=0, split_variants=False):
+                 layout_policy=0, split_variants=False, keep_root=False):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
@@ -111,7 +111,8 @@ class Plan:
         d.n_batch = n_batch
         d.n_ranks = n_ranks
         d.rank = rank
-        d.flags = (_capi.JTP_PLAN_ONLY if plan_only else 0) | (_capi.JTP_SPLIT_VARIANTS if split_variants else 0)
+        d.flags = ((_capi.JTP_PLAN_ONLY if plan_only else 0) | (_capi.JTP_SPLIT_VARIANTS if split_variants else 0)
+                   | (_capi.JTP_KEEP_ROOT if keep_root else 0))
         d.lds_budget = lds_budget
         d.block_log2 = block_log2
         d.layout_policy = layout_policy

@@ -140,7 +140,7 @@ def test_refsafe_synthetic_trees_f64_and_f32(golden):
 @pytest.mark.parametrize("opts", [
     {}, {"block_log2": 10}, {"block_log2": 11, "lds_budget": 256}, {"layout_policy": 1},
     {"layout_policy": 1, "block_log2": 10, "lds_budget": 128}, {"block_log2": 12, "lds_budget": 2048},
-    {"split_variants": True}, {"split_variants": True, "block_log2": 10},
+    {"split_variants": True}, {"split_variants": True, "block_log2": 10}, {"keep_root": True},
 ])
 def test_planner_options_do_not_change_results(opts):
     specs = [
@@ -354,3 +354,60 @@ def test_device_evaluate_many_factors_and_mixed_dtypes():
     with pytest.raises(ValueError):
         plan.set_potential_product(0, [np.ones(3)], [["z"]] if False else [["a"]])   # wrong length along a
     plan.close()
+
+
+def test_batched_evidence_sets_on_streams():
+    """BASELINE config 5 in miniature: several evidence sets share one plan (structure, task
+    tables), each with its own potentials and HIP stream; evidence enters as a one-hot indicator
+    multiplied into one clique (tests/test_computation.py:411-459 shows the equivalence)."""
+    spec = synthetic.wide_binary_tree(n_cliques=15, width=12, sep=6, card=2, seed=2)
+    n, nb = spec["n_cliques"], 6
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", n_batch=nb)
+    base = synthetic.potentials_for(spec, seed=4)
+    all_pots = []
+    for b in range(nb):
+        rng = np.random.default_rng(1000 + b)
+        pots = [p.copy() for p in base]
+        for var in rng.choice(len(spec["sizes"]), size=3, replace=False):
+            state = int(rng.integers(0, 2))
+            host = next(c for c in range(n) if var in spec["node_vars"][c])
+            axis = spec["node_vars"][host].index(var)
+            ind = np.zeros(2)
+            ind[state] = 1.0
+            shape = [1] * pots[host].ndim
+            shape[axis] = 2
+            pots[host] = pots[host] * ind.reshape(shape)
+        all_pots.append(pots)
+        for c in range(n):
+            plan.set_potential(c, pots[c], batch=b)
+    plan.propagate(0, nb)
+    for b in range(nb):
+        want, z = oracle.beliefs_exact(spec["tree"], all_pots[b], spec["node_vars"], return_z=True)
+        for node in range(len(spec["node_vars"])):
+            close(plan.belief(node, batch=b), want[node], what="batch %d node %d" % (b, node))
+        assert abs(plan.z(batch=b) - z) <= 1e-11 * abs(z)
+    plan.close()
+
+
+def test_grid_mrf_through_public_api_vs_bruteforce():
+    """Loopy pairwise models (BASELINE config 3 family at brute-forceable size): 3x3, 4x4 and
+    3x3x2 binary lattices through create_junction_tree / propagate (the reference is wrong or
+    raises on these)."""
+    rng = np.random.default_rng(3)
+    for dims in ((3, 3), (4, 4), (3, 3, 2)):
+        names = {pos: "v" + "_".join(map(str, pos)) for pos in np.ndindex(*dims)}
+        factors = []
+        for pos in np.ndindex(*dims):
+            for ax in range(len(dims)):
+                nb = list(pos)
+                nb[ax] += 1
+                if nb[ax] < dims[ax]:
+                    factors.append([names[pos], names[tuple(nb)]])
+        sizes = {v: 2 for v in names.values()}
+        values = [rng.uniform(0.5, 1.5, (2, 2)) * 0.7 for _ in factors]
+        ops = []
+        for v, f in zip(values, factors):
+            ops += [v, f]
+        out = jt.create_junction_tree(factors, sizes).propagate(values)
+        for o, f in zip(out, factors):
+            close(o, oracle.labelled_einsum(*ops, f), rtol=1e-10, what=str(dims))

@@ -70,7 +70,7 @@ def test_divergent_cases(golden):
 
 @pytest.mark.parametrize("opts", [
     {}, {"block_log2": 10}, {"block_log2": 11, "lds_budget": 256}, {"layout_policy": 1},
-    {"layout_policy": 1, "block_log2": 10, "lds_budget": 128},
+    {"layout_policy": 1, "block_log2": 10, "lds_budget": 128}, {"keep_root": True},
 ])
 def test_synthetic_trees(opts):
     specs = [
@@ -156,5 +156,5 @@ def test_full_scale_configs_plan():
     spec = synthetic.chain_tree(n_cliques=1000, card=64, width=3)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", plan_only=True)
     d = plan.describe()
-    assert d["n_messages"] == 1998 and len(d["launches"]) == 1999
+    assert d["n_messages"] == 1998 and len(d["launches"]) == 1001       # re-rooted at the centre: 500 + 501 levels
     plan.close()
