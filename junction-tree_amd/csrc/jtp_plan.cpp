@@ -475,14 +475,19 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             // register-summed R loop of the distribute pass, which moves twice the bytes of collect.
             int nchild = (int)p.children.size();
             std::vector<int> priv, ponly, part, allc;
+            int n_full = 0;
             for (size_t i = 0; i < host.size(); ++i) {
                 int v = host[i];
                 int in_parent = p.psep >= 0 && find_var(hp.ps[p.psep].vars, v) >= 0;
                 int in_child = 0;
                 for (int k : p.children) in_child += find_var(hp.ps[hp.pn[k].psep].vars, v) >= 0;
                 if (!in_parent && !in_child) priv.push_back(v);
-                else if ((nchild > 0 && in_child == nchild) || nchild == 0) allc.push_back(v);
-                else if (in_child == 0) ponly.push_back(v);
+                else if ((nchild > 0 && in_child == nchild) || nchild == 0) {
+                    // variables of EVERY message (parent's too) first: they are never summed over in
+                    // either pass, so they are the best occupants of the thread part
+                    if (in_parent && nchild > 0) allc.insert(allc.begin() + n_full++, v);
+                    else allc.push_back(v);
+                } else if (in_child == 0) ponly.push_back(v);
                 else part.push_back(v);
             }
             auto take = [&](std::vector<int> &from, int want_bits) {
@@ -500,11 +505,14 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
                 for (int v : l) b += hp.vbits[v];
                 return b;
             };
+            // (variables are not split: a wide variable taken for the element bits spills into the
+            // lane bits, so without a private variable prefer one that outgoing messages contain)
             int got = take(priv, hp.EB);
-            if (got < hp.EB) got += take(ponly, hp.EB - got);
             if (got < hp.EB) got += take(part, hp.EB - got);
             if (got < hp.EB) got += take(allc, hp.EB - got);
-            int lane = take(part, 6);
+            if (got < hp.EB) got += take(ponly, hp.EB - got);
+            int lane = got > hp.EB ? got - hp.EB : 0;       // bits a wide variable already spilled
+            lane += take(part, 6 - std::min(lane, 6));
             // lanes prefer message bits (no shuffle sum) but leave two allc bits for the waves
             while (lane < 6 && !allc.empty() && bits_of(allc) - hp.vbits[allc.front()] >= 2) lane += take(allc, 1);
             if (lane < 6) lane += take(ponly, 6 - lane);
