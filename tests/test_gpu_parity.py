@@ -411,3 +411,21 @@ def test_grid_mrf_through_public_api_vs_bruteforce():
         out = jt.create_junction_tree(factors, sizes).propagate(values)
         for o, f in zip(out, factors):
             close(o, oracle.labelled_einsum(*ops, f), rtol=1e-10, what=str(dims))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_trees_mixed_cardinalities_on_device(seed):
+    """Random junction trees: cardinalities 1..8 (non powers of two are zero padded on the device),
+    empty separators, up to 5 children per clique, 0..5 variables shared per edge."""
+    from test_planner_emulated import random_junction_tree
+    rng = np.random.default_rng(200 + seed)
+    spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 40)), max_width=6)
+    want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+    opts = [{}, {"block_log2": 10}, {"layout_policy": 1}, {"keep_root": True}, {"split_variants": True}][seed % 5]
+    for dtype in ("f64", "f32"):
+        cast = [p.astype(np.float32) for p in pots] if dtype == "f32" else pots
+        ref = oracle.beliefs_exact(spec["tree"], cast, spec["node_vars"]) if dtype == "f32" else want
+        out, zz = run_plan(spec, cast, dtype, **opts)
+        for o, w in zip(out, ref):
+            close(o, w, rtol=RTOL32 if dtype == "f32" else RTOL64, what="seed %d %s" % (seed, dtype))
+    assert abs(zz - z) <= 1e-5 * abs(z)

@@ -158,3 +158,43 @@ def test_full_scale_configs_plan():
     d = plan.describe()
     assert d["n_messages"] == 1998 and len(d["launches"]) == 1001       # re-rooted at the centre: 500 + 501 levels
     plan.close()
+
+
+def random_junction_tree(rng, n_cliques, max_width=5, cards=(1, 2, 2, 3, 4, 5, 8), max_children=5):
+    """Random junction tree with mixed cardinalities, empty separators and wide fan-out.  Grown
+    clique by clique (a child shares a random subset of its parent's variables and adds fresh
+    ones), so the running-intersection property holds by construction."""
+    sizes, clique_vars, parent, n_children = {}, [], [-1], [0]
+    def fresh():
+        v = len(sizes)
+        sizes[v] = int(rng.choice(cards))
+        return v
+    clique_vars.append([fresh() for _ in range(int(rng.integers(1, max_width + 1)))])
+    for c in range(1, n_cliques):
+        cands = [p for p in range(c) if n_children[p] < max_children]
+        p = int(rng.choice(cands))
+        pv = clique_vars[p]
+        k = int(rng.integers(0, min(len(pv), max_width - 1) + 1))
+        shared = [pv[i] for i in rng.choice(len(pv), size=k, replace=False)] if k else []
+        n_new = int(rng.integers(0 if shared else 1, max_width - len(shared) + 1))
+        vars_c = shared + [fresh() for _ in range(n_new)]
+        if not vars_c:
+            vars_c = [fresh()]
+        rng.shuffle(vars_c)
+        clique_vars.append([int(v) for v in vars_c])
+        parent.append(p)
+        n_children[p] += 1
+        n_children.append(0)
+    spec = synthetic._assemble(parent, clique_vars, sizes)
+    # scaled like the synthetic recipes so that Z stays O(1) (float32 storage cannot hold 1e38)
+    pots = [rng.uniform(0.5, 1.5, [sizes[v] for v in vs]) * spec["scales"][c] for c, vs in enumerate(clique_vars)]
+    pots += [np.ones([sizes[v] for v in vs]) for vs in spec["node_vars"][n_cliques:]]
+    return spec, pots
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_trees_mixed_cardinalities(seed):
+    rng = np.random.default_rng(100 + seed)
+    spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 14)))
+    opts = [{}, {"block_log2": 10}, {"layout_policy": 1}, {"keep_root": True}][seed % 4]
+    check(spec["tree"], pots, spec["node_vars"], spec["sizes"], **opts)
