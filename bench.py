@@ -103,8 +103,10 @@ def main():
     device = local_rank % ndev                      # one process per GPU (ranks > GPUs only in smoke runs)
 
     from junctiontree_amd.rendezvous import Rendezvous
-    rdzv = Rendezvous(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                      int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    master_port = int(os.environ.get("MASTER_PORT", "29500"))
+    run_id = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:32]
+    rdzv = Rendezvous(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), master_port + 1,
+                      port_file="/tmp/jtp_rdzv_%d_%s_%d" % (master_port, run_id, os.getppid()))
     if world > 1:
         uid = None
         if rank == 0:

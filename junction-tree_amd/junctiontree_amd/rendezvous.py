@@ -2,7 +2,8 @@
 
 Only three things are needed outside the data path: hand the RCCL unique id from rank 0 to
 the others, a barrier, and a max-reduction of the measured time.  They are done with plain
-sockets on MASTER_ADDR : MASTER_PORT + 1 (the launcher's own store owns MASTER_PORT).
+sockets (rank 0 listens on an ephemeral port published through a file in /tmp named after
+MASTER_PORT and the launcher's run id; the launcher's own store owns MASTER_PORT).
 
 Why not torch.distributed: importing torch pulls the wheel's bundled ROCm runtime
 (libamdhip64 / libhsa-runtime64 / librccl of another ROCm release) into the process next to
@@ -12,6 +13,7 @@ The separator messages themselves never touch this channel: they move GPU to GPU
 ncclSend / ncclRecv inside libjtprop.so.
 """
 
+import os
 import socket
 import struct
 import time
@@ -41,16 +43,27 @@ def _recv_msg(sock):
 class Rendezvous:
     """Star topology: rank 0 accepts one connection per other rank."""
 
-    def __init__(self, rank, world, addr="127.0.0.1", port=29501, timeout=120.0):
+    def __init__(self, rank, world, addr="127.0.0.1", port=29501, timeout=120.0, port_file=None):
+        """`port_file` (single node): rank 0 binds an ephemeral port and publishes it in that file,
+        so a busy MASTER_PORT + 1 cannot break the run; without it the fixed `port` is used."""
         self.rank, self.world = rank, world
         self.peers = []
         self.sock = None
+        self._port_file = port_file
         if world <= 1:
             return
+        host = "127.0.0.1" if addr in ("localhost", "") else addr
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
+            if port_file is not None:
+                srv.bind((host, 0))
+                tmp = "%s.%d" % (port_file, os.getpid())
+                with open(tmp, "w") as fh:
+                    fh.write("%d\n" % srv.getsockname()[1])
+                os.replace(tmp, port_file)
+            else:
+                srv.bind((host, port))
             srv.listen(world)
             srv.settimeout(timeout)
             conns = {}
@@ -65,9 +78,12 @@ class Rendezvous:
             deadline = time.time() + timeout
             while True:
                 try:
-                    s = socket.create_connection((addr, port), timeout=5.0)
+                    if port_file is not None:
+                        with open(port_file) as fh:
+                            port = int(fh.read().strip())
+                    s = socket.create_connection((host, port), timeout=5.0)
                     break
-                except OSError:
+                except (OSError, ValueError):       # not published yet, or a stale file of an earlier run
                     if time.time() > deadline:
                         raise
                     time.sleep(0.05)
@@ -75,6 +91,14 @@ class Rendezvous:
             s.settimeout(timeout)
             s.sendall(struct.pack("<I", rank))
             self.sock = s
+
+    def _port_file_cleanup(self):
+        path = getattr(self, "_port_file", None)
+        if path and self.rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
 
     def broadcast(self, payload=None):
         """bytes from rank 0 to everyone; returns the payload on every rank."""
@@ -102,6 +126,7 @@ class Rendezvous:
         self.allreduce_max(0.0)
 
     def close(self):
+        self._port_file_cleanup()
         for p in self.peers:
             p.close()
         if self.sock is not None:

@@ -134,7 +134,7 @@ def _rdzv_worker(rank, world, port, queue):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(os.path.dirname(here), "junction-tree_amd"))
     from junctiontree_amd.rendezvous import Rendezvous
-    z = Rendezvous(rank, world, "127.0.0.1", port)
+    z = Rendezvous(rank, world, "127.0.0.1", port, port_file="/tmp/jtp_rdzv_test_%d" % port)
     payload = z.broadcast(b"x" * 128 if rank == 0 else None)
     z.barrier()
     m = z.allreduce_max(1.0 + rank)
