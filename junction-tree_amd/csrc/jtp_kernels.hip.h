@@ -172,17 +172,18 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             }
         }
         // grouped messages: every thread sums its range of copies of its entry, all messages at once
-        for (int p = 0; p < maxper; p += 8) {
-            double c[NIN > 0 ? NIN : 1][8];
+        constexpr int GC = NIN >= 3 ? 4 : 8;          // copies in flight per message (register budget)
+        for (int p = 0; p < maxper; p += GC) {
+            double c[NIN > 0 ? NIN : 1][GC];
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < GC; ++u)
                     c[k][u] = (grouped[k] && gp0[k] + p + u < gp1[k]) ? src[k][(int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]] : 0.0;
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) psum[k] += c[k][u];
+                for (int u = 0; u < GC; ++u) psum[k] += c[k][u];
         }
 #pragma unroll
         for (int k = 0; k < NIN; ++k)
