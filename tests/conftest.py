@@ -16,6 +16,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The C-ABI library is required by most tests (planner checks run it in plan-only mode on
+    # CPU): build it with hipcc if it is missing or older than its sources (~30 s, cross-compiles
+    # without a GPU).  On the GPU box the prebuilt file travels with the snapshot.
+    sys.path.insert(0, os.path.join(ROOT, "junction-tree_amd"))
+    try:
+        import build as jt_build
+        jt_build.build(force=False, verbose=False)
+    except Exception as exc:                         # noqa: BLE001 - report, let the tests fail loudly
+        print("WARNING: could not build libjtprop.so: %r" % (exc,), file=sys.stderr)
 
 
 class Golden:
