@@ -121,7 +121,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // split their partial copies over 256/n thread groups; the loads of ALL such messages are
     // issued together (one round trip to L2 for the whole staging), group sums are combined
     // through LDS in group order (deterministic).  Larger sub-boxes: one thread per entry.
-    double *scratch = reinterpret_cast<double *>(smem + tk.itab_lds - JT_STAGE_SCRATCH * JT_MAX_IN);
+    double *scratch = reinterpret_cast<double *>(smem + tk.itab_lds - JT_STAGE_SCRATCH * NIN);
     {
         const double *src[NIN > 0 ? NIN : 1];
         int idx_t[NIN > 0 ? NIN : 1], gp0[NIN > 0 ? NIN : 1], gp1[NIN > 0 ? NIN : 1];

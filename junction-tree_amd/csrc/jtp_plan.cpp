@@ -233,7 +233,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
         for (int c = 0; c < JT_NCOL; ++c) itab[(size_t)i * JT_NCOL + c] = (int32_t)(uint32_t)row[c];
         if (i < 8) tk.first_x[i] = (uint32_t)row[0];
     }
-    tk.itab_lds = ((lds + 15) & ~15) + JT_STAGE_SCRATCH * JT_MAX_IN;      // sub-boxes, staging scratch per incoming message
+    tk.itab_lds = ((lds + 15) & ~15) + JT_STAGE_SCRATCH * tk.n_in;        // sub-boxes, staging scratch per incoming message
     tk.lds_bytes = tk.itab_lds;                           // (the iteration table is register resident)
     return JTP_OK;
 }
