@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--config", default="c4", choices=["c4", "c2"],
                     help="c4 = BASELINE configs[3] (default, the metric's workload); c2 = configs[1]: chain of "
                          "1000 cliques, width 3, cardinality 64, float64 (latency-bound, reported in DESIGN.md)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="independent evidence sets per step, one HIP stream each (BASELINE configs[4] in "
+                         "miniature; default 1 = the metric's workload)")
     ap.add_argument("--cliques", type=int, default=256)
     ap.add_argument("--width", type=int, default=20)
     ap.add_argument("--sep", type=int, default=10)
@@ -81,6 +84,8 @@ def main():
     ap.add_argument("--lds-budget", type=int, default=0)
     ap.add_argument("--layout-policy", type=int, default=0)
     ap.add_argument("--per-launch", action="store_true", help="print per-launch device times to stderr")
+    ap.add_argument("--level-launches", action="store_true",
+                    help="one launch per tree level instead of one dataflow launch per phase")
     ap.add_argument("--split-variants", action="store_true",
                     help="one launch per (level, clique shape): per-shape timings (profiling aid)")
     args = ap.parse_args()
@@ -130,10 +135,12 @@ def main():
     n = spec["n_cliques"]
     owner = partition.subtree_owners(spec["parent"], [1.0] * n, world)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=args.dtype,
-                       device=device, n_ranks=world, rank=rank, owner=owner,
+                       device=device, n_ranks=world, rank=rank, owner=owner, n_batch=args.batch,
                        block_log2=args.block_log2, lds_budget=args.lds_budget,
-                       layout_policy=args.layout_policy, split_variants=args.split_variants)
-    plan.fill_synthetic(1, spec["scales"])
+                       layout_policy=args.layout_policy, split_variants=args.split_variants,
+                       level_launches=args.level_launches)
+    for b in range(args.batch):
+        plan.fill_synthetic(1 + b, spec["scales"], batch=b)
 
     for _ in range(args.warmup):
         plan.propagate(sync=False)
@@ -159,13 +166,13 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        gbps = alg["total"] * args.steps / elapsed / 1e9
+        gbps = alg["total"] * args.batch * args.steps / elapsed / 1e9
         out = {
             "metric": "clique-potential GB/s (algorithmic bytes per propagate / time; messages/sec alongside), "
                       "synthetic width-%d tree" % args.width,
             "value": gbps, "unit": "GB/s",
-            "messages_per_sec": alg["messages"] * args.steps / elapsed,
-            "read_GBps": alg["read"] * args.steps / elapsed / 1e9,
+            "messages_per_sec": alg["messages"] * args.batch * args.steps / elapsed,
+            "read_GBps": alg["read"] * args.batch * args.steps / elapsed / 1e9,
             "frac_of_hbm_roofline": gbps / (HBM_PEAK_GBPS * world),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -176,14 +183,15 @@ def main():
                             "BASELINE.json configs[3]: %d cliques, width %d, cardinality %d (2^%d-entry %s "
                             "potentials), %d shared variables per edge, balanced binary tree"
                             % (n, args.width, args.card, args.width, args.dtype, args.sep),
-                "algorithmic_bytes_per_step": alg["total"], "messages_per_step": alg["messages"],
+                "algorithmic_bytes_per_step": alg["total"] * args.batch, "messages_per_step": alg["messages"] * args.batch,
+                "evidence_sets_per_step": args.batch,
                 "parallelism": "1 GPU" if world == 1 else "subtree-sharded x%d, RCCL send/recv at cuts" % world,
                 "launches_per_step": stats["n_launches"], "Z": z,
             },
         }
         if not args.no_profile and stats["kernels"]:
             name, k = max(stats["kernels"].items(), key=lambda kv: kv[1]["ms"])
-            per_launch_bytes = k["bytes"] / k["launches"]
+            per_launch_bytes = k["bytes"] / k["launches"]          # (profiled: evidence set 0 only)
             per_launch_ms = k["ms"] / k["launches"]
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             traffic = None                 # HBM bytes per launch from the committed PMC passes (profiles/)
