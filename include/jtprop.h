@@ -41,6 +41,12 @@ extern "C" {
 #define JTP_SPLIT_VARIANTS 2u /* one launch per (level, neighbour count) instead of per level:
                                profiling aid, attributes device time to each clique shape   */
 
+#define JTP_LEVEL_LAUNCHES 8u /* one launch per tree level instead of the default one per phase, whose
+                               workgroups wait on per-message completion counters (dataflow)  */
+
+#define JTP_FLOW_TICKETS 16u /* dataflow launches: workgroups draw their place in the block list from an
+                               atomic counter instead of relying on in-order workgroup dispatch     */
+
 typedef struct jtp_plan jtp_plan;
 
 /* Structure of one junction tree.  Mirrors the reference's data model
@@ -64,7 +70,7 @@ typedef struct jtp_tree_desc {
     int32_t n_ranks;                /* processes sharing the tree (1 = single GPU)           */
     int32_t rank;                   /* this process                                          */
     const int32_t *clique_owner;    /* [n_cliques] owning rank, or NULL (all rank 0)         */
-    uint32_t flags;                 /* JTP_PLAN_ONLY | JTP_SPLIT_VARIANTS | JTP_KEEP_ROOT                   */
+    uint32_t flags;                 /* JTP_PLAN_ONLY | JTP_SPLIT_VARIANTS | JTP_KEEP_ROOT | JTP_LEVEL_LAUNCHES | ... */
     int32_t lds_budget;             /* bytes of LDS per workgroup the planner may use, 0=default */
     int32_t block_log2;             /* log2 of target elements per workgroup, 0 = automatic  */
     int32_t layout_policy;          /* 0 = default heuristic, 1 = keep host axis order       */
@@ -82,7 +88,7 @@ typedef struct jtp_stats {
     double  kernel_ms[32];          /* device time per kernel variant, mean per propagate    */
     double  kernel_bytes[32];       /* algorithmic bytes processed per kernel variant        */
     int32_t kernel_launches[32];    /* launches per kernel variant                           */
-    int32_t pad;
+    int32_t flow_fallbacks;         /* dataflow launches that timed out and were re-run per level (expected 0) */
 } jtp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

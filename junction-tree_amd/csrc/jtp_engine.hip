@@ -97,7 +97,7 @@ static int load() {
 
 template <typename T>
 struct KernelTable {
-    typedef void (*fn)(const JtTask *, const JtBlock *, const int *, const T *, T *, double *);
+    typedef void (*fn)(const JtTask *, const JtBlock *, const int *, const T *, T *, double *, JtFlow);
     static fn get(int variant) {
         switch (variant) {
             case JT_K_COLLECT0: return jt_collect<T, 0>;
@@ -117,19 +117,25 @@ struct KernelTable {
         }
         return nullptr;
     }
+    static fn get_flow(int phase) { return phase == 0 ? jt_collect_flow<T> : jt_distribute_flow<T>; }
 };
 
 static const char *k_names[JT_K_COUNT] = {
     "jt_collect<T, 0>", "jt_collect<T, 1>", "jt_collect<T, 2>", "jt_collect<T, 3>",
     "jt_distribute<T, 0, 0>", "jt_distribute<T, 0, 1>", "jt_distribute<T, 0, 2>", "jt_distribute<T, 0, 3>",
     "jt_distribute<T, 1, 0>", "jt_distribute<T, 1, 1>", "jt_distribute<T, 1, 2>", "jt_distribute<T, 1, 3>",
-    "jt_collect_level<T>", "jt_distribute_level<T>",
+    "jt_collect_level<T>", "jt_distribute_level<T>", "jt_collect_flow<T>", "jt_distribute_flow<T>",
 };
 
 struct BatchBuffers {
     void *psi = nullptr;
     void *bel = nullptr;
     double *msg = nullptr;
+    uint32_t *sync = nullptr;       // dataflow launches: abort flag and ticket counters
+    uint32_t epoch = 0;             // propagates enqueued so far; its parity selects the message arena half
+    uint32_t flow_runs = 0;         // of which dataflow (ticket counters only grow)
+    bool unchecked = false;         // a dataflow propagate was enqueued and its abort flag not looked at yet
+    int64_t cur_off(int64_t half) const { return (epoch & 1u) ? half : 0; }     // half in use by the last propagate
 };
 
 struct jtp_plan {
@@ -146,6 +152,9 @@ struct jtp_plan {
     std::vector<hipEvent_t> ev;     // prof_steps x (2 per launch)
     int prof_cursor = 0;            // propagates recorded since profiling was switched on
     bool prof_per_launch = false;   // event pair per launch instead of three per propagate
+    bool flow = true;               // dataflow launches (one per phase) instead of one per level
+    uint32_t *host_abort = nullptr; // pinned: set by a workgroup that gave up waiting
+    int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
     int esize = 4;
 };
 
@@ -198,7 +207,9 @@ void jtp_plan_destroy(jtp_plan *pl) {
             if (b.psi) (void)hipFree(b.psi);
             if (b.bel) (void)hipFree(b.bel);
             if (b.msg) (void)hipFree(b.msg);
+            if (b.sync) (void)hipFree(b.sync);
         }
+        if (pl->host_abort) (void)hipHostFree(pl->host_abort);
         if (pl->d_tasks) (void)hipFree(pl->d_tasks);
         if (pl->d_blocks) (void)hipFree(pl->d_blocks);
         if (pl->d_itab) (void)hipFree(pl->d_itab);
@@ -221,6 +232,8 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     }
     HostPlan &hp = pl->hp;
     pl->esize = hp.dtype == JTP_F32 ? 4 : 8;
+    // one launch per level when asked for, for per-shape launches and for the JTP_DEBUG experiments
+    pl->flow = !(hp.flags & (JTP_LEVEL_LAUNCHES | JTP_SPLIT_VARIANTS)) && !(getenv("JTP_DEBUG") && (atoi(getenv("JTP_DEBUG")) & 1));
     if (hp.flags & JTP_PLAN_ONLY) {
         *out = pl;
         return JTP_OK;
@@ -252,15 +265,21 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     for (auto &s : pl->streams) CREATE_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     pl->bufs.resize(hp.n_batch);
     const size_t abytes = (size_t)std::max<int64_t>(hp.arena_elems, 256) * pl->esize;
-    const size_t mbytes = (size_t)std::max<int64_t>(hp.msg_doubles, 2) * 8;
+    // two halves, used by alternate propagates (jtp_internal.h: JT_UNWRITTEN)
+    const size_t mbytes = (size_t)std::max<int64_t>(hp.msg_doubles, 2) * 8 * 2;
     for (auto &b : pl->bufs) {
         CREATE_TRY(hipMalloc(&b.psi, abytes));
         CREATE_TRY(hipMalloc(&b.bel, abytes));
         CREATE_TRY(hipMalloc((void **)&b.msg, mbytes));
         CREATE_TRY(hipMemsetAsync(b.psi, 0, abytes, pl->streams[0]));
         CREATE_TRY(hipMemsetAsync(b.bel, 0, abytes, pl->streams[0]));
-        CREATE_TRY(hipMemsetAsync(b.msg, 0, mbytes, pl->streams[0]));
+        CREATE_TRY(hipMemsetD32Async((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), mbytes / 4, pl->streams[0]));
+        CREATE_TRY(hipMalloc((void **)&b.sync, (size_t)hp.sync_words * 4));
+        CREATE_TRY(hipMemsetAsync(b.sync, 0, (size_t)hp.sync_words * 4, pl->streams[0]));
     }
+    CREATE_TRY(hipHostMalloc((void **)&pl->host_abort, 64, hipHostMallocMapped));
+    *pl->host_abort = 0;
+
     for (auto &b : pl->bufs) {
         for (const VirtualFill &vf : hp.virtual_fills) {
             const int64_t n = (int64_t)1 << vf.nbits;
@@ -283,8 +302,12 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         CREATE_TRY(hipMemcpy(pl->d_itab, hp.itab.data(), hp.itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     if (hp.max_lds > 64 * 1024) {
-        for (int v = 0; v < JT_K_COUNT; ++v) {
+        for (int v = 0; v < JT_K_COLLECT_FLOW; ++v) {
             const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v);
+            CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hp.max_lds));
+        }
+        for (int ph = 0; ph < 2; ++ph) {
+            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph) : (const void *)KernelTable<double>::get_flow(ph);
             CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hp.max_lds));
         }
     }
@@ -451,14 +474,45 @@ int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double 
 // ------------------------------------------------------------------------------------------ compute
 
 static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipStream_t s, const JtTask *tasks,
-                          const JtBlock *blocks, const int *itab, void *psi, void *bel, double *msg) {
+                          const JtBlock *blocks, const int *itab, void *psi, void *bel, double *msg, const JtFlow &fl) {
     if (pl->hp.dtype == JTP_F32) {
         auto f = KernelTable<float>::get(variant);
-        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const float *)psi, (float *)bel, msg);
+        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const float *)psi, (float *)bel, msg, fl);
     } else {
         auto f = KernelTable<double>::get(variant);
-        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const double *)psi, (double *)bel, msg);
+        hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const double *)psi, (double *)bel, msg, fl);
     }
+    return JTP_OK;
+}
+
+// Called wherever the host has just synchronised with the plan's streams.  A dataflow launch whose
+// workgroups gave up waiting (it would take workgroups dispatched out of order, or a stuck device;
+// never observed) has left that propagate unfinished: mark the whole arena unwritten again, switch the
+// plan to one launch per level for good, and run the affected evidence sets again that way.
+static int check_flow(jtp_plan *pl) {
+    if (!pl->host_abort) return JTP_OK;
+    if (*(volatile uint32_t *)pl->host_abort == 0) {
+        for (auto &b : pl->bufs) b.unchecked = false;
+        return JTP_OK;
+    }
+    *(volatile uint32_t *)pl->host_abort = 0;
+    pl->flow = false;
+    pl->flow_fallbacks++;
+    for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < pl->bufs.size(); ++i) {
+        BatchBuffers &b = pl->bufs[i];
+        HIP_TRY(hipMemset(b.sync, 0, (size_t)pl->hp.sync_words * 4));
+        HIP_TRY(hipMemsetD32((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 4));
+        b.epoch = 0;
+        b.flow_runs = 0;
+    }
+    for (size_t i = 0; i < pl->bufs.size(); ++i) {
+        if (!pl->bufs[i].unchecked) continue;
+        pl->bufs[i].unchecked = false;
+        int rc = jtp_propagate(pl, (int32_t)i, (int32_t)i + 1);
+        if (rc) return rc;
+    }
+    for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
     return JTP_OK;
 }
 
@@ -487,22 +541,53 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         const bool per_phase = pb && !pl->prof_per_launch;
         bool mid_done = false;
         if (per_phase) HIP_TRY(hipEventRecord(pl->ev[ev_base + 0], s));
-        for (const Step &st : hp.steps) {
-            if (st.kind == 0) {
+        const bool flow = pl->flow && !per_launch;
+        const int64_t half = std::max<int64_t>(hp.msg_doubles, 2);
+        bb.epoch++;
+        JtFlow fl;
+        memset(&fl, 0, sizeof fl);
+        fl.sync = bb.sync;
+        fl.host_abort = pl->host_abort;
+        fl.cur_off = bb.cur_off(half);
+        fl.oth_off = half - fl.cur_off;
+        fl.dbg = getenv("JTP_FLOW_DEBUG") ? (uint32_t)atoi(getenv("JTP_FLOW_DEBUG")) : 0u;
+        if (flow) {
+            bb.flow_runs++;
+            bb.unchecked = true;
+        }
+        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0;
+        for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {
+            if (st.kind == 0 && flow) {
+                const Segment &sg = hp.segments[st.first];
+                if (per_phase && !mid_done && sg.phase == 1) {
+                    HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
+                    mid_done = true;
+                }
+                fl.ticket_idx = tickets ? (uint32_t)sg.ticket_idx : 0xffffffffu;
+                fl.blk_base = (uint32_t)sg.blk_off;
+                fl.ticket_base = (bb.flow_runs - 1u) * (uint32_t)sg.nblocks;
+                if (hp.dtype == JTP_F32)
+                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                                       pl->d_blocks + sg.blk_off, pl->d_itab, (const float *)bb.psi, (float *)bb.bel, bb.msg, fl);
+                else
+                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                                       pl->d_blocks + sg.blk_off, pl->d_itab, (const double *)bb.psi, (double *)bb.bel, bb.msg, fl);
+            } else if (st.kind == 0) {
                 const Launch &L = hp.launches[st.first];
                 if (per_phase && !mid_done && L.phase == 1) {
                     HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
                     mid_done = true;
                 }
                 if (per_launch) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first], s));
-                launch_variant(pl, L.variant, L.nblocks, L.lds_bytes, s, pl->d_tasks, pl->d_blocks + L.blk_off, pl->d_itab, bb.psi, bb.bel, bb.msg);
+                fl.blk_base = (uint32_t)L.blk_off;
+                launch_variant(pl, L.variant, L.nblocks, L.lds_bytes, s, pl->d_tasks, pl->d_blocks + L.blk_off, pl->d_itab, bb.psi, bb.bel, bb.msg, fl);
                 if (per_launch) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first + 1], s));
             } else {
                 NCCL_TRY(rccl::GroupStart());
                 for (int i = st.first; i < st.first + st.count; ++i) {
                     const CommOp &op = hp.comm[i];
-                    if (op.send) NCCL_TRY(rccl::Send(bb.msg + op.off, (size_t)op.count, rccl::ncclFloat64, op.peer, rccl::comm, s));
-                    else NCCL_TRY(rccl::Recv(bb.msg + op.off, (size_t)op.count, rccl::ncclFloat64, op.peer, rccl::comm, s));
+                    if (op.send) NCCL_TRY(rccl::Send(bb.msg + fl.cur_off + op.off, (size_t)op.count, rccl::ncclFloat64, op.peer, rccl::comm, s));
+                    else NCCL_TRY(rccl::Recv(bb.msg + fl.cur_off + op.off, (size_t)op.count, rccl::ncclFloat64, op.peer, rccl::comm, s));
                 }
                 NCCL_TRY(rccl::GroupEnd());
             }
@@ -522,7 +607,7 @@ int jtp_sync(jtp_plan *pl) {
     if (!pl->device) return JTP_OK;
     HIP_TRY(hipSetDevice(pl->hp.device));
     for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
-    return JTP_OK;
+    return check_flow(pl);
 }
 
 // ------------------------------------------------------------------------------------------ data out
@@ -553,7 +638,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)d.host_elems * hsz, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        return JTP_OK;
+        return check_flow(pl);
     }
     const int si = hp.sep_of_node[node];
     if (si < 0) return set_err(JTP_EINVAL, "separator node %d is not part of the tree", node);
@@ -579,14 +664,15 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
     if (rc) return rc;
     const int grid = (int)std::min<int64_t>((stride + 255) / 256, 4096);
     const int64_t pstride = (int64_t)1 << sp.nbits;
+    const double *cur = b.msg + b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));      // the half the last propagate wrote
     if (host_dtype == JTP_F32)
-        hipLaunchKernelGGL((jt_msg_unpack<float>), dim3(grid), dim3(256), 0, s, d, b.msg + sp.up_off, sp.up_npart, b.msg + sp.dn_off, sp.dn_npart, pstride, (float *)pl->stage);
+        hipLaunchKernelGGL((jt_msg_unpack<float>), dim3(grid), dim3(256), 0, s, d, cur + sp.up_off, sp.up_npart, cur + sp.dn_off, sp.dn_npart, pstride, (float *)pl->stage);
     else
-        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, b.msg + sp.up_off, sp.up_npart, b.msg + sp.dn_off, sp.dn_npart, pstride, (double *)pl->stage);
+        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, cur + sp.up_off, sp.up_npart, cur + sp.dn_off, sp.dn_npart, pstride, (double *)pl->stage);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)stride * hsz, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    return JTP_OK;
+    return check_flow(pl);
 }
 
 int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t *out_vars, int32_t n_out, double *host) {
@@ -628,7 +714,10 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
         HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tk.lds_bytes));
     }
     // marginalise the BELIEF table: it is the "potential" argument of a childless collect
-    launch_variant(pl, JT_K_COLLECT0, (int)blocks.size(), tk.lds_bytes, s, d_task, d_blk, d_tab, b.bel, b.bel, scratch);
+    JtFlow plain;
+    memset(&plain, 0, sizeof plain);
+    plain.oth_off = -1;                      // a one-off output buffer: one half, nothing to mark
+    launch_variant(pl, JT_K_COLLECT0, (int)blocks.size(), tk.lds_bytes, s, d_task, d_blk, d_tab, b.bel, b.bel, scratch, plain);
     HIP_TRY(hipGetLastError());
     JtPackDesc d;
     memset(&d, 0, sizeof d);
@@ -665,7 +754,7 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
     (void)hipFree(d_task);
     (void)hipFree(d_blk);
     (void)hipFree(d_tab);
-    return rc;
+    return rc != JTP_OK ? rc : check_flow(pl);
 }
 
 int jtp_get_z(jtp_plan *pl, int32_t batch, double *z) {
@@ -695,14 +784,24 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     HostPlan &hp = pl->hp;
     memset(st, 0, sizeof *st);
     st->struct_size = (int32_t)sizeof(jtp_stats);
-    st->n_launches = (int32_t)hp.launches.size();
+    const bool flow = pl->flow && !pl->prof_per_launch;
+    st->n_launches = (int32_t)(flow ? hp.segments.size() : hp.launches.size());
     st->n_messages = hp.n_messages;
     st->n_tasks = (int32_t)hp.tasks.size();
     st->algorithmic_bytes = hp.alg_bytes;
-    for (size_t i = 0; i < hp.launches.size(); ++i) {
-        const Launch &L = hp.launches[i];
-        st->kernel_bytes[L.variant] += L.alg_bytes;
-        st->kernel_launches[L.variant] += 1;
+    st->flow_fallbacks = pl->flow_fallbacks;
+    if (flow) {
+        for (const Segment &sg : hp.segments) {
+            const int v = sg.phase == 0 ? JT_K_COLLECT_FLOW : JT_K_DISTRIBUTE_FLOW;
+            for (int i = sg.first_launch; i < sg.first_launch + sg.n_launch; ++i) st->kernel_bytes[v] += hp.launches[i].alg_bytes;
+            st->kernel_launches[v] += 1;
+        }
+    } else {
+        for (size_t i = 0; i < hp.launches.size(); ++i) {
+            const Launch &L = hp.launches[i];
+            st->kernel_bytes[L.variant] += L.alg_bytes;
+            st->kernel_launches[L.variant] += 1;
+        }
     }
     if (pl->device && pl->prof_steps > 0 && pl->prof_cursor > 0) {
         HIP_TRY(hipSetDevice(hp.device));
@@ -732,7 +831,10 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
             }
             // with one kernel per phase (the default), the phase time is that kernel's time over
             // its back-to-back launches (gaps included)
-            if (!(hp.flags & JTP_SPLIT_VARIANTS)) {
+            if (flow) {
+                st->kernel_ms[JT_K_COLLECT_FLOW] = st->collect_ms;
+                st->kernel_ms[JT_K_DISTRIBUTE_FLOW] = st->distribute_ms;
+            } else if (!(hp.flags & JTP_SPLIT_VARIANTS)) {
                 st->kernel_ms[JT_K_COLLECT_LEVEL] = st->collect_ms;
                 st->kernel_ms[JT_K_DISTRIBUTE_LEVEL] = st->distribute_ms;
             }

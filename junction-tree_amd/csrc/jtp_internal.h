@@ -26,6 +26,13 @@
 #define JT_STAGE_SCRATCH 2048    // bytes of LDS for staging sums
 #define JT_MAX_ITER_LOG2 6       // a workgroup runs at most 64 loop iterations: its offset table lives in
                                  // registers, row r in lane r
+#define JT_SYNC_ABORT 0        // dataflow launches, per evidence set: word 0 = abort flag, then one ticket
+#define JT_SYNC_HDR 2          // counter per launch segment
+// "Not written yet" marker of a message entry (a NaN no arithmetic produces; both 32-bit halves equal so
+// that a 32-bit memset fills it).  The message arena has two halves used by alternate propagates; a
+// producer writes its entries in this propagate's half and the marker in the other half, so at the
+// start of every propagate the half about to be used holds markers only.
+#define JT_UNWRITTEN 0x7FF8BEEF7FF8BEEFull
 #define JT_MAX_VARS 32         // variables per node
 
 struct JtMsg {
@@ -62,6 +69,19 @@ struct JtTask {
     int32_t itab_lds;          // byte offset of the iteration table in dynamic LDS
     int64_t dbg_off;           // JTP_DEBUG & 2: msg-arena offset of 8 time stamps per workgroup (diagnostic builds)
     JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing
+};
+
+// per-launch arguments of the message-passing kernels
+struct JtFlow {
+    uint32_t *sync;            // dataflow launches: abort flag and segment ticket counters
+    uint32_t *host_abort;      // host-visible copy of the abort flag (pinned memory)
+    int64_t cur_off;           // offset (doubles) of this propagate's half of the message arena
+    int64_t oth_off;           // the other half, to be marked unwritten (< 0: leave it alone)
+    uint32_t ticket_idx;       // the segment's ticket counter; 0xffffffff: workgroups run in blockIdx order
+    uint32_t ticket_base;      // its value when the launch starts
+    uint32_t dbg;              // timing experiments (JTP_FLOW_DEBUG): 4 = no waits (wrong results), 8 = every wait
+                               // times out after 20 ms (exercises the fallback to one launch per level)
+    uint32_t blk_base;         // index of the launch's first workgroup in the plan's block list (time stamps)
 };
 
 // one workgroup: which task, and the chunk's decoded bases (so the kernel does no bit decode)
@@ -109,6 +129,7 @@ enum {
     JT_K_COLLECT0 = 0, JT_K_COLLECT1, JT_K_COLLECT2, JT_K_COLLECT3,
     JT_K_DIST_P0C0, JT_K_DIST_P0C1, JT_K_DIST_P0C2, JT_K_DIST_P0C3,
     JT_K_DIST_P1C0, JT_K_DIST_P1C1, JT_K_DIST_P1C2, JT_K_DIST_P1C3,
-    JT_K_COLLECT_LEVEL, JT_K_DISTRIBUTE_LEVEL,      // one launch per tree level (default)
+    JT_K_COLLECT_LEVEL, JT_K_DISTRIBUTE_LEVEL,      // one launch per tree level
+    JT_K_COLLECT_FLOW, JT_K_DISTRIBUTE_FLOW,        // one launch per phase, workgroups wait on message counters (default)
     JT_K_COUNT
 };

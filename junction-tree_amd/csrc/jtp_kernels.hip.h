@@ -62,10 +62,36 @@ __device__ __forceinline__ double jt_shfl_xor(double v, int laneMask) {
 // message-index bit of sub-box index bit b (free_pos[] packed four per word)
 #define JT_FPOS(fp, b) (((fp)[(b) >> 2] >> (8 * ((b) & 3))) & 0xffu)
 
-template <typename T, int NIN, int NOUT, int MODE>
+// Dataflow launches (FLOW = true): ONE launch covers all levels of a phase, so a message may still be
+// in the making (by workgroups of the same launch) when its consumer starts.  Every message entry
+// carries its own "ready" state: the arena half of this propagate holds JT_UNWRITTEN markers until the
+// producer stores the value (64-bit stores are single-copy atomic), so the consumer loads its sub-box,
+// and while it finds a marker it waits on that entry and loads again.  Loads and stores of message
+// entries are agent-scope atomics here (they go through to memory: the L2 caches of the eight XCDs
+// are not coherent with each other inside a launch); no fences, no counters.
+__device__ __forceinline__ bool jt_unwritten(double v) { return (uint64_t)__double_as_longlong(v) == JT_UNWRITTEN; }
+
+template <bool FLOW>
+__device__ __forceinline__ double jt_msg_load(const double *p) {
+    if constexpr (FLOW)
+        return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else
+        return *p;
+}
+
+template <bool FLOW>
+__device__ __forceinline__ void jt_msg_store(double *p, double v) {
+    if constexpr (FLOW)
+        __hip_atomic_store(reinterpret_cast<long long *>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
-                                        double *__restrict__ msg_arena) {
+                                        double *__restrict__ msg_arena, const JtFlow &fl,
+                                        uint32_t bindex, uint32_t *flow_ctl = nullptr, uint64_t t_entry = 0) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int EB = (VEC == 4) ? 2 : 1;
     constexpr int NMSG = NIN + NOUT;
@@ -80,7 +106,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 
     // diagnostic time stamps (JTP_DEBUG=2): 100 MHz wall clock at stage boundaries, lane 0 only
     uint64_t stamp[6];
-    stamp[0] = __builtin_amdgcn_s_memrealtime();
+    stamp[0] = FLOW ? t_entry : __builtin_amdgcn_s_memrealtime();
     const uint32_t xF = bk.xF + (uint32_t)tid * VEC;
     const T *psi = psi_arena + tk.psi_off;
     T *bel = bel_arena + (MODE == 1 ? tk.bel_off : 0);   // distribute always stores (virtual cliques: scratch)
@@ -122,81 +148,145 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // issued together (one round trip to L2 for the whole staging), group sums are combined
     // through LDS in group order (deterministic).  Larger sub-boxes: one thread per entry.
     double *scratch = reinterpret_cast<double *>(smem + tk.itab_lds - JT_STAGE_SCRATCH * NIN);
-    {
-        const double *src[NIN > 0 ? NIN : 1];
-        int idx_t[NIN > 0 ? NIN : 1], gp0[NIN > 0 ? NIN : 1], gp1[NIN > 0 ? NIN : 1];
-        int64_t ps[NIN > 0 ? NIN : 1];
-        bool grouped[NIN > 0 ? NIN : 1];
-        double psum[NIN > 0 ? NIN : 1];
-        int maxper = 0;
+    const double *msg_cur = msg_arena + fl.cur_off;
+    uint64_t wait_t0 = 0;
+    for (int attempt = 0;; ++attempt) {
+        const double *unready = nullptr;          // (FLOW) an entry this thread found not written yet
+        {
+            const double *src[NIN > 0 ? NIN : 1];
+            int idx_t[NIN > 0 ? NIN : 1], gp0[NIN > 0 ? NIN : 1], gp1[NIN > 0 ? NIN : 1];
+            int64_t ps[NIN > 0 ? NIN : 1];
+            bool grouped[NIN > 0 ? NIN : 1];
+            double psum[NIN > 0 ? NIN : 1];
+            int maxper = 0;
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) {
-            const JtMsg &m = tk.msg[k];
-            const int nfree = m.nfree;
-            const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
-            const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
-            src[k] = msg_arena + m.off + bk.gbase[k];
-            ps[k] = m.pstride;
-            idx_t[k] = 0;
+            for (int k = 0; k < NIN; ++k) {
+                const JtMsg &m = tk.msg[k];
+                const int nfree = m.nfree;
+                const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+                const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
+                src[k] = msg_cur + m.off + bk.gbase[k];
+                ps[k] = m.pstride;
+                idx_t[k] = 0;
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
-                if (b < nfree) idx_t[k] += ((tid >> b) & 1) << JT_FPOS(fp, b);
-            grouped[k] = nfree < 8 && m.npart > 1;
-            psum[k] = 0.0;
-            gp0[k] = gp1[k] = 0;
-            if (grouped[k]) {
-                const int groups = JT_THREADS >> nfree;   // >= 2
-                const int per = (m.npart + groups - 1) / groups;
-                gp0[k] = (tid >> nfree) * per;
-                gp1[k] = (gp0[k] + per < m.npart) ? gp0[k] + per : m.npart;
-                maxper = per > maxper ? per : maxper;
-            } else {
-                // one thread per entry, all copies (eight loads in flight)
-                double *sub = reinterpret_cast<double *>(smem + m.lds_off);
-                const int n = 1 << nfree;
-                for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
-                    int idx = idx_t[k];
+                for (int b = 0; b < 8; ++b)
+                    if (b < nfree) idx_t[k] += ((tid >> b) & 1) << JT_FPOS(fp, b);
+                grouped[k] = nfree < 8 && m.npart > 1;
+                psum[k] = 0.0;
+                gp0[k] = gp1[k] = 0;
+                if (grouped[k]) {
+                    const int groups = JT_THREADS >> nfree;   // >= 2
+                    const int per = (m.npart + groups - 1) / groups;
+                    gp0[k] = (tid >> nfree) * per;
+                    gp1[k] = (gp0[k] + per < m.npart) ? gp0[k] + per : m.npart;
+                    maxper = per > maxper ? per : maxper;
+                } else {
+                    // one thread per entry, all copies (eight loads in flight)
+                    double *sub = reinterpret_cast<double *>(smem + m.lds_off);
+                    const int n = 1 << nfree;
+                    for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
+                        int idx = idx_t[k];
 #pragma unroll
-                    for (int b = 8; b < JT_MAX_FREE; ++b)
-                        if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
-                    double sum = 0.0;
-                    for (int p = 0; p < m.npart; p += 8) {
-                        double c[8];
+                        for (int b = 8; b < JT_MAX_FREE; ++b)
+                            if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
+                        double sum = 0.0;
+                        for (int p = 0; p < m.npart; p += 8) {
+                            double c[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) c[u] = (p + u < m.npart) ? src[k][(int64_t)(p + u) * ps[k] + idx] : 0.0;
+                            for (int u = 0; u < 8; ++u) c[u] = (p + u < m.npart) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(p + u) * ps[k] + idx)) : 0.0;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) sum += c[u];
+                            for (int u = 0; u < 8; ++u) {
+                                sum += c[u];
+                                if (FLOW && jt_unwritten(c[u])) unready = src[k] + ((int64_t)(p + u) * ps[k] + idx);
+                            }
+                        }
+                        sub[s] = sum;
                     }
-                    sub[s] = sum;
                 }
             }
-        }
-        // grouped messages: every thread sums its range of copies of its entry, all messages at once
-        constexpr int GC = NIN >= 3 ? 4 : 8;          // copies in flight per message (register budget)
-        for (int p = 0; p < maxper; p += GC) {
-            double c[NIN > 0 ? NIN : 1][GC];
+            // grouped messages: every thread sums its range of copies of its entry, all messages at once
+            constexpr int GC = NIN >= 3 ? 4 : 8;          // copies in flight per message (register budget)
+            for (int p = 0; p < maxper; p += GC) {
+                double c[NIN > 0 ? NIN : 1][GC];
+#pragma unroll
+                for (int k = 0; k < NIN; ++k)
+#pragma unroll
+                    for (int u = 0; u < GC; ++u)
+                        c[k][u] = (grouped[k] && gp0[k] + p + u < gp1[k]) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k])) : 0.0;
+#pragma unroll
+                for (int k = 0; k < NIN; ++k)
+#pragma unroll
+                    for (int u = 0; u < GC; ++u) {
+                        psum[k] += c[k][u];
+                        if (FLOW && jt_unwritten(c[k][u])) unready = src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]);
+                    }
+            }
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
-#pragma unroll
-                for (int u = 0; u < GC; ++u)
-                    c[k][u] = (grouped[k] && gp0[k] + p + u < gp1[k]) ? src[k][(int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]] : 0.0;
-#pragma unroll
-            for (int k = 0; k < NIN; ++k)
-#pragma unroll
-                for (int u = 0; u < GC; ++u) psum[k] += c[k][u];
+                if (grouped[k]) scratch[k * JT_THREADS + tid] = psum[k];
         }
+        if (attempt == 0) {
 #pragma unroll
-        for (int k = 0; k < NIN; ++k)
-            if (grouped[k]) scratch[k * JT_THREADS + tid] = psum[k];
+            for (int k = 0; k < NOUT; ++k) {
+                const JtMsg &m = tk.msg[JT_MAX_IN + k];
+                double *sub = reinterpret_cast<double *>(smem + m.lds_off);
+                const int n = 1 << m.nfree;
+                for (int s = tid; s < n; s += JT_THREADS) sub[s] = 0.0;
+            }
+        }
+        if constexpr (!FLOW || NIN == 0) {
+            __syncthreads();
+            break;
+        } else {
+            // Some entry was not ready: ONE lane of the workgroup waits on one such entry (polling with
+            // back-off: thousands of workgroups may be waiting at the top of a tree, and their polls
+            // share the memory system with the workgroups they wait for), then everybody loads again.
+            // The poller gives up after 2 s (100 MHz clock) or when another workgroup did, so that the
+            // grid always drains; the host then reports the propagate as failed.
+            if (fl.dbg & 4) unready = nullptr;
+            if (fl.dbg & 8) unready = msg_cur;                           // fault injection: wait for ever
+            uint32_t *slot = flow_ctl + 4 + (attempt & 1) * 12;          // [0..3] wave flags, [4..11] wave candidates
+            {
+                const uint64_t have = __ballot(unready != nullptr);
+                if (have != 0 && lane == (int)__builtin_ctzll(have)) {
+                    slot[4 + 2 * wave] = (uint32_t)(uintptr_t)unready;
+                    slot[5 + 2 * wave] = (uint32_t)((uintptr_t)unready >> 32);
+                }
+                if (lane == 0) slot[wave] = have != 0 ? 1u : 0u;
+            }
+            __syncthreads();
+            const uint32_t w3 = slot[3], w2 = slot[2], w1 = slot[1], w0 = slot[0];
+            if ((w0 | w1 | w2 | w3) == 0) break;
+            if (tid == 0) {
+                const int cw = w3 ? 3 : (w2 ? 2 : (w1 ? 1 : 0));          // later waves hold later partial copies
+                const double *entry = reinterpret_cast<const double *>((uintptr_t)slot[4 + 2 * cw] | ((uintptr_t)slot[5 + 2 * cw] << 32));
+                if (wait_t0 == 0) wait_t0 = __builtin_amdgcn_s_memrealtime();
+                uint32_t give_up = 0;
+                unsigned spins = 0;
+                const uint64_t limit = (fl.dbg & 8) ? 2000000ull : 200000000ull;
+                while (jt_unwritten(jt_msg_load<true>(entry)) || (fl.dbg & 8)) {
+                    if (spins < 2) __builtin_amdgcn_s_sleep(8);            // ~0.25 us, 0.5 us, then 1 us per poll
+                    else if (spins < 6) __builtin_amdgcn_s_sleep(16);
+                    else __builtin_amdgcn_s_sleep(32);
+                    if ((++spins & 15u) == 0) {
+                        if (__hip_atomic_load(fl.sync + JT_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = 1;
+                        else if (__builtin_amdgcn_s_memrealtime() - wait_t0 > limit) {
+                            __hip_atomic_store(fl.sync + JT_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(fl.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            give_up = 1;
+                        }
+                        if (give_up) break;
+                    }
+                }
+                flow_ctl[1] = give_up;
+            }
+            __syncthreads();
+            if (flow_ctl[1] != 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA loads must land before the wave ends
+                return;
+            }
+        }
     }
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
-        const JtMsg &m = tk.msg[JT_MAX_IN + k];
-        double *sub = reinterpret_cast<double *>(smem + m.lds_off);
-        const int n = 1 << m.nfree;
-        for (int s = tid; s < n; s += JT_THREADS) sub[s] = 0.0;
-    }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         const JtMsg &m = tk.msg[k];
@@ -430,7 +520,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
             const JtMsg &m = tk.msg[JT_MAX_IN + j];
-            double *dst = msg_arena + m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+            const int64_t at = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+            double *dst = msg_arena + fl.cur_off + at;
+            double *oth = msg_arena + fl.oth_off + at;          // the half the next propagate will use
+            const bool mark = fl.oth_off >= 0;
             const int nfree = m.nfree;
             const int n = 1 << nfree;
             const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
@@ -444,7 +537,8 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 #pragma unroll
                 for (int b = 8; b < JT_MAX_FREE; ++b)
                     if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
-                dst[idx] = out_sub[j][s];
+                jt_msg_store<FLOW>(dst + idx, out_sub[j][s]);
+                if (mark) oth[idx] = __longlong_as_double((long long)JT_UNWRITTEN);
             }
         }
     }
@@ -452,7 +546,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp[5] = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
-            double *o = msg_arena + tk.dbg_off + (int64_t)blockIdx.x * 8;
+            double *o = msg_arena + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * 8;
             for (int i = 0; i < 6; ++i) o[i] = (double)stamp[i];
         }
     }
@@ -464,14 +558,14 @@ template <typename T>
 __global__ __launch_bounds__(JT_THREADS) void jt_collect_level(const JtTask *__restrict__ tasks,
                                                                const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                const T *__restrict__ psi, T *__restrict__ bel,
-                                                               double *__restrict__ msg) {
+                                                               double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
     switch (tk.n_in) {
-        case 0: jt_pass<T, 0, 1, 0>(tk, bk, itab, psi, bel, msg); break;
-        case 1: jt_pass<T, 1, 1, 0>(tk, bk, itab, psi, bel, msg); break;
-        case 2: jt_pass<T, 2, 1, 0>(tk, bk, itab, psi, bel, msg); break;
-        default: jt_pass<T, 3, 1, 0>(tk, bk, itab, psi, bel, msg); break;
+        case 0: jt_pass<T, 0, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 1: jt_pass<T, 1, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 2: jt_pass<T, 2, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        default: jt_pass<T, 3, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
     }
 }
 
@@ -479,18 +573,73 @@ template <typename T>
 __global__ __launch_bounds__(JT_THREADS) void jt_distribute_level(const JtTask *__restrict__ tasks,
                                                                   const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                   const T *__restrict__ psi, T *__restrict__ bel,
-                                                                  double *__restrict__ msg) {
+                                                                  double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
-        case 0: jt_pass<T, 0, 0, 1>(tk, bk, itab, psi, bel, msg); break;
-        case 1: jt_pass<T, 1, 1, 1>(tk, bk, itab, psi, bel, msg); break;
-        case 2: jt_pass<T, 2, 2, 1>(tk, bk, itab, psi, bel, msg); break;
-        case 3: jt_pass<T, 3, 3, 1>(tk, bk, itab, psi, bel, msg); break;
-        case 4: jt_pass<T, 1, 0, 1>(tk, bk, itab, psi, bel, msg); break;
-        case 5: jt_pass<T, 2, 1, 1>(tk, bk, itab, psi, bel, msg); break;
-        case 6: jt_pass<T, 3, 2, 1>(tk, bk, itab, psi, bel, msg); break;
-        default: jt_pass<T, 4, 3, 1>(tk, bk, itab, psi, bel, msg); break;
+        case 0: jt_pass<T, 0, 0, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 1: jt_pass<T, 1, 1, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 2: jt_pass<T, 2, 2, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 3: jt_pass<T, 3, 3, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 4: jt_pass<T, 1, 0, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 5: jt_pass<T, 2, 1, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 6: jt_pass<T, 3, 2, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        default: jt_pass<T, 4, 3, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+    }
+}
+
+// Dataflow entry points: ONE launch per phase.  Workgroups take the block list in blockIdx order; the
+// waits cannot deadlock as long as no workgroup is dispatched before one with a lower index (then the
+// lowest unfinished workgroup is always running, and it never waits on an unfinished one).  That is
+// how the hardware dispatches; should it ever not be, the wait times out, the host notices and runs
+// the propagate again with one launch per level (jtp_engine.hip: check_flow).  With JTP_FLOW_TICKETS
+// the list position is drawn from an atomic counter instead, which needs no such assumption but costs
+// a memory round trip before anything else can start (~10% on the benchmark tree).
+__device__ __forceinline__ uint32_t jt_flow_ticket(const JtFlow &fl, uint32_t *flow_ctl) {
+    if (fl.ticket_idx == 0xffffffffu) return blockIdx.x;
+    if (threadIdx.x == 0)
+        flow_ctl[0] = __hip_atomic_fetch_add(fl.sync + fl.ticket_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fl.ticket_base;
+    __syncthreads();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)flow_ctl[0]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS) void jt_collect_flow(const JtTask *__restrict__ tasks,
+                                                              const JtBlock *__restrict__ blk, const int *__restrict__ itab,
+                                                              const T *__restrict__ psi, T *__restrict__ bel,
+                                                              double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28];
+    const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
+    const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
+    const JtBlock &bk = blk[ticket];
+    const JtTask &tk = tasks[bk.task];
+    switch (tk.n_in) {
+        case 0: jt_pass<T, 0, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 1: jt_pass<T, 1, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        default: jt_pass<T, 3, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS) void jt_distribute_flow(const JtTask *__restrict__ tasks,
+                                                                 const JtBlock *__restrict__ blk, const int *__restrict__ itab,
+                                                                 const T *__restrict__ psi, T *__restrict__ bel,
+                                                                 double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28];
+    const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
+    const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
+    const JtBlock &bk = blk[ticket];
+    const JtTask &tk = tasks[bk.task];
+    switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
+        case 0: jt_pass<T, 0, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 1: jt_pass<T, 1, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 3: jt_pass<T, 3, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 4: jt_pass<T, 1, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 5: jt_pass<T, 2, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 6: jt_pass<T, 3, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        default: jt_pass<T, 4, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
     }
 }
 
@@ -499,17 +648,17 @@ __global__ __launch_bounds__(JT_THREADS) void jt_distribute_level(const JtTask *
 template <typename T, int NCH>
 __global__ __launch_bounds__(JT_THREADS) void jt_collect(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                          const T *__restrict__ psi, T *__restrict__ bel,
-                                                         double *__restrict__ msg) {
+                                                         double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
-    jt_pass<T, NCH, 1, 0>(tasks[bk.task], bk, itab, psi, bel, msg);
+    jt_pass<T, NCH, 1, 0>(tasks[bk.task], bk, itab, psi, bel, msg, fl, blockIdx.x);
 }
 
 template <typename T, int HASP, int NCH>
 __global__ __launch_bounds__(JT_THREADS) void jt_distribute(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                             const T *__restrict__ psi, T *__restrict__ bel,
-                                                            double *__restrict__ msg) {
+                                                            double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
-    jt_pass<T, HASP + NCH, NCH, 1>(tasks[bk.task], bk, itab, psi, bel, msg);
+    jt_pass<T, HASP + NCH, NCH, 1>(tasks[bk.task], bk, itab, psi, bel, msg, fl, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------

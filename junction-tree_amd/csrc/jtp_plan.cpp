@@ -793,11 +793,38 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         }
     }
     flush_comm();
+    // ---- dataflow schedule: runs of launches of one phase become one segment --------------------
+    for (const Step &st : hp.steps) {
+        if (st.kind == 1) {
+            hp.flow_steps.push_back(st);
+            continue;
+        }
+        const Launch &L = hp.launches[st.first];
+        const bool extend = !hp.flow_steps.empty() && hp.flow_steps.back().kind == 0 && hp.segments.back().phase == L.phase;
+        if (!extend) {
+            Segment sg;
+            sg.phase = L.phase;
+            sg.first_launch = st.first;
+            sg.blk_off = L.blk_off;
+            sg.ticket_idx = JT_SYNC_HDR + (int)hp.segments.size();
+            Step fs;
+            fs.kind = 0;
+            fs.first = (int)hp.segments.size();
+            fs.count = 1;
+            hp.segments.push_back(sg);
+            hp.flow_steps.push_back(fs);
+        }
+        Segment &sg = hp.segments.back();
+        sg.n_launch++;
+        sg.nblocks += L.nblocks;
+        sg.lds_bytes = std::max(sg.lds_bytes, L.lds_bytes);
+    }
+    hp.sync_words = JT_SYNC_HDR + (int)hp.segments.size();
     if (getenv("JTP_DEBUG") && (atoi(getenv("JTP_DEBUG")) & 2)) {     // time-stamp region, 8 doubles per workgroup
         hp.dbg_base = hp.msg_doubles;
         hp.msg_doubles += (int64_t)hp.blocks.size() * 8;
         for (const Launch &L : hp.launches)
-            for (int t : L.tasks) hp.tasks[t].dbg_off = hp.dbg_base + L.blk_off * 8;
+            for (int t : L.tasks) hp.tasks[t].dbg_off = hp.dbg_base;
     }
     hp.n_messages = 0;
     for (int c = 0; c < N; ++c)
@@ -924,6 +951,19 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
     for (size_t i = 0; i < hp.steps.size(); ++i) {
         if (i) o << ",";
         o << "[" << hp.steps[i].kind << "," << hp.steps[i].first << "," << hp.steps[i].count << "]";
+    }
+    o << "],\"sync_words\":" << hp.sync_words << ",\"segments\":[";
+    for (size_t i = 0; i < hp.segments.size(); ++i) {
+        const Segment &g = hp.segments[i];
+        if (i) o << ",";
+        o << "{\"phase\":" << g.phase << ",\"first_launch\":" << g.first_launch << ",\"n_launch\":" << g.n_launch
+          << ",\"blk_off\":" << g.blk_off << ",\"nblocks\":" << g.nblocks << ",\"lds_bytes\":" << g.lds_bytes
+          << ",\"ticket_idx\":" << g.ticket_idx << "}";
+    }
+    o << "],\"flow_steps\":[";
+    for (size_t i = 0; i < hp.flow_steps.size(); ++i) {
+        if (i) o << ",";
+        o << "[" << hp.flow_steps[i].kind << "," << hp.flow_steps[i].first << "," << hp.flow_steps[i].count << "]";
     }
     o << "],\"comm\":[";
     for (size_t i = 0; i < hp.comm.size(); ++i) {

@@ -55,6 +55,17 @@ struct Step {
     int first = 0, count = 0;        // launch index, or [first, first+count) in comm
 };
 
+// Dataflow schedule: consecutive launches of one phase run as ONE launch whose workgroups take
+// their place in the block list from a ticket counter and wait on message completion counters.
+struct Segment {
+    int phase = 0;
+    int first_launch = 0, n_launch = 0;
+    int64_t blk_off = 0;
+    int nblocks = 0;
+    int lds_bytes = 0;
+    int ticket_idx = 0;              // word of the sync buffer
+};
+
 struct VirtualFill { int64_t off; int nbits, real_bits; };   // all-ones table of a virtual clique
 
 // decode chunk number -> workgroup record (element base, message bases, partial numbers)
@@ -84,6 +95,9 @@ struct HostPlan {
     std::vector<VirtualFill> virtual_fills;
     std::vector<CommOp> comm;
     std::vector<Step> steps;
+    std::vector<Segment> segments;
+    std::vector<Step> flow_steps;        // as `steps`, launches replaced by segments (kind 0: first = segment)
+    int sync_words = 0;                  // uint32 words of the per-evidence-set sync buffer
     std::vector<JtPackDesc> pack;    // per real clique (host order)
     int64_t arena_elems = 0;         // potential arena == belief arena size (elements)
     int64_t msg_doubles = 0;

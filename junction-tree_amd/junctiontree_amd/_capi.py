@@ -15,7 +15,9 @@ JTP_F32, JTP_F64 = 0, 1
 JTP_PLAN_ONLY = 1
 JTP_SPLIT_VARIANTS = 2
 JTP_KEEP_ROOT = 4
-N_VARIANTS = 14
+JTP_LEVEL_LAUNCHES = 8
+JTP_FLOW_TICKETS = 16
+N_VARIANTS = 16
 
 
 class TreeDesc(C.Structure):
@@ -64,7 +66,7 @@ class Stats(C.Structure):
         ("kernel_ms", C.c_double * 32),
         ("kernel_bytes", C.c_double * 32),
         ("kernel_launches", C.c_int32 * 32),
-        ("pad", C.c_int32),
+        ("flow_fallbacks", C.c_int32),
     ]
 
 

@@ -56,7 +56,8 @@ class Plan:
 
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
-                 layout_policy=0, split_variants=False, keep_root=False):
+                 layout_policy=0, split_variants=False, keep_root=False, level_launches=False,
+                 flow_tickets=False):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
@@ -112,7 +113,9 @@ class Plan:
         d.n_ranks = n_ranks
         d.rank = rank
         d.flags = ((_capi.JTP_PLAN_ONLY if plan_only else 0) | (_capi.JTP_SPLIT_VARIANTS if split_variants else 0)
-                   | (_capi.JTP_KEEP_ROOT if keep_root else 0))
+                   | (_capi.JTP_KEEP_ROOT if keep_root else 0)
+                   | (_capi.JTP_LEVEL_LAUNCHES if level_launches else 0)
+                   | (_capi.JTP_FLOW_TICKETS if flow_tickets else 0))
         d.lds_budget = lds_budget
         d.block_log2 = block_log2
         d.layout_policy = layout_policy
@@ -250,7 +253,7 @@ class Plan:
                                  "bytes": st.kernel_bytes[v]}
         return {"n_launches": st.n_launches, "n_messages": st.n_messages, "n_tasks": st.n_tasks,
                 "algorithmic_bytes": st.algorithmic_bytes, "collect_ms": st.collect_ms,
-                "distribute_ms": st.distribute_ms, "kernels": kernels}
+                "distribute_ms": st.distribute_ms, "kernels": kernels, "flow_fallbacks": st.flow_fallbacks}
 
 
 # ---------------------------------------------------------------------- plan cache

@@ -76,7 +76,7 @@ class Emulator:
         return (up * dn).reshape(cards)
 
     # ---------------------------------------------------------------- one workgroup
-    def _block(self, tk, chunk, collect, record=None):
+    def _block(self, tk, chunk, collect, record=None, strict=False):
         VEC, EB = self.VEC, self.EB
         n_in, n_out = tk["n_in"], tk["n_out"]
         ins, outs = tk["in"], tk["out"]
@@ -103,6 +103,8 @@ class Emulator:
             tot = np.zeros(len(s))
             for p in range(m["npart"]):
                 tot = tot + self.msg[m["off"] + p * m["pstride"] + gb_in[k] + idx]
+            if strict:      # dataflow order: every entry read was written by an earlier workgroup
+                assert not np.any(np.isnan(tot)), "a workgroup precedes the producer of an entry it reads"
             subs.append(tot)
         osubs = [np.zeros(1 << m["nfree"]) for m in outs]
 
@@ -187,6 +189,31 @@ class Emulator:
             self.msg[dst] = osubs[j]
 
     # ---------------------------------------------------------------- whole schedule
+    def propagate_flow(self, comm=None):
+        """Run the dataflow schedule (one launch per phase): workgroups in block-list order, each
+        checked to find every message entry it reads already written (NaN = unwritten, as the
+        device marks it) - i.e. its producers come earlier in the list, which is what makes the
+        device-side waits deadlock free once workgroups draw their list position from a ticket."""
+        d = self.d
+        self.msg[:] = np.nan
+        tickets = [g["ticket_idx"] for g in d["segments"]]
+        assert len(set(tickets)) == len(tickets) and all(2 <= t < d["sync_words"] for t in tickets)
+        covered = []
+        for kind, first, count in d["flow_steps"]:
+            if kind == 1:
+                assert comm is not None, "multi-rank plan needs a comm callback"
+                comm(d["comm"][first:first + count], self.msg)
+                continue
+            seg = d["segments"][first]
+            launches = d["launches"][seg["first_launch"]:seg["first_launch"] + seg["n_launch"]]
+            assert all(L["phase"] == seg["phase"] for L in launches)
+            assert seg["blk_off"] == launches[0]["blk_off"] and seg["nblocks"] == sum(L["nblocks"] for L in launches)
+            assert seg["lds_bytes"] == max(L["lds_bytes"] for L in launches)
+            covered += list(range(seg["first_launch"], seg["first_launch"] + seg["n_launch"]))
+            for blk in d["blocks"][seg["blk_off"]:seg["blk_off"] + seg["nblocks"]]:
+                self._block(d["tasks"][blk[0]], blk[1], seg["phase"] == 0, blk[2:], strict=True)
+        assert covered == list(range(len(d["launches"])))
+
     def propagate(self, comm=None):
         """Run the plan's step list.  `comm(ops, msg)` executes one exchange group (a list of the
         plan's comm records) on the message arena `msg`; it is required for multi-rank plans."""

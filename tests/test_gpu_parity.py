@@ -141,6 +141,7 @@ def test_refsafe_synthetic_trees_f64_and_f32(golden):
     {}, {"block_log2": 10}, {"block_log2": 11, "lds_budget": 256}, {"layout_policy": 1},
     {"layout_policy": 1, "block_log2": 10, "lds_budget": 128}, {"block_log2": 12, "lds_budget": 2048},
     {"split_variants": True}, {"split_variants": True, "block_log2": 10}, {"keep_root": True},
+    {"level_launches": True}, {"level_launches": True, "block_log2": 10, "lds_budget": 256},
 ])
 def test_planner_options_do_not_change_results(opts):
     specs = [
@@ -387,6 +388,54 @@ def test_batched_evidence_sets_on_streams():
             close(plan.belief(node, batch=b), want[node], what="batch %d node %d" % (b, node))
         assert abs(plan.z(batch=b) - z) <= 1e-11 * abs(z)
     plan.close()
+
+
+def test_repeated_propagates_with_new_potentials_and_mixed_launch_modes():
+    """The dataflow launches (one per phase) find their inputs through "unwritten" markers in the
+    message arena, whose two halves alternate between propagates: run many propagates on one plan,
+    changing every potential in between and switching between dataflow and per-level launches
+    (per-launch profiling uses the latter), and check every result - a stale or early read of any
+    message entry would show up as a wrong belief."""
+    spec = synthetic.wide_binary_tree(n_cliques=31, width=15, sep=7, card=2, seed=5)
+    n = spec["n_cliques"]
+    for dtype in ("f64", "f32"):
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, block_log2=11)
+        for it in range(8):
+            pots = synthetic.potentials_for(spec, seed=100 + it, dtype=np.float32 if dtype == "f32" else np.float64)
+            for c in range(n):
+                plan.set_potential(c, pots[c])
+            plan.set_profiling(1 if it in (2, 3, 6) else 0, per_launch=it in (2, 3, 6))
+            plan.propagate()
+            if it % 3 == 1:
+                plan.propagate()               # twice on the same inputs: same answer
+            want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+            for node in range(len(spec["node_vars"])):
+                close(plan.belief(node), want[node], rtol=RTOL32 if dtype == "f32" else 1e-11, what="%s it %d node %d" % (dtype, it, node))
+            assert abs(plan.z() - z) <= (1e-5 if dtype == "f32" else 1e-11) * abs(z)
+        plan.close()
+
+
+def test_dataflow_timeout_falls_back_to_level_launches(monkeypatch):
+    """Fault injection: every dataflow wait times out (JTP_FLOW_DEBUG=8).  The host must notice at the
+    next synchronisation, run the propagate again with one launch per level, and keep doing so."""
+    spec = synthetic.wide_binary_tree(n_cliques=15, width=13, sep=6, card=2, seed=8)
+    pots = synthetic.potentials_for(spec, seed=31)
+    want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+    for tickets in (False, True):
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", flow_tickets=tickets)
+        for c in range(spec["n_cliques"]):
+            plan.set_potential(c, pots[c])
+        plan.propagate()
+        assert plan.stats()["flow_fallbacks"] == 0 and plan.stats()["n_launches"] == 2
+        monkeypatch.setenv("JTP_FLOW_DEBUG", "8")
+        plan.propagate()
+        monkeypatch.delenv("JTP_FLOW_DEBUG")
+        for node in range(len(spec["node_vars"])):
+            close(plan.belief(node), want[node], what="node %d" % node)
+        assert plan.stats()["flow_fallbacks"] == 1 and plan.stats()["n_launches"] > 2
+        plan.propagate()
+        assert abs(plan.z() - z) <= 1e-11 * abs(z) and plan.stats()["flow_fallbacks"] == 1
+        plan.close()
 
 
 def test_grid_mrf_through_public_api_vs_bruteforce():

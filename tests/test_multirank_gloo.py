@@ -68,6 +68,9 @@ def _worker(rank, world, port, recipe, kwargs, queue):
                 view[:] = buf.numpy()
 
         emu.propagate(comm)
+        level_bel = emu.bel.copy()
+        emu.propagate_flow(comm)               # dataflow segments between the same exchange groups
+        np.testing.assert_array_equal(emu.bel, level_bel)
         mine = {}
         for c in range(n):
             if owner[c] == rank:

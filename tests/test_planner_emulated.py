@@ -20,6 +20,10 @@ def emulate(tree, potentials, node_vars, sizes, dtype="f64", **opts):
         ids = [plan.var_id[lab] for lab in node_vars[c]]
         emu.set_potential(plan.abi_of[c], ids, [sizes[lab] for lab in node_vars[c]], potentials[c])
     emu.propagate()
+    level_bel, level_msg = emu.bel.copy(), emu.msg.copy()
+    emu.propagate_flow()                       # the one-launch-per-phase order computes the same thing
+    np.testing.assert_array_equal(emu.bel, level_bel)
+    np.testing.assert_array_equal(emu.msg, level_msg)
     psep_of = {s["node"]: i for i, s in enumerate(desc["pseps"]) if s["node"] >= 0}
     out = {}
     for c in plan.cliques:
