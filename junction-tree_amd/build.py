@@ -24,21 +24,24 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=True, extra=()):
-    if not force and not needs_build():
+def build(force=False, verbose=True, extra=(), out=None):
+    out = out or LIB
+    if out == LIB and not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wno-unused-variable"] + list(extra)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB, "-ldl"]
+    cmd += ["-o", out, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print("built", LIB)
+    # python build.py [--force] [--out path.so] [-DNAME ...]   (the last two: experimental builds)
+    args = sys.argv[1:]
+    out = args[args.index("--out") + 1] if "--out" in args else None
+    print("built", build(force="--force" in args or out is not None, out=out, extra=[a for a in args if a.startswith("-D")]))

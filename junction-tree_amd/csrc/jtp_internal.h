@@ -24,6 +24,7 @@
 #define JT_THREADS 256
 #define JT_RING_BYTES 16384      // LDS bytes at offset 0: per wave a ring of 4 x 1 KiB element slots (LDS-DMA)
 #define JT_STAGE_SCRATCH 2048    // bytes of LDS for staging sums
+#define JT_MIN_ITER_LOG2 2       // a workgroup runs at least 4 loop iterations (one per ring slot)
 #define JT_MAX_ITER_LOG2 6       // a workgroup runs at most 64 loop iterations: its offset table lives in
                                  // registers, row r in lane r
 #define JT_SYNC_ABORT 0        // dataflow launches, per evidence set: word 0 = abort flag, then one ticket
@@ -63,9 +64,9 @@ struct JtTask {
     int32_t real_bits;         // index bits actually used by variables (<= nbits; rest is padding)
     int32_t debug;             // timing experiments only (JTP_DEBUG): 1 = skip epilogues and flush
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
-    uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base)
+    uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base; 0 past the end)
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer
-    int32_t total;             // loop iterations per workgroup = 2^(nA + nR), >= 8
+    int32_t total;             // loop iterations per workgroup = 2^(nA + nR), 4 .. 64
     int32_t itab_lds;          // byte offset of the iteration table in dynamic LDS
     int64_t dbg_off;           // JTP_DEBUG & 2: msg-arena offset of 8 time stamps per workgroup (diagnostic builds)
     JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing

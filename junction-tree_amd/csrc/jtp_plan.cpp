@@ -105,7 +105,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
         int best = -1;
         long best_lds = 0;
         int best_part = 0;
-        for (int b = TB; b < nbits && nbits - popc(F) > TB + 3; ++b) {
+        for (int b = TB; b < nbits && nbits - popc(F) > TB + JT_MIN_ITER_LOG2; ++b) {
             if (F >> b & 1) continue;
             long l = lds_of(F | 1u << b);
             int pl = part_log2(F | 1u << b);
@@ -121,7 +121,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     }
     // 2. Parallelism: split until a workgroup handles at most 2^block_log2 elements, preferring
     //    bits that every outgoing message contains (no partial copies), highest bit first.
-    block_log2 = std::max(block_log2, TB + 3);          // a workgroup always runs >= 8 iterations
+    block_log2 = std::max(block_log2, TB + JT_MIN_ITER_LOG2);   // a workgroup always runs >= 4 iterations
     block_log2 = std::min(block_log2, TB + JT_MAX_ITER_LOG2);   // and at most 2^JT_MAX_ITER_LOG2
     while (nbits - popc(F) > block_log2) {
         int best = -1;
@@ -537,7 +537,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             bit += hp.vbits[v];
         }
         if (bit > JT_MAX_BITS) FAIL(JTP_EUNSUPPORTED, "clique %d needs %d index bits (max %d)", p.real, bit, JT_MAX_BITS);
-        p.nbits = std::max(bit, hp.TB + 3);             // >= 8 loop iterations per workgroup
+        p.nbits = std::max(bit, hp.TB + JT_MIN_ITER_LOG2);   // >= 4 loop iterations per workgroup
         if (p.nbits - hp.TB > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
     }
     for (size_t s = 0; s < hp.ps.size(); ++s) {

@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libjtprop.so")
+LIB_PATH = os.environ.get("JTPROP_LIB", LIB_PATH)      # developer aid: A/B runs of two builds
 
 JTP_OK, JTP_EINVAL, JTP_EHIP, JTP_ECOMM, JTP_ENOMEM, JTP_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 JTP_F32, JTP_F64 = 0, 1
