@@ -114,6 +114,7 @@ struct KernelTable {
             case JT_K_DIST_P1C3: return jt_distribute<T, 1, 3>;
             case JT_K_COLLECT_LEVEL: return jt_collect_level<T>;
             case JT_K_DISTRIBUTE_LEVEL: return jt_distribute_level<T>;
+            case JT_K_REDUCE_LEVEL: return jt_reduce_level<T>;
         }
         return nullptr;
     }
@@ -124,7 +125,7 @@ static const char *k_names[JT_K_COUNT] = {
     "jt_collect<T, 0>", "jt_collect<T, 1>", "jt_collect<T, 2>", "jt_collect<T, 3>",
     "jt_distribute<T, 0, 0>", "jt_distribute<T, 0, 1>", "jt_distribute<T, 0, 2>", "jt_distribute<T, 0, 3>",
     "jt_distribute<T, 1, 0>", "jt_distribute<T, 1, 1>", "jt_distribute<T, 1, 2>", "jt_distribute<T, 1, 3>",
-    "jt_collect_level<T>", "jt_distribute_level<T>", "jt_collect_flow<T>", "jt_distribute_flow<T>",
+    "jt_collect_level<T>", "jt_distribute_level<T>", "jt_collect_flow<T>", "jt_distribute_flow<T>", "jt_reduce_level<T>",
 };
 
 struct BatchBuffers {
@@ -302,7 +303,8 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         CREATE_TRY(hipMemcpy(pl->d_itab, hp.itab.data(), hp.itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     if (hp.max_lds > 64 * 1024) {
-        for (int v = 0; v < JT_K_COLLECT_FLOW; ++v) {
+        for (int v = 0; v < JT_K_COUNT; ++v) {
+            if (v == JT_K_COLLECT_FLOW || v == JT_K_DISTRIBUTE_FLOW) continue;
             const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v);
             CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hp.max_lds));
         }
@@ -666,9 +668,9 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
     const int64_t pstride = (int64_t)1 << sp.nbits;
     const double *cur = b.msg + b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));      // the half the last propagate wrote
     if (host_dtype == JTP_F32)
-        hipLaunchKernelGGL((jt_msg_unpack<float>), dim3(grid), dim3(256), 0, s, d, cur + sp.up_off, sp.up_npart, cur + sp.dn_off, sp.dn_npart, pstride, (float *)pl->stage);
+        hipLaunchKernelGGL((jt_msg_unpack<float>), dim3(grid), dim3(256), 0, s, d, cur + sp.up_roff, sp.up_rnpart, cur + sp.dn_roff, sp.dn_rnpart, pstride, (float *)pl->stage);
     else
-        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, cur + sp.up_off, sp.up_npart, cur + sp.dn_off, sp.dn_npart, pstride, (double *)pl->stage);
+        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, cur + sp.up_roff, sp.up_rnpart, cur + sp.dn_roff, sp.dn_rnpart, pstride, (double *)pl->stage);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)stride * hsz, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -63,6 +63,9 @@ struct JtTask {
     int32_t pnode;             // planner node this task belongs to
     int32_t real_bits;         // index bits actually used by variables (<= nbits; rest is padding)
     int32_t debug;             // timing experiments only (JTP_DEBUG): 1 = skip epilogues and flush
+    int32_t kind;              // 0: clique pass; 1: reduce task - sum the msg[0].npart partial copies of a
+                               // message (2^nbits entries, 256 per workgroup from entry xF) into msg[JT_MAX_IN].off
+    int32_t pad0;
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
     uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base; 0 past the end)
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer
@@ -131,6 +134,7 @@ enum {
     JT_K_DIST_P0C0, JT_K_DIST_P0C1, JT_K_DIST_P0C2, JT_K_DIST_P0C3,
     JT_K_DIST_P1C0, JT_K_DIST_P1C1, JT_K_DIST_P1C2, JT_K_DIST_P1C3,
     JT_K_COLLECT_LEVEL, JT_K_DISTRIBUTE_LEVEL,      // one launch per tree level
-    JT_K_COLLECT_FLOW, JT_K_DISTRIBUTE_FLOW,        // one launch per phase, workgroups wait on message counters (default)
+    JT_K_COLLECT_FLOW, JT_K_DISTRIBUTE_FLOW,        // one launch per phase, workgroups wait for their message entries (default)
+    JT_K_REDUCE_LEVEL,                              // reduce tasks of one level (per-level launches only)
     JT_K_COUNT
 };

@@ -558,6 +558,72 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     }
 }
 
+// Reduce task: entry i of the sum = copy_0[i] + copy_1[i] + ... (in copy order: bit-reproducible), 256
+// entries per workgroup.  In a dataflow launch the copies may still be in the making: every entry is
+// loaded until it is no longer the "unwritten" marker (one poller per wave here; the wait is short,
+// the producers are the workgroups just ahead in the list).
+template <bool FLOW>
+__device__ __forceinline__ void jt_reduce(const JtTask &tk, const JtBlock &bk, double *__restrict__ msg_arena,
+                                          const JtFlow &fl) {
+    const int64_t n = (int64_t)1 << tk.nbits;
+    const int64_t i = (int64_t)bk.xF + threadIdx.x;
+    const JtMsg &src = tk.msg[0];
+    const bool active = i < n;
+    const double *copies = msg_arena + fl.cur_off + src.off + (active ? i : 0);
+    const int npart = src.npart;
+    const int64_t ps = src.pstride;
+    double sum = 0.0;
+    uint64_t t0 = 0;
+    for (int p0 = 0; p0 < npart; p0 += 8) {
+        double c[8];
+        for (;;) {
+            const double *unready = nullptr;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = (active && p0 + u < npart) ? jt_msg_load<FLOW>(copies + (int64_t)(p0 + u) * ps) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (FLOW && jt_unwritten(c[u])) unready = copies + (int64_t)(p0 + u) * ps;
+            if (!FLOW || (fl.dbg & 4)) break;
+            const uint64_t have = __ballot(unready != nullptr);
+            if (have == 0) break;
+            bool give_up = false;
+            if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(have)) {
+                if (t0 == 0) t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                while (jt_unwritten(jt_msg_load<true>(unready))) {
+                    if (spins < 4) __builtin_amdgcn_s_sleep(8);
+                    else __builtin_amdgcn_s_sleep(32);
+                    if ((++spins & 15u) == 0) {
+                        if (__hip_atomic_load(fl.sync + JT_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+                        else if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+                            __hip_atomic_store(fl.sync + JT_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(fl.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            give_up = true;
+                        }
+                        if (give_up) break;
+                    }
+                }
+            }
+            if (__any(give_up)) return;          // (no LDS-DMA in flight here; other waves find the abort flag themselves)
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += c[u];
+    }
+    if (active) {
+        const int64_t at = tk.msg[JT_MAX_IN].off + i;
+        jt_msg_store<FLOW>(msg_arena + fl.cur_off + at, sum);
+        if (fl.oth_off >= 0) msg_arena[fl.oth_off + at] = __longlong_as_double((long long)JT_UNWRITTEN);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS) void jt_reduce_level(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                              const int *__restrict__ itab, const T *__restrict__ psi,
+                                                              T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    const JtBlock &bk = blk[blockIdx.x];
+    jt_reduce<false>(tasks[bk.task], bk, msg, fl);
+}
+
 // Entry points (these names appear in rocprofv3 traces).  One launch covers every clique of
 // one tree level, whatever its number of neighbours: the workgroup dispatches on its task.
 template <typename T>
@@ -619,6 +685,10 @@ __global__ __launch_bounds__(JT_THREADS) void jt_collect_flow(const JtTask *__re
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
     const JtTask &tk = tasks[bk.task];
+    if (tk.kind != 0) {
+        jt_reduce<true>(tk, bk, msg, fl);
+        return;
+    }
     switch (tk.n_in) {
         case 0: jt_pass<T, 0, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
         case 1: jt_pass<T, 1, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
@@ -637,6 +707,10 @@ __global__ __launch_bounds__(JT_THREADS) void jt_distribute_flow(const JtTask *_
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
     const JtTask &tk = tasks[bk.task];
+    if (tk.kind != 0) {
+        jt_reduce<true>(tk, bk, msg, fl);
+        return;
+    }
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
         case 0: jt_pass<T, 0, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
         case 1: jt_pass<T, 1, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;

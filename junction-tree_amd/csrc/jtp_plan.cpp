@@ -665,31 +665,66 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     }
 
     // ---- message arena ----------------------------------------------------------------------
+    // A message written as many partial copies costs every consuming workgroup (sub-box x copies)
+    // loads before it can start, on the critical path of the small levels near the root.  From
+    // `red_min` copies on, a reduce task behind the producer sums them once and consumers read the sum.
+    const int red_min = getenv("JTP_REDUCE_MIN") ? atoi(getenv("JTP_REDUCE_MIN")) : 8;
     hp.msg_doubles = 0;
     for (auto &s : hp.ps) {
         bool mine = hp.pn[s.child].owner == hp.rank || hp.pn[s.parent].owner == hp.rank;
         if (!mine) continue;
         int64_t n = (int64_t)1 << s.nbits;
-        s.up_off = hp.msg_doubles;
+        s.up_off = s.up_roff = hp.msg_doubles;
         hp.msg_doubles += n * s.up_npart;
-        s.dn_off = hp.msg_doubles;
+        s.dn_off = s.dn_roff = hp.msg_doubles;
         hp.msg_doubles += n * s.dn_npart;
+        s.up_rnpart = s.up_npart;
+        s.dn_rnpart = s.dn_npart;
+        for (int up = 0; up < 2; ++up) {
+            const int npart = up ? s.up_npart : s.dn_npart;
+            if (red_min <= 0 || npart < red_min) continue;
+            (up ? s.up_roff : s.dn_roff) = hp.msg_doubles;
+            (up ? s.up_rnpart : s.dn_rnpart) = 1;
+            hp.msg_doubles += n;
+            JtTask rt;
+            memset(&rt, 0, sizeof rt);
+            rt.kind = 1;
+            rt.pnode = up ? s.child : s.parent;              // the producer: its rank runs the reduction
+            rt.nbits = s.nbits;
+            rt.n_in = rt.n_out = 1;
+            rt.bel_off = -1;
+            rt.msg[0].off = up ? s.up_off : s.dn_off;
+            rt.msg[0].npart = npart;
+            rt.msg[0].pstride = (int32_t)n;
+            rt.msg[JT_MAX_IN].off = up ? s.up_roff : s.dn_roff;
+            rt.msg[JT_MAX_IN].npart = 1;
+            rt.msg[JT_MAX_IN].pstride = (int32_t)n;
+            while ((256 << rt.nF) < n) {
+                rt.f_x[rt.nF] = 256u << rt.nF;
+                rt.nF++;
+            }
+            (up ? s.up_red_task : s.dn_red_task) = (int)hp.tasks.size();
+            hp.tasks.push_back(rt);
+            hp.task_variant.push_back(JT_K_REDUCE_LEVEL);
+            task_bytes.push_back(0.0);
+        }
         hp.msg_doubles = (hp.msg_doubles + 1) & ~(int64_t)1;
     }
     for (size_t t = 0; t < hp.tasks.size(); ++t) {
         JtTask &tk = hp.tasks[t];
+        if (tk.kind != 0) continue;
         const PNode &p = hp.pn[tk.pnode];
         bool collect = (int)t == p.collect_task;
         int k = 0;
         if (!collect && p.psep >= 0) {
-            tk.msg[k].off = hp.ps[p.psep].dn_off;
-            tk.msg[k].npart = hp.ps[p.psep].dn_npart;
+            tk.msg[k].off = hp.ps[p.psep].dn_roff;
+            tk.msg[k].npart = hp.ps[p.psep].dn_rnpart;
             ++k;
         }
         for (int ch : p.children) {
             const PSep &s = hp.ps[hp.pn[ch].psep];
-            tk.msg[k].off = s.up_off;
-            tk.msg[k].npart = s.up_npart;
+            tk.msg[k].off = s.up_roff;
+            tk.msg[k].npart = s.up_rnpart;
             ++k;
         }
         if (collect) tk.msg[JT_MAX_IN].off = hp.ps[p.psep].up_off;
@@ -718,8 +753,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         op.psep = psep;
         op.up = up;
         op.peer = peer;
-        op.off = up ? s.up_off : s.dn_off;
-        op.count = ((int64_t)1 << s.nbits) * (up ? s.up_npart : s.dn_npart);
+        op.off = up ? s.up_roff : s.dn_roff;                 // (the sum, when the producer's rank reduces)
+        op.count = ((int64_t)1 << s.nbits) * (up ? s.up_rnpart : s.dn_rnpart);
         pending.push_back(op);
     };
     auto by_level = [&](int level) {
@@ -766,13 +801,49 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             hp.steps.push_back(st);
         }
     };
+    // reduce tasks of the messages one level has just produced (its own launch when launching per level)
+    auto emit_reduce = [&](int phase, int level) {
+        std::vector<int> tasks;
+        for (int c : by_level(level)) {
+            const PNode &p = hp.pn[c];
+            if (p.owner != hp.rank) continue;
+            if (phase == 0) {
+                if (p.psep >= 0 && hp.ps[p.psep].up_red_task >= 0) tasks.push_back(hp.ps[p.psep].up_red_task);
+            } else {
+                for (int k : p.children)
+                    if (hp.ps[hp.pn[k].psep].dn_red_task >= 0) tasks.push_back(hp.ps[hp.pn[k].psep].dn_red_task);
+            }
+        }
+        if (tasks.empty()) return;
+        Launch L;
+        L.phase = phase;
+        L.level = level;
+        L.variant = JT_K_REDUCE_LEVEL;
+        L.tasks = tasks;
+        L.blk_off = (int64_t)hp.blocks.size();
+        for (int t : tasks)
+            for (uint32_t f = 0; f < (1u << hp.tasks[t].nF); ++f) {
+                hp.blocks.push_back(jtp_make_block(hp.tasks[t], (uint32_t)t, f));
+                hp.block_chunk.push_back(f);
+            }
+        L.nblocks = (int)(hp.blocks.size() - L.blk_off);
+        Step st;
+        st.kind = 0;
+        st.first = (int)hp.launches.size();
+        st.count = 1;
+        hp.launches.push_back(L);
+        hp.steps.push_back(st);
+    };
     for (int level = maxdepth; level >= 0; --level) {          // collect
         for (int c : by_level(level)) {                        // receive what this level consumes
             if (hp.pn[c].owner != hp.rank) continue;
             for (int k : hp.pn[c].children)
                 if (hp.pn[k].owner != hp.rank) comm_op(0, hp.pn[k].psep, 1, hp.pn[k].owner);
         }
-        if (level >= 1) emit_launches(0, level);
+        if (level >= 1) {
+            emit_launches(0, level);
+            emit_reduce(0, level);
+        }
         for (int c : by_level(level)) {                        // send what this level produced
             const PNode &p = hp.pn[c];
             if (p.owner != hp.rank || p.parent < 0) continue;
@@ -786,6 +857,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             if (hp.pn[p.parent].owner != hp.rank) comm_op(0, p.psep, 0, hp.pn[p.parent].owner);
         }
         emit_launches(1, level);
+        emit_reduce(1, level);
         for (int c : by_level(level)) {
             if (hp.pn[c].owner != hp.rank) continue;
             for (int k : hp.pn[c].children)
@@ -929,7 +1001,9 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         if (i) o << ",";
         o << "{\"node\":" << s.node << ",\"child\":" << s.child << ",\"parent\":" << s.parent << ",\"nbits\":" << s.nbits
           << ",\"up_npart\":" << s.up_npart << ",\"dn_npart\":" << s.dn_npart << ",\"up_off\":" << s.up_off
-          << ",\"dn_off\":" << s.dn_off << ",\"vars\":";
+          << ",\"dn_off\":" << s.dn_off << ",\"up_roff\":" << s.up_roff << ",\"dn_roff\":" << s.dn_roff
+          << ",\"up_rnpart\":" << s.up_rnpart << ",\"dn_rnpart\":" << s.dn_rnpart
+          << ",\"up_red_task\":" << s.up_red_task << ",\"dn_red_task\":" << s.dn_red_task << ",\"vars\":";
         json_vec(o, s.vars);
         o << ",\"pos\":";
         json_vec(o, s.pos);
@@ -978,7 +1052,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         for (size_t t = 0; t < hp.tasks.size(); ++t) {
             const JtTask &tk = hp.tasks[t];
             if (t) o << ",";
-            o << "{\"pnode\":" << tk.pnode << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
+            o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
               << ",\"nR\":" << tk.nR << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";

@@ -28,6 +28,11 @@ struct PSep {                        // a separator = one message tensor per dir
     int child = -1, parent = -1;     // pnodes
     int up_npart = 1, dn_npart = 1;  // partial copies written by the producer
     int64_t up_off = -1, dn_off = -1;  // msg arena offsets (doubles); -1: not held by this rank
+    // What consumers, exchanges and read-back use: the partial copies themselves, or - when the
+    // producer writes many - their sum, formed once by a reduce task right behind the producer
+    int64_t up_roff = -1, dn_roff = -1;
+    int up_rnpart = 1, dn_rnpart = 1;
+    int up_red_task = -1, dn_red_task = -1;
 };
 
 struct Launch {

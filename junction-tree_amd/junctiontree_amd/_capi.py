@@ -18,7 +18,7 @@ JTP_SPLIT_VARIANTS = 2
 JTP_KEEP_ROOT = 4
 JTP_LEVEL_LAUNCHES = 8
 JTP_FLOW_TICKETS = 16
-N_VARIANTS = 16
+N_VARIANTS = 17
 
 
 class TreeDesc(C.Structure):

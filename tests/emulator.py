@@ -71,12 +71,32 @@ class Emulator:
         for v, dig in zip(host_vars, digits):
             x += dig.astype(np.int64) << pos[v]
         size = 1 << s["nbits"]
-        up = sum(self.msg[s["up_off"] + p * size + x] for p in range(s["up_npart"]))
-        dn = sum(self.msg[s["dn_off"] + p * size + x] for p in range(s["dn_npart"]))
+        up = sum(self.msg[s["up_roff"] + p * size + x] for p in range(s["up_rnpart"]))
+        dn = sum(self.msg[s["dn_roff"] + p * size + x] for p in range(s["dn_rnpart"]))
         return (up * dn).reshape(cards)
 
     # ---------------------------------------------------------------- one workgroup
+    def _reduce_block(self, tk, chunk, record, strict):
+        """reduce task (csrc/jtp_kernels.hip.h jt_reduce): 256 entries of the sum of the partial copies"""
+        assert tk["n_in"] == 1 and tk["n_out"] == 1 and tk["out"][0]["npart"] == 1
+        src, dst = tk["in"][0], tk["out"][0]
+        n = 1 << tk["nbits"]
+        x0 = sum(tk["f_x"][j] for j in range(tk["nF"]) if (chunk >> j) & 1)
+        assert x0 == chunk * 256 and record[0] == x0
+        i = x0 + np.arange(256)
+        i = i[i < n]
+        assert src["pstride"] == n
+        tot = np.zeros(len(i))
+        for p in range(src["npart"]):
+            tot = tot + self.msg[src["off"] + p * src["pstride"] + i]
+        if strict:
+            assert not np.any(np.isnan(tot)), "a reduce workgroup precedes a producer of its message"
+        assert np.all(np.isnan(self.msg[dst["off"] + i])), "a summed entry is written twice"
+        self.msg[dst["off"] + i] = tot
+
     def _block(self, tk, chunk, collect, record=None, strict=False):
+        if tk["kind"] == 1:
+            return self._reduce_block(tk, chunk, record, strict)
         VEC, EB = self.VEC, self.EB
         n_in, n_out = tk["n_in"], tk["n_out"]
         ins, outs = tk["in"], tk["out"]
@@ -209,6 +229,7 @@ class Emulator:
             assert all(L["phase"] == seg["phase"] for L in launches)
             assert seg["blk_off"] == launches[0]["blk_off"] and seg["nblocks"] == sum(L["nblocks"] for L in launches)
             assert seg["lds_bytes"] == max(L["lds_bytes"] for L in launches)
+            assert all(d["tasks"][t]["kind"] == (1 if L["variant"] == 16 else 0) for L in launches for t in L["tasks"])
             covered += list(range(seg["first_launch"], seg["first_launch"] + seg["n_launch"]))
             for blk in d["blocks"][seg["blk_off"]:seg["blk_off"] + seg["nblocks"]]:
                 self._block(d["tasks"][blk[0]], blk[1], seg["phase"] == 0, blk[2:], strict=True)
@@ -232,7 +253,7 @@ class Emulator:
                 tk = d["tasks"][t]
                 assert t in launch["tasks"]
                 assert launch["variant"] in (tk["variant"], 12 + launch["phase"])      # per level or per shape
-                assert (tk["variant"] < 4) == (launch["phase"] == 0)
+                assert tk["kind"] == 1 or (tk["variant"] < 4) == (launch["phase"] == 0)
                 assert tk["lds_bytes"] <= launch["lds_bytes"]
                 seen.add((t, chunk))
                 self._block(tk, chunk, launch["phase"] == 0, blk[2:])

@@ -167,6 +167,29 @@ def test_planner_options_do_not_change_results(opts):
             close(o, w, rtol=RTOL32, what="spec %d f32 %r" % (i, opts))
 
 
+@pytest.mark.parametrize("level_launches", [False, True])
+def test_reduce_tasks_on_device(monkeypatch, level_launches):
+    """Reduce tasks (sum of a message's partial copies, formed once behind the producer) in dataflow
+    and in per-level launches; a low threshold makes small trees use them."""
+    monkeypatch.setenv("JTP_REDUCE_MIN", "2")
+    for spec in (synthetic.wide_binary_tree(n_cliques=15, width=14, sep=7, card=2, seed=2),
+                 synthetic.random_tree(n_cliques=9, width=13, sep=5, card=2, seed=3),
+                 synthetic.chain_tree(n_cliques=6, card=16, width=3)):
+        pots = synthetic.potentials_for(spec, seed=5)
+        want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", block_log2=10,
+                           level_launches=level_launches)
+        assert sum(t["kind"] for t in plan.describe()["tasks"]) > 0
+        for c in range(spec["n_cliques"]):
+            plan.set_potential(c, pots[c])
+        for _ in range(3):
+            plan.propagate()
+        for node in range(len(spec["node_vars"])):
+            close(plan.belief(node), want[node], what="node %d" % node)
+        assert abs(plan.z() - z) <= 1e-11 * abs(z)
+        plan.close()
+
+
 def test_mid_size_wide_tree_vs_oracle():
     spec = synthetic.wide_binary_tree(n_cliques=31, width=16, sep=8, card=2, seed=0)
     pots = synthetic.potentials_for(spec, seed=2, dtype=np.float32)

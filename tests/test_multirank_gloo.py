@@ -102,9 +102,13 @@ def _worker(rank, world, port, recipe, kwargs, queue):
 @pytest.mark.parametrize("recipe,kwargs", [
     ("wide_binary_tree", {"n_cliques": 15, "width": 12, "sep": 6, "card": 2, "seed": 1}),
     ("random_tree", {"n_cliques": 14, "width": 11, "sep": 5, "card": 2, "seed": 3}),
+    ("wide_binary_tree", {"n_cliques": 15, "width": 13, "sep": 6, "card": 2, "seed": 4, "reduce_min": "2"}),
 ])
-def test_two_rank_exchange_schedule(recipe, kwargs):
+def test_two_rank_exchange_schedule(recipe, kwargs, monkeypatch):
     import multiprocessing as mp
+    kwargs = dict(kwargs)
+    if "reduce_min" in kwargs:          # reduce tasks at the cuts: the summed message is what travels
+        monkeypatch.setenv("JTP_REDUCE_MIN", kwargs.pop("reduce_min"))
     ctx = mp.get_context("spawn")
     queue = ctx.Queue()
     port = _free_port()

@@ -93,6 +93,29 @@ def test_synthetic_trees(opts):
         assert desc["n_messages"] == 2 * (spec["n_cliques"] - 1)
 
 
+@pytest.mark.parametrize("red_min", ["2", "4", "0"])
+def test_reduce_tasks_sum_partial_copies(monkeypatch, red_min):
+    """Messages written as >= JTP_REDUCE_MIN partial copies get a reduce task behind their producer
+    and consumers read the sum (the default threshold of 8 only triggers on large cliques)."""
+    monkeypatch.setenv("JTP_REDUCE_MIN", red_min)
+    specs = [
+        synthetic.wide_binary_tree(n_cliques=7, width=14, sep=7, card=2, seed=2),
+        synthetic.random_tree(n_cliques=9, width=13, sep=5, card=2, seed=3),
+        synthetic.chain_tree(n_cliques=4, card=16, width=3),
+    ]
+    n_red = 0
+    for spec in specs:
+        pots = synthetic.potentials_for(spec, seed=5)
+        desc = check(spec["tree"], pots, spec["node_vars"], spec["sizes"], block_log2=10)
+        n_red += sum(t["kind"] for t in desc["tasks"])
+        for s in desc["pseps"]:
+            for d in ("up", "dn"):
+                reduced = s[d + "_red_task"] >= 0
+                assert reduced == (red_min != "0" and s[d + "_npart"] >= int(red_min))
+                assert s[d + "_rnpart"] == (1 if reduced else s[d + "_npart"])
+    assert (n_red > 0) == (red_min != "0")
+
+
 def star(n_children, card=2, seed=0):
     rng = np.random.default_rng(seed)
     hub = list(range(6))

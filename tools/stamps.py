@@ -3,8 +3,12 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
 from junctiontree_amd import _capi, engine, synthetic
-spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
-plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
+if len(sys.argv) > 1 and sys.argv[1] == "c2":
+    spec = synthetic.chain_tree(n_cliques=int(sys.argv[2]) if len(sys.argv) > 2 else 64, card=64, width=3)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64")
+else:
+    spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
 plan.fill_synthetic(1, spec["scales"])
 for _ in range(3):
     plan.propagate()
