@@ -156,6 +156,7 @@ struct jtp_plan {
     bool flow = true;               // dataflow launches (one per phase) instead of one per level
     uint32_t *host_abort = nullptr; // pinned: set by a workgroup that gave up waiting
     int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
+    bool fake_comm = false;         // JTP_FAKE_COMM
     int esize = 4;
 };
 
@@ -239,7 +240,10 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         *out = pl;
         return JTP_OK;
     }
-    if (hp.n_ranks > 1 && (!rccl::comm || rccl::comm_size != hp.n_ranks || rccl::comm_rank != hp.rank)) {
+    // JTP_FAKE_COMM=1 (development aid): run ONE rank's share of a multi-rank plan on its own; what
+    // it would receive is filled with ones, what it would send goes nowhere.  Timing only.
+    pl->fake_comm = hp.n_ranks > 1 && getenv("JTP_FAKE_COMM") && atoi(getenv("JTP_FAKE_COMM")) != 0;
+    if (hp.n_ranks > 1 && !pl->fake_comm && (!rccl::comm || rccl::comm_size != hp.n_ranks || rccl::comm_rank != hp.rank)) {
         delete pl;
         return set_err(JTP_ECOMM, "n_ranks=%d but jtp_comm_init was not called with a matching communicator", hp.n_ranks);
     }
@@ -584,6 +588,13 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 fl.blk_base = (uint32_t)L.blk_off;
                 launch_variant(pl, L.variant, L.nblocks, L.lds_bytes, s, pl->d_tasks, pl->d_blocks + L.blk_off, pl->d_itab, bb.psi, bb.bel, bb.msg, fl);
                 if (per_launch) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first + 1], s));
+            } else if (pl->fake_comm) {
+                for (int i = st.first; i < st.first + st.count; ++i) {
+                    const CommOp &op = hp.comm[i];
+                    if (op.send) continue;
+                    const int grid = (int)std::min<int64_t>((op.count + 255) / 256, 1024);
+                    hipLaunchKernelGGL(jt_fill_value, dim3(grid), dim3(256), 0, s, bb.msg + fl.cur_off + op.off, op.count, 1.0);
+                }
             } else {
                 NCCL_TRY(rccl::GroupStart());
                 for (int i = st.first; i < st.first + st.count; ++i) {

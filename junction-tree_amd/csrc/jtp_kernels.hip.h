@@ -151,7 +151,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     double *scratch = reinterpret_cast<double *>(smem + tk.itab_lds - JT_STAGE_SCRATCH * NIN);
     const double *msg_cur = msg_arena + fl.cur_off;
     uint64_t wait_t0 = 0;
+    int n_attempts = 0;
     for (int attempt = 0;; ++attempt) {
+        n_attempts = attempt + 1;
         const double *unready = nullptr;          // (FLOW) an entry this thread found not written yet
         {
             const double *src[NIN > 0 ? NIN : 1];
@@ -266,9 +268,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 unsigned spins = 0;
                 const uint64_t limit = (fl.dbg & 8) ? 2000000ull : 200000000ull;
                 while (jt_unwritten(jt_msg_load<true>(entry)) || (fl.dbg & 8)) {
-                    if (spins < 2) __builtin_amdgcn_s_sleep(8);            // ~0.25 us, 0.5 us, then 1 us per poll
-                    else if (spins < 6) __builtin_amdgcn_s_sleep(16);
-                    else __builtin_amdgcn_s_sleep(32);
+                    // one load in flight per workgroup is no traffic to speak of: poll back to back while the
+                    // wait is young (a short wait is a producer about to finish), then every ~0.5 us, ~1 us
+                    if (spins >= 64) __builtin_amdgcn_s_sleep(32);
+                    else if (spins >= 16) __builtin_amdgcn_s_sleep(16);
                     if ((++spins & 15u) == 0) {
                         if (__hip_atomic_load(fl.sync + JT_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = 1;
                         else if (__builtin_amdgcn_s_memrealtime() - wait_t0 > limit) {
@@ -554,6 +557,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         if (tid == 0) {
             double *o = msg_arena + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * 8;
             for (int i = 0; i < 6; ++i) o[i] = (double)stamp[i];
+            o[6] = (double)n_attempts;
         }
     }
 }
@@ -795,6 +799,11 @@ __global__ __launch_bounds__(256) void jt_fill_ones(T *__restrict__ arena, int64
     const int64_t lim = (int64_t)1 << real_bits;
     for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x)
         arena[off + x] = (T)(x < lim ? 1.0 : 0.0);
+}
+
+// JTP_FAKE_COMM: stand-in for a received message
+__global__ __launch_bounds__(256) void jt_fill_value(double *__restrict__ dst, int64_t n, double v) {
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) dst[x] = v;
 }
 
 // clique potential = product of factor tables, written in the clique's device layout

@@ -609,6 +609,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         static const double target = getenv("JTP_TARGET_BLOCKS") ? atof(getenv("JTP_TARGET_BLOCKS")) : 2048.0;
         static const int lgmin = getenv("JTP_MIN_BLOCK_LOG2") ? atoi(getenv("JTP_MIN_BLOCK_LOG2")) : 13;
         static const int lgmax = getenv("JTP_MAX_BLOCK_LOG2") ? atoi(getenv("JTP_MAX_BLOCK_LOG2")) : 16;
+        // levels of a clique or two are latency bound: 4 iterations per workgroup, so that every element
+        // load is already in flight while the workgroup waits for its messages
+        static const double tiny = getenv("JTP_TINY_LEVEL_ELEMS") ? atof(getenv("JTP_TINY_LEVEL_ELEMS")) : 2097152.0;
+        if (lvl_elems[phase][level] <= tiny) return hp.TB + JT_MIN_ITER_LOG2;
         double want = lvl_elems[phase][level] / target;
         int lg = lgmin;
         while (lg < lgmax && (double)(1 << (lg + 1)) <= want) ++lg;

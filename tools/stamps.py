@@ -17,12 +17,17 @@ base, nb = d["dbg_base"], d["n_blocks"]
 buf = np.empty(nb * 8)
 _capi.check(plan._lib.jtp_debug_read_msg(plan._handle, 0, base, nb * 8, buf.ctypes.data_as(C.POINTER(C.c_double))))
 st = buf.reshape(nb, 8)[:, :6] * 0.01      # 100 MHz ticks -> microseconds
+attempts = buf.reshape(nb, 8)[:, 6]
 phase_t0 = {}
 for L in d["launches"]:
+    if L["variant"] == 16:          # reduce tasks carry no time stamps
+        continue
     s = st[L["blk_off"]:L["blk_off"] + L["nblocks"]]
     phase_t0.setdefault(L["phase"], s[:, 0].min())
     print("   [since phase start: first block in %.1f us, last block in %.1f, last block out %.1f]" % (
         s[:, 0].min() - phase_t0[L["phase"]], s[:, 0].max() - phase_t0[L["phase"]], s[:, 5].max() - phase_t0[L["phase"]]))
+    att = attempts[L["blk_off"]:L["blk_off"] + L["nblocks"]]
+    print("   [staging attempts: mean %.2f max %d]" % (att.mean(), att.max()))
     t0 = s[:, 0].min()
     rel = s - t0
     names = ["entry", "loads issued", "staged", "consts", "loop done", "flushed"]
