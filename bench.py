@@ -13,10 +13,9 @@ send/recv at the cuts; total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0.  `value` = algorithmic clique-potential GB/s of the whole
 job (SURVEY.md 8d definition of algorithmic bytes), `messages_per_sec` beside it.
-`roofline` is for the dominant kernel (jt_distribute_level: one launch per tree level), timed
-with hipEvents on the plan's own stream during the timed steps: one event before its first and
-one after its last launch of every propagate (its launches run back to back; the gaps between
-them are included, so the figure is conservative).  `cpu_baseline` times the numpy restatement of the
+`roofline` is for the dominant kernel (jt_distribute_flow: the whole distribute phase in one
+launch), timed with hipEvents on the plan's own stream during the timed steps: one event before
+and one after the launch in every propagate.  `cpu_baseline` times the numpy restatement of the
 reference's einsum sequence (oracle/jt_oracle.py: beliefs_refshaped) on one host core over a
 bounded sample of the same workload; it is a checker/baseline, never the measured path.
 
