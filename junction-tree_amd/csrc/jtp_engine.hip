@@ -235,7 +235,12 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     HostPlan &hp = pl->hp;
     pl->esize = hp.dtype == JTP_F32 ? 4 : 8;
     // one launch per level when asked for, for per-shape launches and for the JTP_DEBUG experiments
-    pl->flow = !(hp.flags & (JTP_LEVEL_LAUNCHES | JTP_SPLIT_VARIANTS)) && !(getenv("JTP_DEBUG") && (atoi(getenv("JTP_DEBUG")) & 1));
+    pl->flow = !(hp.flags & (JTP_LEVEL_LAUNCHES | JTP_SPLIT_VARIANTS)) && !(getenv("JTP_DEBUG") && (atoi(getenv("JTP_DEBUG")) & 1)) &&
+               !(getenv("JTP_FORCE_LEVEL_LAUNCHES") && atoi(getenv("JTP_FORCE_LEVEL_LAUNCHES")));
+    // Sub-boxes so large that one or two workgroups fill a CU (config 3: 121 KB): a waiting workgroup
+    // then idles a whole CU, and staging is a large share of the traffic, which per-level launches read
+    // through L2 while a dataflow launch has to read through to memory.  Measured 39.6 vs 46.9 ms.
+    if (hp.max_lds > 64 * 1024 && !(getenv("JTP_FORCE_FLOW") && atoi(getenv("JTP_FORCE_FLOW")))) pl->flow = false;
     if (hp.flags & JTP_PLAN_ONLY) {
         *out = pl;
         return JTP_OK;

@@ -48,6 +48,9 @@ struct JtMsg {
     int32_t red_lane;          // outgoing: lane bits NOT in the message (summed by shuffles)
     int32_t red_wave;          // outgoing: wave bits NOT in the message (summed through LDS)
     int32_t e_dep;             // incoming: 1 if the message depends on any e bit
+    int32_t same_launch;       // incoming: 1 if a dataflow launch may run its producer concurrently (then entries
+                               // are read through to memory and checked for the unwritten marker)
+    int32_t pad1;
     int32_t f_w[JT_MAX_HI];    // weight of F bit j in the message's global index
     int32_t f_p[JT_MAX_HI];    // outgoing: weight of F bit j in the partial-copy number
     uint8_t free_pos[16];      // global-index bit of each sub-box index bit

@@ -79,6 +79,13 @@ __device__ __forceinline__ double jt_msg_load(const double *p) {
         return *p;
 }
 
+// (FLOW) through to memory only where the producer may be running in this launch (JtMsg::same_launch)
+template <bool FLOW>
+__device__ __forceinline__ double jt_msg_load(const double *p, bool through) {
+    if constexpr (FLOW) return through ? jt_msg_load<true>(p) : *p;
+    else return *p;
+}
+
 template <bool FLOW>
 __device__ __forceinline__ void jt_msg_store(double *p, double v) {
     if constexpr (FLOW)
@@ -159,7 +166,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             const double *src[NIN > 0 ? NIN : 1];
             int idx_t[NIN > 0 ? NIN : 1], gp0[NIN > 0 ? NIN : 1], gp1[NIN > 0 ? NIN : 1];
             int64_t ps[NIN > 0 ? NIN : 1];
-            bool grouped[NIN > 0 ? NIN : 1];
+            bool grouped[NIN > 0 ? NIN : 1], thr_mem[NIN > 0 ? NIN : 1];
             double psum[NIN > 0 ? NIN : 1];
             int maxper = 0;
 #pragma unroll
@@ -174,6 +181,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 #pragma unroll
                 for (int b = 0; b < 8; ++b)
                     if (b < nfree) idx_t[k] += ((tid >> b) & 1) << JT_FPOS(fp, b);
+                thr_mem[k] = m.same_launch != 0;
                 grouped[k] = nfree < 8 && m.npart > 1;
                 psum[k] = 0.0;
                 gp0[k] = gp1[k] = 0;
@@ -196,7 +204,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                         for (int p = 0; p < m.npart; p += 8) {
                             double c[8];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) c[u] = (p + u < m.npart) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(p + u) * ps[k] + idx)) : 0.0;
+                            for (int u = 0; u < 8; ++u) c[u] = (p + u < m.npart) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(p + u) * ps[k] + idx), thr_mem[k]) : 0.0;
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 sum += c[u];
@@ -215,7 +223,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 for (int k = 0; k < NIN; ++k)
 #pragma unroll
                     for (int u = 0; u < GC; ++u)
-                        c[k][u] = (grouped[k] && gp0[k] + p + u < gp1[k]) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k])) : 0.0;
+                        c[k][u] = (grouped[k] && gp0[k] + p + u < gp1[k]) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]), thr_mem[k]) : 0.0;
 #pragma unroll
                 for (int k = 0; k < NIN; ++k)
 #pragma unroll

@@ -105,7 +105,8 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
         int best = -1;
         long best_lds = 0;
         int best_part = 0;
-        for (int b = TB; b < nbits && nbits - popc(F) > TB + JT_MIN_ITER_LOG2; ++b) {
+        for (int b = TB; b < nbits && nbits - popc(F) > TB + 3; ++b) {      // (fitting LDS never goes below 8 iterations:
+                                                                              //  staging a big sub-box for 4 would cost more than it saves)
             if (F >> b & 1) continue;
             long l = lds_of(F | 1u << b);
             int pl = part_log2(F | 1u << b);
@@ -700,6 +701,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             rt.msg[0].off = up ? s.up_off : s.dn_off;
             rt.msg[0].npart = npart;
             rt.msg[0].pstride = (int32_t)n;
+            rt.msg[0].same_launch = 1;
             rt.msg[JT_MAX_IN].off = up ? s.up_roff : s.dn_roff;
             rt.msg[JT_MAX_IN].npart = 1;
             rt.msg[JT_MAX_IN].pstride = (int32_t)n;
@@ -720,15 +722,20 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         const PNode &p = hp.pn[tk.pnode];
         bool collect = (int)t == p.collect_task;
         int k = 0;
+        // same_launch: the producer runs in the same dataflow launch as this consumer (same phase, same
+        // rank).  Upward messages read during distribute were finished by the collect launch, messages
+        // of other ranks arrive by an exchange between launches: those are read with ordinary loads.
         if (!collect && p.psep >= 0) {
             tk.msg[k].off = hp.ps[p.psep].dn_roff;
             tk.msg[k].npart = hp.ps[p.psep].dn_rnpart;
+            tk.msg[k].same_launch = hp.pn[p.parent].owner == p.owner;
             ++k;
         }
         for (int ch : p.children) {
             const PSep &s = hp.ps[hp.pn[ch].psep];
             tk.msg[k].off = s.up_roff;
             tk.msg[k].npart = s.up_rnpart;
+            tk.msg[k].same_launch = collect && hp.pn[ch].owner == p.owner;
             ++k;
         }
         if (collect) tk.msg[JT_MAX_IN].off = hp.ps[p.psep].up_off;
@@ -793,6 +800,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
                 }
                 L.lds_bytes = std::max(L.lds_bytes, tk.lds_bytes);
                 L.alg_bytes += task_bytes[t];
+                for (int k = 0; k < tk.n_in; ++k) hp.staging_bytes += (double)(1u << tk.nF) * (8.0 * (1 << tk.msg[k].nfree)) * tk.msg[k].npart;
+                hp.table_bytes += (double)((int64_t)1 << tk.nbits) * esize * (phase == 1 ? 2 : 1);
             }
             L.nblocks = (int)(hp.blocks.size() - L.blk_off);
             hp.max_lds = std::max(hp.max_lds, L.lds_bytes);
@@ -965,7 +974,7 @@ void json_msg(std::ostringstream &o, const JtMsg &m, int nF) {
     o << ",\"t_w\":";
     json_list(o, m.t_w, m.t_w + 8);
     o << ",\"red_e\":" << m.red_e << ",\"red_lane\":" << m.red_lane << ",\"red_wave\":" << m.red_wave
-      << ",\"e_dep\":" << m.e_dep << ",\"f_w\":";
+      << ",\"e_dep\":" << m.e_dep << ",\"same_launch\":" << m.same_launch << ",\"f_w\":";
     json_list(o, m.f_w, m.f_w + nF);
     o << ",\"f_p\":";
     json_list(o, m.f_p, m.f_p + nF);
@@ -981,6 +990,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
       << ",\"n_cliques\":" << hp.n_cliques << ",\"n_ranks\":" << hp.n_ranks << ",\"rank\":" << hp.rank
       << ",\"root\":" << hp.root << ",\"arena_elems\":" << hp.arena_elems << ",\"msg_doubles\":" << hp.msg_doubles
       << ",\"dbg_base\":" << hp.dbg_base << ",\"max_lds\":" << hp.max_lds << ",\"alg_bytes\":" << (long long)hp.alg_bytes
+      << ",\"staging_bytes\":" << (long long)hp.staging_bytes << ",\"table_bytes\":" << (long long)hp.table_bytes
       << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
       << ",\"n_blocks\":" << hp.blocks.size();
     o << ",\"pnodes\":[";

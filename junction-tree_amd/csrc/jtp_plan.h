@@ -109,6 +109,8 @@ struct HostPlan {
     int64_t dbg_base = -1;           // JTP_DEBUG & 2: time-stamp region inside the message arena
     int max_lds = 0;
     double alg_bytes = 0;
+    double staging_bytes = 0;        // message bytes all workgroups load while staging (partial copies included)
+    double table_bytes = 0;          // clique-table bytes all workgroups stream (reads + belief writes)
     int n_messages = 0;
     std::string json;
 };

@@ -125,6 +125,11 @@ class Emulator:
                 tot = tot + self.msg[m["off"] + p * m["pstride"] + gb_in[k] + idx]
             if strict:      # dataflow order: every entry read was written by an earlier workgroup
                 assert not np.any(np.isnan(tot)), "a workgroup precedes the producer of an entry it reads"
+                if not m["same_launch"]:        # read with ordinary loads: must be complete before the launch
+                    snap = np.zeros(len(s))
+                    for p in range(m["npart"]):
+                        snap = snap + self._launch_snapshot[m["off"] + p * m["pstride"] + gb_in[k] + idx]
+                    assert not np.any(np.isnan(snap)), "an ordinary load of a message the same launch produces"
             subs.append(tot)
         osubs = [np.zeros(1 << m["nfree"]) for m in outs]
 
@@ -231,6 +236,7 @@ class Emulator:
             assert seg["lds_bytes"] == max(L["lds_bytes"] for L in launches)
             assert all(d["tasks"][t]["kind"] == (1 if L["variant"] == 16 else 0) for L in launches for t in L["tasks"])
             covered += list(range(seg["first_launch"], seg["first_launch"] + seg["n_launch"]))
+            self._launch_snapshot = self.msg.copy()
             for blk in d["blocks"][seg["blk_off"]:seg["blk_off"] + seg["nblocks"]]:
                 self._block(d["tasks"][blk[0]], blk[1], seg["phase"] == 0, blk[2:], strict=True)
         assert covered == list(range(len(d["launches"])))

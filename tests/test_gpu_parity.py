@@ -438,6 +438,25 @@ def test_repeated_propagates_with_new_potentials_and_mixed_launch_modes():
         plan.close()
 
 
+def test_launch_modes_are_bit_identical():
+    """One launch per phase (dataflow), one per level, and ticket-ordered dataflow run the same
+    workgroups on the same tables: every belief must agree to the last bit."""
+    spec = synthetic.wide_binary_tree(n_cliques=31, width=15, sep=7, card=2, seed=9)
+    pots = synthetic.potentials_for(spec, seed=77, dtype=np.float32)
+    results = []
+    for opts in ({}, {"level_launches": True}, {"flow_tickets": True}):
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", block_log2=11, **opts)
+        for c in range(spec["n_cliques"]):
+            plan.set_potential(c, pots[c])
+        plan.propagate()
+        plan.propagate()
+        results.append([plan.belief(node) for node in range(len(spec["node_vars"]))])
+        plan.close()
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert np.array_equal(a, b)
+
+
 def test_dataflow_timeout_falls_back_to_level_launches(monkeypatch):
     """Fault injection: every dataflow wait times out (JTP_FLOW_DEBUG=8).  The host must notice at the
     next synchronisation, run the propagate again with one launch per level, and keep doing so."""
