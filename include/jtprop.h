@@ -156,6 +156,16 @@ int jtp_get_belief(jtp_plan *plan, int32_t batch, int32_t node, void *host, int3
 int jtp_get_marginal(jtp_plan *plan, int32_t batch, int32_t clique, const int32_t *out_vars,
                      int32_t n_out, double *host);
 
+/* Many marginals in one go: all of CliqueGraph.marginalize (junctiontree.py:229-274, one
+ * einsum per factor) as ONE kernel launch over every requested clique, one conversion launch
+ * and one device-to-host copy.  Request i asks clique `cliques[i]` for the variables
+ * var_ids[var_off[i] .. var_off[i+1]) (that axis order) and receives them at host + out_off[i]
+ * (doubles, C order).  The device tables of a request list are kept with the plan, so asking for
+ * the same list again (every propagate of one model does) costs no planning. */
+int jtp_get_marginals(jtp_plan *plan, int32_t batch, int32_t n, const int32_t *cliques,
+                      const int32_t *var_off, const int32_t *var_ids, const int64_t *out_off,
+                      double *host);
+
 /* Z = sum of the root belief (the value the reference computes and drops,
  * computation.py:90-96). */
 int jtp_get_z(jtp_plan *plan, int32_t batch, double *z);

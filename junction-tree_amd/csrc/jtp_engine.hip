@@ -139,6 +139,27 @@ struct BatchBuffers {
     int64_t cur_off(int64_t half) const { return (epoch & 1u) ? half : 0; }     // half in use by the last propagate
 };
 
+// device tables of one list of marginal requests (jtp_get_marginals), kept for the next call
+struct MargBatch {
+    std::vector<int32_t> key;            // n, cliques, var_off, var_ids
+    JtTask *d_tasks = nullptr;
+    JtBlock *d_blocks = nullptr;
+    int *d_itab = nullptr;
+    JtMargDesc *d_descs = nullptr;
+    double *scratch = nullptr, *stage = nullptr;
+    int n = 0, nblocks = 0, lds = 0, max_grid_x = 1;
+    int64_t total_out = 0;
+    std::vector<int64_t> elems;          // host entries of each request
+    void release() {
+        if (d_tasks) (void)hipFree(d_tasks);
+        if (d_blocks) (void)hipFree(d_blocks);
+        if (d_itab) (void)hipFree(d_itab);
+        if (d_descs) (void)hipFree(d_descs);
+        if (scratch) (void)hipFree(scratch);
+        if (stage) (void)hipFree(stage);
+    }
+};
+
 struct jtp_plan {
     HostPlan hp;
     bool device = false;
@@ -157,6 +178,7 @@ struct jtp_plan {
     uint32_t *host_abort = nullptr; // pinned: set by a workgroup that gave up waiting
     int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
     bool fake_comm = false;         // JTP_FAKE_COMM
+    std::vector<MargBatch *> marg_cache;
     int esize = 4;
 };
 
@@ -212,6 +234,10 @@ void jtp_plan_destroy(jtp_plan *pl) {
             if (b.sync) (void)hipFree(b.sync);
         }
         if (pl->host_abort) (void)hipHostFree(pl->host_abort);
+        for (MargBatch *mb : pl->marg_cache) {
+            mb->release();
+            delete mb;
+        }
         if (pl->d_tasks) (void)hipFree(pl->d_tasks);
         if (pl->d_blocks) (void)hipFree(pl->d_blocks);
         if (pl->d_itab) (void)hipFree(pl->d_itab);
@@ -773,6 +799,154 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
     (void)hipFree(d_blk);
     (void)hipFree(d_tab);
     return rc != JTP_OK ? rc : check_flow(pl);
+}
+
+int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cliques, const int32_t *var_off,
+                      const int32_t *var_ids, const int64_t *out_off, double *host) {
+    int rc = check_ready(pl, batch);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!cliques || !var_off || !out_off || !host))) return set_err(JTP_EINVAL, "null argument");
+    if (n == 0) return JTP_OK;
+    if (n > 65535) {                                        // grid.y of the read-out launch
+        for (int32_t i = 0; i < n; i += 65535) {
+            rc = jtp_get_marginals(pl, batch, std::min(65535, n - i), cliques + i, var_off + i, var_ids, out_off + i, host);
+            if (rc) return rc;
+        }
+        return JTP_OK;
+    }
+    HostPlan &hp = pl->hp;
+    HIP_TRY(hipSetDevice(hp.device));
+    hipStream_t s = pl->streams[batch % pl->streams.size()];
+    BatchBuffers &b = pl->bufs[batch];
+    std::vector<int32_t> key;
+    key.push_back(n);
+    key.insert(key.end(), cliques, cliques + n);
+    for (int i = 0; i <= n; ++i) key.push_back(var_off[i] - var_off[0]);
+    key.insert(key.end(), var_ids + var_off[0], var_ids + var_off[n]);
+    MargBatch *mb = nullptr;
+    for (MargBatch *c : pl->marg_cache)
+        if (c->key == key) mb = c;
+    if (!mb) {
+        std::vector<JtTask> tasks;
+        std::vector<JtBlock> blocks;
+        std::vector<int32_t> itab;
+        std::vector<JtMargDesc> descs;
+        std::vector<int64_t> elems;
+        int64_t scratch_doubles = 0, total_out = 0;
+        int lds = 0;
+        for (int i = 0; i < n; ++i) {
+            const int clique = cliques[i];
+            if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "request %d: node %d is not a clique", i, clique);
+            if (hp.pn[clique].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
+            const int n_out = var_off[i + 1] - var_off[i];
+            if (n_out < 0 || n_out > JT_MAX_VARS) return set_err(JTP_EINVAL, "request %d: bad variable count", i);
+            std::vector<int> ov(var_ids + var_off[i], var_ids + var_off[i + 1]);
+            for (int a = 0; a < n_out; ++a)
+                for (int c = 0; c < a; ++c)
+                    if (ov[a] == ov[c]) return set_err(JTP_EINVAL, "request %d: variable %d requested twice", i, ov[a]);
+            JtTask tk;
+            int out_bits = 0, npart = 1;
+            std::vector<JtBlock> blk;
+            std::vector<int32_t> tab;
+            std::string err;
+            rc = jtp_plan_marginal_task(hp, clique, ov, tk, tab, out_bits, npart, blk, err);
+            if (rc) return set_err(rc, "request %d: %s", i, err.c_str());
+            tk.itab_off = (int64_t)itab.size();
+            tk.msg[JT_MAX_IN].off = scratch_doubles;
+            itab.insert(itab.end(), tab.begin(), tab.end());
+            for (JtBlock &bk : blk) {
+                bk.task = (uint32_t)i;
+                blocks.push_back(bk);
+            }
+            lds = std::max(lds, tk.lds_bytes);
+            JtMargDesc md;
+            memset(&md, 0, sizeof md);
+            md.d.nvars = n_out;
+            md.d.nbits = out_bits;
+            int64_t stride = 1;
+            int bit = 0;
+            std::vector<int> pos(n_out);
+            for (int a = n_out - 1; a >= 0; --a) {          // last requested variable = lowest bits
+                pos[a] = bit;
+                bit += hp.vbits[ov[a]];
+            }
+            for (int a = n_out - 1; a >= 0; --a) {
+                md.d.pos[a] = (uint8_t)pos[a];
+                md.d.nb[a] = (uint8_t)hp.vbits[ov[a]];
+                md.d.card[a] = hp.card[ov[a]];
+                md.d.hstride[a] = stride;
+                stride *= hp.card[ov[a]];
+            }
+            md.d.host_elems = stride;
+            md.src_off = scratch_doubles;
+            md.pstride = (int64_t)1 << out_bits;
+            md.dst_off = total_out;
+            md.npart = npart;
+            descs.push_back(md);
+            elems.push_back(stride);
+            tasks.push_back(tk);
+            scratch_doubles += md.pstride * npart;
+            total_out += stride;
+        }
+        mb = new MargBatch();
+        mb->key = key;
+        mb->n = n;
+        mb->nblocks = (int)blocks.size();
+        mb->lds = lds;
+        mb->total_out = total_out;
+        mb->elems = elems;
+        int64_t biggest = 1;
+        for (int64_t e : elems) biggest = std::max(biggest, e);
+        mb->max_grid_x = (int)std::min<int64_t>((biggest + 255) / 256, 64);
+        hipError_t e = hipMalloc((void **)&mb->d_tasks, tasks.size() * sizeof(JtTask));
+        if (e == hipSuccess) e = hipMalloc((void **)&mb->d_blocks, blocks.size() * sizeof(JtBlock));
+        if (e == hipSuccess) e = hipMalloc((void **)&mb->d_itab, std::max<size_t>(itab.size(), 1) * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&mb->d_descs, descs.size() * sizeof(JtMargDesc));
+        if (e == hipSuccess) e = hipMalloc((void **)&mb->scratch, (size_t)std::max<int64_t>(scratch_doubles, 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&mb->stage, (size_t)std::max<int64_t>(total_out, 1) * 8);
+        if (e == hipSuccess) e = hipMemcpy(mb->d_tasks, tasks.data(), tasks.size() * sizeof(JtTask), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(mb->d_blocks, blocks.data(), blocks.size() * sizeof(JtBlock), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !itab.empty()) e = hipMemcpy(mb->d_itab, itab.data(), itab.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(mb->d_descs, descs.data(), descs.size() * sizeof(JtMargDesc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            mb->release();
+            delete mb;
+            return set_err(e == hipErrorOutOfMemory ? JTP_ENOMEM : JTP_EHIP, "marginal tables: %s", hipGetErrorString(e));
+        }
+        if (pl->marg_cache.size() >= 4) {                   // a model asks for one or two lists; keep the last few
+            pl->marg_cache.front()->release();
+            delete pl->marg_cache.front();
+            pl->marg_cache.erase(pl->marg_cache.begin());
+        }
+        pl->marg_cache.push_back(mb);
+        if (lds > 64 * 1024) {
+            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_COLLECT0) : (const void *)KernelTable<double>::get(JT_K_COLLECT0);
+            HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, hp.max_lds)));
+        }
+    }
+    // marginalise the BELIEF tables: each is the "potential" argument of a childless collect
+    JtFlow plain;
+    memset(&plain, 0, sizeof plain);
+    plain.oth_off = -1;
+    launch_variant(pl, JT_K_COLLECT0, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.bel, b.bel, mb->scratch, plain);
+    hipLaunchKernelGGL(jt_marg_unpack, dim3(mb->max_grid_x, mb->n), dim3(256), 0, s, mb->d_descs, mb->scratch, mb->stage);
+    HIP_TRY(hipGetLastError());
+    bool packed = true;
+    for (int i = 0; i < n; ++i) packed = packed && out_off[i + 1] - out_off[i] == mb->elems[i];
+    if (packed) {
+        HIP_TRY(hipMemcpyAsync(host + out_off[0], mb->stage, (size_t)mb->total_out * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        std::vector<double> tmp((size_t)mb->total_out);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), mb->stage, (size_t)mb->total_out * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        int64_t at = 0;
+        for (int i = 0; i < n; ++i) {
+            memcpy(host + out_off[i], tmp.data() + at, (size_t)mb->elems[i] * 8);
+            at += mb->elems[i];
+        }
+    }
+    return check_flow(pl);
 }
 
 int jtp_get_z(jtp_plan *pl, int32_t batch, double *z) {

@@ -115,6 +115,16 @@ struct JtPackDesc {
     int64_t hstride[JT_MAX_VARS]; // host C-order stride in elements (0: broadcast axis)
 };
 
+// one request of a batched marginal read-out (jt_marg_unpack): partial copies -> host order
+struct JtMargDesc {
+    JtPackDesc d;              // layout of the requested variables (dev_off unused)
+    int64_t src_off;           // scratch offset (doubles) of partial copy 0
+    int64_t pstride;           // doubles between partial copies
+    int64_t dst_off;           // offset (doubles) in the staging buffer
+    int32_t npart;
+    int32_t pad;
+};
+
 // clique potential = product of factor tables (jt_eval_product)
 #define JT_EVAL_MAX_F 8
 struct JtEvalFactor {

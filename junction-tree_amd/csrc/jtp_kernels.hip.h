@@ -886,3 +886,15 @@ __global__ __launch_bounds__(256) void jt_msg_unpack(JtPackDesc d, const double 
         stage[h] = (S)u;
     }
 }
+
+// batched marginal read-out: request blockIdx.y, entries strided over blockIdx.x
+__global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restrict__ descs, const double *__restrict__ scratch,
+                                                      double *__restrict__ stage) {
+    const JtMargDesc &m = descs[blockIdx.y];
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < m.d.host_elems; h += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = jt_host_to_dev(m.d, h);
+        double u = 0.0;
+        for (int p = 0; p < m.npart; ++p) u += scratch[m.src_off + (int64_t)p * m.pstride + x];
+        stage[m.dst_off + h] = u;
+    }
+}

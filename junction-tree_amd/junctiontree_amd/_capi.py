@@ -91,6 +91,8 @@ SYMBOLS = {
     "jtp_get_belief": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "jtp_get_marginal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                    C.c_int32, C.POINTER(C.c_double)]),
+    "jtp_get_marginals": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "jtp_get_z": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "jtp_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "jtp_set_profiling_granularity": (C.c_int, [C.c_void_p, C.c_int32]),

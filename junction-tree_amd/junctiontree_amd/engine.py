@@ -217,6 +217,29 @@ class Plan:
                                                out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def marginals(self, requests, batch=0):
+        """`requests` = [(clique, labels), ...] -> list of float64 arrays: every marginal from one
+        kernel launch and one copy back (`jtp_get_marginals`)."""
+        n = len(requests)
+        if n == 0:
+            return []
+        cliques = _int_array([self.abi_of[c] for c, _ in requests])
+        var_off, var_ids, out_off, shapes = [0], [], [0], []
+        for _, labels in requests:
+            ids = [self.var_id[lab] for lab in labels]
+            var_ids += ids
+            var_off.append(len(var_ids))
+            shape = tuple(self.card[i] for i in ids)
+            shapes.append(shape)
+            out_off.append(out_off[-1] + int(np.prod(shape, dtype=np.int64)) if shape else out_off[-1] + 1)
+        flat = np.empty(out_off[-1], dtype=np.float64)
+        offs = (C.c_int64 * (n + 1))(*out_off)
+        _capi.check(self._lib.jtp_get_marginals(
+            self._handle, batch, n, C.cast(cliques, C.POINTER(C.c_int32)),
+            C.cast(_int_array(var_off), C.POINTER(C.c_int32)), C.cast(_int_array(var_ids), C.POINTER(C.c_int32)),
+            C.cast(offs, C.POINTER(C.c_int64)), flat.ctypes.data_as(C.POINTER(C.c_double))))
+        return [flat[out_off[i]:out_off[i + 1]].reshape(shapes[i]).copy() for i in range(n)]
+
     def z(self, batch=0):
         val = C.c_double(0.0)
         _capi.check(self._lib.jtp_get_z(self._handle, batch, C.byref(val)))

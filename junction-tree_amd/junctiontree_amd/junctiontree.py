@@ -153,5 +153,5 @@ class JunctionTree:
         for c, members in enumerate(ct._members()):
             plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
         plan.propagate()
-        return [plan.marginal(mc, list(fvars))
-                for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)]
+        # marginalize (junctiontree.py:229-274) on the device, all factors in one launch
+        return plan.marginals([(mc, list(fvars)) for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)])

@@ -438,6 +438,37 @@ def test_repeated_propagates_with_new_potentials_and_mixed_launch_modes():
         plan.close()
 
 
+def test_batched_marginals_match_single_requests():
+    """jtp_get_marginals (all of CliqueGraph.marginalize in one launch) against jtp_get_marginal and
+    the oracle: several requests per clique, permuted axis orders, the empty request (= Z), a repeated
+    call served from the plan's cache, and a second, different request list."""
+    spec = synthetic.random_tree(n_cliques=9, width=6, sep=3, card=3, seed=12)
+    pots = synthetic.potentials_for(spec, seed=3)
+    want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64")
+    for c in range(spec["n_cliques"]):
+        plan.set_potential(c, pots[c])
+    plan.propagate()
+    rng = np.random.default_rng(0)
+    requests = []
+    for c in range(spec["n_cliques"]):
+        labels = list(spec["node_vars"][c])
+        for k in (0, 1, 2, len(labels)):
+            requests.append((c, [labels[i] for i in rng.permutation(len(labels))[:k]]))
+    for reqs in (requests, requests, requests[::3]):
+        got = plan.marginals(reqs)
+        assert len(got) == len(reqs)
+        for (c, labels), g in zip(reqs, got):
+            single = plan.marginal(c, labels)
+            assert g.shape == single.shape and np.array_equal(g, single)
+            axes = [spec["node_vars"][c].index(lab) for lab in labels]
+            drop = tuple(a for a in range(len(spec["node_vars"][c])) if a not in axes)
+            ref = np.transpose(want[c].sum(axis=drop), np.argsort(np.argsort(axes))) if labels else want[c].sum()
+            close(g, ref, what="clique %d labels %r" % (c, labels))
+    assert abs(plan.marginals([(0, [])])[0] - z) <= 1e-11 * abs(z)
+    plan.close()
+
+
 def test_launch_modes_are_bit_identical():
     """One launch per phase (dataflow), one per level, and ticket-ordered dataflow run the same
     workgroups on the same tables: every belief must agree to the last bit."""

@@ -28,6 +28,14 @@ d = plan.describe()
 print("plan %.2f s: arena %.2f GiB, %d launches, %d blocks, max LDS %d" % (t2 - t1, d["arena_elems"] * 4 / 2**30, len(d["launches"]), d["n_blocks"], d["max_lds"]))
 t3 = time.perf_counter(); out = tree.propagate(values); t4 = time.perf_counter()
 print("propagate() end to end (H2D factors, device evaluate, collect+distribute, %d device marginals, D2H) %.2f s" % (len(factors), t4 - t3))
+ct = tree.clique_tree
+ta = time.perf_counter()
+for c, members in enumerate(ct._members()):
+    plan.set_potential_product(c, jt.take(values, members), jt.take(ct.factor_graph.factors, members))
+plan.sync(); tb = time.perf_counter()
+plan.propagate(); tc = time.perf_counter()
+plan.marginals([(mc, list(fvars)) for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)]); td = time.perf_counter()
+print("   of which: device evaluate of %d cliques %.3f s, collect+distribute %.3f s, %d marginals %.3f s" % (len(widths), tb - ta, tc - tb, len(factors), td - tc))
 plan.set_profiling(3)
 for _ in range(3): plan.propagate()
 st = plan.stats()
