@@ -179,6 +179,13 @@ struct jtp_plan {
     int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
     bool fake_comm = false;         // JTP_FAKE_COMM
     std::vector<MargBatch *> marg_cache;
+    // factor tables on their way to jt_eval_product: slices of one buffer handed out in turn, so that
+    // evaluating clique after clique needs no synchronisation until the buffer wraps
+    char *eval_stage = nullptr;          // device
+    char *eval_host = nullptr;           // pinned mirror: the caller's tables are copied here before the call returns
+    size_t eval_bytes = 0, eval_cursor = 0;
+    hipStream_t eval_stream = nullptr;   // stream whose kernels may still read the buffer
+    bool eval_pending = false;
     int esize = 4;
 };
 
@@ -242,6 +249,8 @@ void jtp_plan_destroy(jtp_plan *pl) {
         if (pl->d_blocks) (void)hipFree(pl->d_blocks);
         if (pl->d_itab) (void)hipFree(pl->d_itab);
         if (pl->stage) (void)hipFree(pl->stage);
+        if (pl->eval_stage) (void)hipFree(pl->eval_stage);
+        if (pl->eval_host) (void)hipHostFree(pl->eval_host);
         for (auto e : pl->ev) (void)hipEventDestroy(e);
         for (auto s : pl->streams) (void)hipStreamDestroy(s);
     }
@@ -436,12 +445,37 @@ int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32
         bytes += (size_t)((n * (ft.dtype == JTP_F32 ? 4 : 8) + 7) / 8) * 8;
     }
     HIP_TRY(hipSetDevice(hp.device));
-    rc = ensure_stage(pl, std::max<size_t>(bytes, 8));
-    if (rc) return rc;
     hipStream_t s = pl->streams[batch % pl->streams.size()];
     BatchBuffers &b = pl->bufs[batch];
+    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
+    if (pl->eval_pending && pl->eval_stream != s) {        // another evidence set's kernels may still read the buffer
+        HIP_TRY(hipStreamSynchronize(pl->eval_stream));
+        pl->eval_pending = false;
+        pl->eval_cursor = 0;
+    }
+    if (pl->eval_cursor + bytes > pl->eval_bytes) {
+        if (pl->eval_pending) HIP_TRY(hipStreamSynchronize(pl->eval_stream));
+        pl->eval_pending = false;
+        pl->eval_cursor = 0;
+        if (bytes > pl->eval_bytes) {
+            if (pl->eval_stage) HIP_TRY(hipFree(pl->eval_stage));
+            if (pl->eval_host) HIP_TRY(hipHostFree(pl->eval_host));
+            pl->eval_stage = pl->eval_host = nullptr;
+            pl->eval_bytes = 0;
+            const size_t want = std::max<size_t>(bytes, (size_t)8 << 20);
+            HIP_TRY(hipMalloc((void **)&pl->eval_stage, want));
+            HIP_TRY(hipHostMalloc((void **)&pl->eval_host, want, hipHostMallocDefault));
+            pl->eval_bytes = want;
+        }
+    }
+    char *stage = pl->eval_stage + pl->eval_cursor;
+    char *hstage = pl->eval_host + pl->eval_cursor;
+    pl->eval_cursor += bytes;
+    pl->eval_stream = s;
+    pl->eval_pending = true;
     for (int f = 0; f < n_factors; ++f)
-        HIP_TRY(hipMemcpyAsync((char *)pl->stage + offs[f] * 8, factors[f].host, (size_t)elems[f] * (factors[f].dtype == JTP_F32 ? 4 : 8), hipMemcpyHostToDevice, s));
+        memcpy(hstage + offs[f] * 8, factors[f].host, (size_t)elems[f] * (factors[f].dtype == JTP_F32 ? 4 : 8));
+    if (n_factors > 0) HIP_TRY(hipMemcpyAsync(stage, hstage, bytes, hipMemcpyHostToDevice, s));
     const int64_t n = (int64_t)1 << hp.pack[clique].nbits;
     const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
     int done = 0;
@@ -468,13 +502,12 @@ int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32
                 stride *= len;
             }
         }
-        if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_product<float>), dim3(grid), dim3(256), 0, s, d, (const char *)pl->stage, (float *)b.psi);
-        else hipLaunchKernelGGL((jt_eval_product<double>), dim3(grid), dim3(256), 0, s, d, (const char *)pl->stage, (double *)b.psi);
+        if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_product<float>), dim3(grid), dim3(256), 0, s, d, (const char *)stage, (float *)b.psi);
+        else hipLaunchKernelGGL((jt_eval_product<double>), dim3(grid), dim3(256), 0, s, d, (const char *)stage, (double *)b.psi);
         done += d.nf;
     } while (done < n_factors);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));      // the staging buffer is reused by the next call
-    return JTP_OK;
+    return JTP_OK;                        // (the caller's tables were copied to pinned memory above)
 }
 
 static uint64_t host_splitmix64(uint64_t x) {
@@ -651,6 +684,8 @@ int jtp_sync(jtp_plan *pl) {
     if (!pl->device) return JTP_OK;
     HIP_TRY(hipSetDevice(pl->hp.device));
     for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
+    pl->eval_pending = false;
+    pl->eval_cursor = 0;
     return check_flow(pl);
 }
 
