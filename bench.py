@@ -34,6 +34,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "junction-tree_amd"))
 
+Z_DEFAULT_C4 = 1.0058528272803358     # partition function of the default workload (one GPU; numpy oracle agrees to 1e-9)
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md "Chip-level parameters": 8.0 TB/s spec
 
 
@@ -47,14 +48,14 @@ def cpu_baseline(width, sep, card, n_sample, seed):
     pots = synthetic.potentials_for(spec, seed=1, dtype=np.float32)
     t0 = time.perf_counter()
     c0 = time.process_time()
-    oracle.beliefs_refshaped(spec["tree"], pots, spec["node_vars"])
+    beliefs = oracle.beliefs_refshaped(spec["tree"], pots, spec["node_vars"])
     wall = time.perf_counter() - t0
     cpu = time.process_time() - c0
     ab = synthetic.algorithmic_bytes(spec, 4)
     return {
         "value": ab["total"] / wall / 1e9, "unit": "GB/s",
         "messages_per_sec": ab["messages"] / wall,
-        "cores": 1, "kind": "port",
+        "cores": 1, "kind": "port", "Z": float(np.sum(beliefs[0], dtype=np.float64)),
         "sample": "%d-clique balanced binary tree, same clique shape (width %d, card %d, %d shared); "
                   "one propagate, %.1f s wall, cpu/wall %.2f" % (n_sample, width, card, sep, wall, cpu / max(wall, 1e-9)),
     }
@@ -157,6 +158,8 @@ def main():
 
     stats = plan.stats()
     z = plan.z() if plan.owns(plan.root) else None
+    if world > 1:                                    # the rank holding the root clique knows Z: share it
+        z = rdzv.allreduce_max(z if z is not None else -1.0e300)
     if args.per_launch and not args.no_profile and rank == 0:
         for L in plan.launch_ms():
             print("# %s level %d: %4d tasks %5d blocks %8.4f ms %7.0f GB/s" % (
@@ -211,8 +214,17 @@ def main():
                                   for kn, kv in stats["kernels"].items()},
                 "collect_ms": stats["collect_ms"], "distribute_ms": stats["distribute_ms"],
             }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.width, args.sep, args.card, args.cpu_sample, 0)
+            if args.cpu_sample == n and args.config == "c4" and z is not None:      # same tree, same values: same Z
+                zc = out["cpu_baseline"]["Z"]
+                out["parity"] = {"Z_gpu": z, "Z_cpu_oracle": zc, "rel_err": abs(z - zc) / abs(zc)}
+        default_c4 = (args.config == "c4" and args.cliques == 256 and args.width == 20 and args.sep == 10
+                      and args.card == 2 and args.dtype == "f32")
+        if default_c4 and z is not None:
+            # Z of the default workload as one GPU and the numpy oracle compute it: a sharded run must agree
+            out["config"]["Z_expected"] = Z_DEFAULT_C4
+            out["config"]["Z_rel_err"] = abs(z - Z_DEFAULT_C4) / Z_DEFAULT_C4
         print(json.dumps(out), flush=True)
 
     plan.close()

@@ -559,10 +559,13 @@ static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipSt
 // workgroups gave up waiting (it would take workgroups dispatched out of order, or a stuck device;
 // never observed) has left that propagate unfinished: mark the whole arena unwritten again, switch the
 // plan to one launch per level for good, and run the affected evidence sets again that way.
-static int check_flow(jtp_plan *pl) {
+// `synced`: the evidence set whose stream the caller has just synchronised (-1: all of them).
+static int check_flow(jtp_plan *pl, int synced = -1) {
     if (!pl->host_abort) return JTP_OK;
     if (*(volatile uint32_t *)pl->host_abort == 0) {
-        for (auto &b : pl->bufs) b.unchecked = false;
+        // only what has actually finished is known to be good (sets sharing the stream finished with it)
+        for (size_t i = 0; i < pl->bufs.size(); ++i)
+            if (synced < 0 || i % pl->streams.size() == (size_t)synced % pl->streams.size()) pl->bufs[i].unchecked = false;
         return JTP_OK;
     }
     *(volatile uint32_t *)pl->host_abort = 0;
@@ -717,7 +720,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)d.host_elems * hsz, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        return check_flow(pl);
+        return check_flow(pl, batch);
     }
     const int si = hp.sep_of_node[node];
     if (si < 0) return set_err(JTP_EINVAL, "separator node %d is not part of the tree", node);
@@ -751,7 +754,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)stride * hsz, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    return check_flow(pl);
+    return check_flow(pl, batch);
 }
 
 int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t *out_vars, int32_t n_out, double *host) {
@@ -833,7 +836,7 @@ int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t 
     (void)hipFree(d_task);
     (void)hipFree(d_blk);
     (void)hipFree(d_tab);
-    return rc != JTP_OK ? rc : check_flow(pl);
+    return rc != JTP_OK ? rc : check_flow(pl, batch);
 }
 
 int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cliques, const int32_t *var_off,
@@ -981,7 +984,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
             at += mb->elems[i];
         }
     }
-    return check_flow(pl);
+    return check_flow(pl, batch);
 }
 
 int jtp_get_z(jtp_plan *pl, int32_t batch, double *z) {
