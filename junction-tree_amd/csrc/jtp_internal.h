@@ -1,5 +1,5 @@
 // Internal structures shared by the host planner (jtp_plan.cpp), the kernels
-// (jtp_kernels.hip) and the C ABI (jtp_api.cpp).  See DESIGN.md "Data layout in HBM".
+// (jtp_kernels.hip.h) and the C ABI (jtp_engine.hip).  See DESIGN.md "Data layout in HBM".
 //
 // Everything on the device is a *bit field*: a variable of cardinality k owns
 // ceil(log2 k) consecutive index bits of every table it appears in (tables are zero padded

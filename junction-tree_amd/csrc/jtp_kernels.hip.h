@@ -20,8 +20,13 @@
 // way); per element the message entry is one ds_read at  thread_offset + uniform_offset.
 // Outgoing sums are kept in VEC registers per message over the R loop, then reduced
 // in-thread (e bits), by wave shuffles (lane bits) and through the LDS sub-box (wave bits
-// and A loop), and written once per workgroup as one partial copy.  No atomics: results are
-// bit-reproducible.
+// and A loop), and written once per workgroup as one partial copy.  No float atomics: results
+// are bit-reproducible.
+//
+// Launch structure: by default ONE launch per phase (jt_collect_flow / jt_distribute_flow) over the
+// block list of all tree levels; a workgroup that finds a message entry still marked unwritten
+// waits for it (FLOW = true below).  The same body runs once per tree level in jt_*_level and once
+// per level and clique shape in jt_collect<> / jt_distribute<> (timing aids, and the fallback).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -123,8 +128,8 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     const int rmask = (1 << tk.nR) - 1;               // an outgoing-message epilogue follows every 2^nR
 
     // ---- element loads run U iterations ahead of their use.  Iteration i's offsets are row i of
-    //      the task's iteration table (host built, copied to LDS below): the loops do no index
-    //      arithmetic beyond one broadcast ds_read per row.
+    //      the task's iteration table (host built, held in registers below): the loops do no index
+    //      arithmetic beyond one v_readlane per column.
     const int *gtab = itab + tk.itab_off;
     // the first U loads use offsets stored in the task record, so they leave immediately
     // (addresses come from the workgroup record alone: one dependent load after launch)
