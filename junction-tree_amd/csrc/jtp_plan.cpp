@@ -595,26 +595,31 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         pd.host_elems = stride;
     }
 
-    // ---- per (phase, level) work, to size workgroups -------------------------------------------
-    std::vector<double> lvl_elems[2];
-    lvl_elems[0].assign(maxdepth + 1, 0);
-    lvl_elems[1].assign(maxdepth + 1, 0);
+    // ---- per (phase, level, rank) work, to size workgroups ----------------------------------------
+    // (per owning rank: a rank's launches hold only its own cliques, and every rank must size every
+    // task the same way because the partial-copy counts of the cut messages follow from it)
+    std::vector<std::vector<double>> lvl_elems[2];
+    for (int ph = 0; ph < 2; ++ph) lvl_elems[ph].assign(hp.n_ranks, std::vector<double>(maxdepth + 1, 0.0));
     for (int c = 0; c < NP; ++c) {
         double e = (double)((int64_t)1 << hp.pn[c].nbits);
-        if (c != hp.root) lvl_elems[0][hp.pn[c].depth] += e;
-        lvl_elems[1][hp.pn[c].depth] += e;
+        if (c != hp.root) lvl_elems[0][hp.pn[c].owner][hp.pn[c].depth] += e;
+        lvl_elems[1][hp.pn[c].owner][hp.pn[c].depth] += e;
     }
-    auto block_log2_for = [&](int phase, int level) {
+    auto block_log2_for = [&](int phase, int level, int owner) {
         if (hp.block_log2 > 0) return std::max(hp.block_log2, hp.TB);
-        // aim at ~2048 workgroups per launch (8 per CU), each streaming 32 KiB .. 256 KiB
-        static const double target = getenv("JTP_TARGET_BLOCKS") ? atof(getenv("JTP_TARGET_BLOCKS")) : 2048.0;
+        // aim at ~1024 workgroups per tree level (one round of resident workgroups; in a dataflow launch
+        // the next level fills the tail), each streaming 16 KiB .. 256 KiB.  Measured on C4: 1024 is
+        // 2-3 % faster than 2048 (which was best with one launch per level), 512 and 4096 slower.
+        static const double target_c = getenv("JTP_TARGET_BLOCKS") ? atof(getenv("JTP_TARGET_BLOCKS")) : 1024.0;
+        static const double target_d = getenv("JTP_TARGET_BLOCKS_D") ? atof(getenv("JTP_TARGET_BLOCKS_D")) : target_c;
+        const double target = phase == 0 ? target_c : target_d;
         static const int lgmin = getenv("JTP_MIN_BLOCK_LOG2") ? atoi(getenv("JTP_MIN_BLOCK_LOG2")) : 13;
         static const int lgmax = getenv("JTP_MAX_BLOCK_LOG2") ? atoi(getenv("JTP_MAX_BLOCK_LOG2")) : 16;
         // levels of a clique or two are latency bound: 4 iterations per workgroup, so that every element
         // load is already in flight while the workgroup waits for its messages
         static const double tiny = getenv("JTP_TINY_LEVEL_ELEMS") ? atof(getenv("JTP_TINY_LEVEL_ELEMS")) : 2097152.0;
-        if (lvl_elems[phase][level] <= tiny) return hp.TB + JT_MIN_ITER_LOG2;
-        double want = lvl_elems[phase][level] / target;
+        if (lvl_elems[phase][owner][level] <= tiny) return hp.TB + JT_MIN_ITER_LOG2;
+        double want = lvl_elems[phase][owner][level] / target;
         int lg = lgmin;
         while (lg < lgmax && (double)(1 << (lg + 1)) <= want) ++lg;
         return std::max(lg, hp.TB);
@@ -645,7 +650,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             int real_bits = 0;
             for (int nb : p.nb) real_bits += nb;
             std::vector<int32_t> itab;
-            int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth), err);
+            int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err);
             if (rc != JTP_OK) return rc;
             tk.itab_off = (int64_t)hp.itab.size();
             hp.itab.insert(hp.itab.end(), itab.begin(), itab.end());
