@@ -211,6 +211,20 @@ extern "C" {
 const char *jtp_last_error(void) { return g_err.c_str(); }
 const char *jtp_version(void) { return "jtprop 0.1.0 (gfx950, HIP, RCCL p2p)"; }
 
+int jtp_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr) return set_err(JTP_EINVAL, "null argument");
+    *ptr = nullptr;
+    hipError_t e = hipHostMalloc(ptr, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) return set_err(e == hipErrorOutOfMemory ? JTP_ENOMEM : JTP_EHIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return JTP_OK;
+}
+
+int jtp_host_free(void *ptr) {
+    if (!ptr) return JTP_OK;
+    HIP_TRY(hipHostFree(ptr));
+    return JTP_OK;
+}
+
 int jtp_device_count(int32_t *count) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -105,6 +105,8 @@ SYMBOLS = {
     "jtp_comm_destroy": (C.c_int, []),
     "jtp_comm_selftest": (C.c_int, [C.c_int32]),
     "jtp_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
+    "jtp_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "jtp_host_free": (C.c_int, [C.c_void_p]),
     "jtp_last_error": (C.c_char_p, []),
     "jtp_version": (C.c_char_p, []),
 }

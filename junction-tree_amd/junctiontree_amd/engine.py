@@ -200,8 +200,13 @@ class Plan:
         _capi.check(self._lib.jtp_sync(self._handle))
 
     # ------------------------------------------------------------------ data out
-    def belief(self, node, batch=0, dtype=np.float64):
-        out = np.empty(self.node_shape[node], dtype=dtype)
+    def belief(self, node, batch=0, dtype=np.float64, out=None):
+        """Belief of node `node` (clique or separator) in the caller's axis order.  `out`: a C-contiguous
+        float32/float64 array of the node's shape to receive it (e.g. from `pinned_empty`)."""
+        if out is None:
+            out = np.empty(self.node_shape[node], dtype=dtype)
+        elif out.shape != tuple(self.node_shape[node]) or not out.flags["C_CONTIGUOUS"] or out.dtype not in (np.float32, np.float64):
+            raise ValueError("`out` must be a C-contiguous float32/float64 array of shape %r" % (tuple(self.node_shape[node]),))
         host_dtype = _capi.JTP_F32 if out.dtype == np.float32 else _capi.JTP_F64
         _capi.check(self._lib.jtp_get_belief(self._handle, batch, self.abi_of[node],
                                              out.ctypes.data_as(C.c_void_p), host_dtype))
@@ -277,6 +282,21 @@ class Plan:
         return {"n_launches": st.n_launches, "n_messages": st.n_messages, "n_tasks": st.n_tasks,
                 "algorithmic_bytes": st.algorithmic_bytes, "collect_ms": st.collect_ms,
                 "distribute_ms": st.distribute_ms, "kernels": kernels, "flow_fallbacks": st.flow_fallbacks}
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory (jtp_host_alloc): potentials passed from it and beliefs
+    read into it (`Plan.belief(..., out=...)`) move at PCIe speed.  Freed with the array."""
+    import weakref
+    lib = _capi.lib()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    ptr = C.c_void_p()
+    _capi.check(lib.jtp_host_alloc(C.byref(ptr), n * dt.itemsize))
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    weakref.finalize(buf, lib.jtp_host_free, ptr.value)
+    return arr
 
 
 # ---------------------------------------------------------------------- plan cache

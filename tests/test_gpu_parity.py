@@ -438,6 +438,29 @@ def test_repeated_propagates_with_new_potentials_and_mixed_launch_modes():
         plan.close()
 
 
+def test_pinned_host_arrays_in_and_out():
+    """Potentials handed over from page-locked arrays (jtp_host_alloc) and beliefs read into them."""
+    spec = synthetic.wide_binary_tree(n_cliques=7, width=12, sep=6, card=2, seed=3)
+    pots = synthetic.potentials_for(spec, seed=8)
+    want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64")
+    bufs = []
+    for c in range(spec["n_cliques"]):
+        a = engine.pinned_empty(pots[c].shape, np.float64)
+        a[...] = pots[c]
+        plan.set_potential(c, a)
+        bufs.append(a)
+    plan.propagate()
+    for c in range(spec["n_cliques"]):
+        got = plan.belief(c, out=bufs[c])
+        assert got is bufs[c]
+        close(got, want[c])
+    with pytest.raises(ValueError):
+        plan.belief(0, out=np.empty((3,)))
+    del bufs, got, a
+    plan.close()
+
+
 def test_batched_marginals_match_single_requests():
     """jtp_get_marginals (all of CliqueGraph.marginalize in one launch) against jtp_get_marginal and
     the oracle: several requests per clique, permuted axis orders, the empty request (= Z), a repeated
