@@ -1,0 +1,52 @@
+"""Soak test of the dataflow launches: many propagates, every result compared bit for bit with the first
+(the engine is deterministic), the fallback counter must stay 0.   python tools/soak.py [propagates]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
+from junctiontree_amd import engine, synthetic
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+cases = [("c4", synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0), "f32", reps),
+         ("mid", synthetic.wide_binary_tree(n_cliques=63, width=16, sep=8, card=2, seed=3), "f64", reps),
+         ("random", synthetic.random_tree(n_cliques=40, width=14, sep=6, card=2, seed=5), "f32", reps),
+         ("chain", synthetic.chain_tree(n_cliques=60, card=16, width=3), "f64", reps)]
+for name, spec, dt, n in cases:
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dt)
+    plan.fill_synthetic(1, spec["scales"])
+    plan.propagate()
+    probe = [c for c in (0, spec["n_cliques"] // 2, spec["n_cliques"] - 1)]
+    ref = [plan.marginal(c, list(spec["node_vars"][c])[:2]) for c in probe]
+    z0 = plan.z()
+    t0 = time.perf_counter()
+    bad = 0
+    for i in range(n):
+        plan.propagate(sync=False)
+        if i % 50 == 49:
+            plan.sync()
+            got = [plan.marginal(c, list(spec["node_vars"][c])[:2]) for c in probe]
+            if plan.z() != z0 or any(not np.array_equal(a, b) for a, b in zip(got, ref)):
+                bad += 1
+    plan.sync()
+    st = plan.stats()
+    print("%-7s %5d propagates  %.1f s  mismatching checks %d  fallbacks %d  Z %.12g" % (name, n, time.perf_counter() - t0, bad, st["flow_fallbacks"], z0))
+    assert bad == 0 and st["flow_fallbacks"] == 0
+    plan.close()
+# several evidence sets in flight on their own streams (their dataflow kernels share the GPU)
+spec = synthetic.wide_binary_tree(n_cliques=127, width=17, sep=8, card=2, seed=7)
+plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", n_batch=6)
+for b in range(6):
+    plan.fill_synthetic(10 + b, spec["scales"], batch=b)
+plan.propagate(0, 6)
+z0 = [plan.z(batch=b) for b in range(6)]
+t0 = time.perf_counter()
+bad = 0
+for i in range(reps):
+    plan.propagate(0, 6, sync=False)
+    if i % 100 == 99:
+        plan.sync()
+        bad += sum(plan.z(batch=b) != z0[b] for b in range(6))
+plan.sync()
+print("batch6  %5d x 6 propagates  %.1f s  mismatching checks %d  fallbacks %d" % (reps, time.perf_counter() - t0, bad, plan.stats()["flow_fallbacks"]))
+assert bad == 0 and plan.stats()["flow_fallbacks"] == 0
+plan.close()
+print("soak ok")
