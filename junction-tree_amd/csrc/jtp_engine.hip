@@ -249,7 +249,7 @@ void jtp_plan_destroy(jtp_plan *pl) {
         (void)hipSetDevice(pl->hp.device);
         for (auto s : pl->streams) (void)hipStreamSynchronize(s);
         for (auto &b : pl->bufs) {
-            if (b.psi) (void)hipFree(b.psi);
+            if (b.psi && (&b == &pl->bufs[0] || b.psi != pl->bufs[0].psi)) (void)hipFree(b.psi);
             if (b.bel) (void)hipFree(b.bel);
             if (b.msg) (void)hipFree(b.msg);
             if (b.sync) (void)hipFree(b.sync);
@@ -326,8 +326,10 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     const size_t abytes = (size_t)std::max<int64_t>(hp.arena_elems, 256) * pl->esize;
     // two halves, used by alternate propagates (jtp_internal.h: JT_UNWRITTEN)
     const size_t mbytes = (size_t)std::max<int64_t>(hp.msg_doubles, 2) * 8 * 2;
+    const bool share_psi = getenv("JTP_SHARE_PSI") && atoi(getenv("JTP_SHARE_PSI"));     // experiment: one potential arena for all evidence sets
     for (auto &b : pl->bufs) {
-        CREATE_TRY(hipMalloc(&b.psi, abytes));
+        if (share_psi && &b != &pl->bufs[0]) b.psi = pl->bufs[0].psi;
+        else CREATE_TRY(hipMalloc(&b.psi, abytes));
         CREATE_TRY(hipMalloc(&b.bel, abytes));
         CREATE_TRY(hipMalloc((void **)&b.msg, mbytes));
         CREATE_TRY(hipMemsetAsync(b.psi, 0, abytes, pl->streams[0]));
@@ -642,7 +644,12 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
             bb.flow_runs++;
             bb.unchecked = true;
         }
-        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0;
+        // Several evidence sets = several dataflow kernels on the device at once.  In blockIdx order that can
+        // deadlock: kernel A's waiting workgroups fill the XCD on which kernel B's lowest unfinished
+        // workgroup should start, and the other way round (seen: --batch 4 hit the 2 s time-out).  A
+        // ticket is drawn by a workgroup that is already running, so the lowest unfinished record of every
+        // kernel is always being worked on, whatever else shares the device.
+        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->streams.size() > 1;
         for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {
             if (st.kind == 0 && flow) {
                 const Segment &sg = hp.segments[st.first];
