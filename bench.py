@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1,
                     help="independent evidence sets per step, one HIP stream each (BASELINE configs[4] in "
                          "miniature; default 1 = the metric's workload)")
+    ap.add_argument("--share", action="store_true",
+                    help="with --batch: the evidence sets share one set of clique tables (JTP_SHARE_POTENTIALS) and "
+                         "differ by hard evidence on 16 variables each (SURVEY 8d, config 5)")
     ap.add_argument("--cliques", type=int, default=256)
     ap.add_argument("--width", type=int, default=20)
     ap.add_argument("--sep", type=int, default=10)
@@ -138,9 +141,18 @@ def main():
                        device=device, n_ranks=world, rank=rank, owner=owner, n_batch=args.batch,
                        block_log2=args.block_log2, lds_budget=args.lds_budget,
                        layout_policy=args.layout_policy, split_variants=args.split_variants,
-                       level_launches=args.level_launches)
-    for b in range(args.batch):
-        plan.fill_synthetic(1 + b, spec["scales"], batch=b)
+                       level_launches=args.level_launches, share_potentials=args.share)
+    if args.share:
+        import numpy as np
+        plan.fill_synthetic(1, spec["scales"])
+        labels = sorted(spec["sizes"])
+        for b in range(args.batch):
+            rng = np.random.default_rng(1000 + b + 64 * rank)
+            plan.set_evidence({labels[i]: int(rng.integers(0, spec["sizes"][labels[i]]))
+                               for i in rng.choice(len(labels), size=16, replace=False)}, batch=b)
+    else:
+        for b in range(args.batch):
+            plan.fill_synthetic(1 + b, spec["scales"], batch=b)
 
     for _ in range(args.warmup):
         plan.propagate(sync=False)
@@ -186,7 +198,7 @@ def main():
                             "potentials), %d shared variables per edge, balanced binary tree"
                             % (n, args.width, args.card, args.width, args.dtype, args.sep),
                 "algorithmic_bytes_per_step": alg["total"] * args.batch, "messages_per_step": alg["messages"] * args.batch,
-                "evidence_sets_per_step": args.batch,
+                "evidence_sets_per_step": args.batch, "shared_potentials": bool(args.share),
                 "parallelism": "1 GPU" if world == 1 else "subtree-sharded x%d, RCCL send/recv at cuts" % world,
                 "launches_per_step": stats["n_launches"], "Z": z,
             },

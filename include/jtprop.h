@@ -42,10 +42,15 @@ extern "C" {
                                profiling aid, attributes device time to each clique shape   */
 
 #define JTP_LEVEL_LAUNCHES 8u /* one launch per tree level instead of the default one per phase, whose
-                               workgroups wait on per-message completion counters (dataflow)  */
+                               workgroups wait for the message entries they need (dataflow)   */
 
 #define JTP_FLOW_TICKETS 16u /* dataflow launches: workgroups draw their place in the block list from an
                                atomic counter instead of relying on in-order workgroup dispatch     */
+
+#define JTP_SHARE_POTENTIALS 32u /* the n_batch evidence sets read ONE set of clique potentials (set through
+                               evidence set 0) and differ by their evidence (jtp_set_evidence): BASELINE
+                               config 5 without 512 copies of the tables, and with the concurrently running
+                               sets finding each other's table reads in the last-level cache             */
 
 typedef struct jtp_plan jtp_plan;
 
@@ -135,6 +140,13 @@ int jtp_set_potential_product(jtp_plan *plan, int32_t batch, int32_t clique, int
  * junctiontree_amd/synthetic.py: psi[i] = (0.5 + u(seed, node, i)) * scale[node], i the
  * C-order host index.  For benchmarks (no host transfer). */
 int jtp_fill_synthetic(jtp_plan *plan, int32_t batch, uint64_t seed, const double *scale);
+
+/* Hard evidence of one evidence set: variable var_ids[i] is observed in state states[i].  Replaces the
+ * set's previous evidence (n = 0 clears it).  Equivalent to multiplying a one-hot indicator into one
+ * clique that contains the variable (the equivalence tests/test_computation.py:411-459 of the
+ * reference demonstrates for apply_evidence, computation.py:11-34), but nothing is rewritten: the kernels
+ * skip the table entries that contradict the evidence.  Takes effect at the next jtp_propagate. */
+int jtp_set_evidence(jtp_plan *plan, int32_t batch, int32_t n, const int32_t *var_ids, const int32_t *states);
 
 /* ---- compute -------------------------------------------------------------------------- */
 

@@ -132,6 +132,7 @@ struct BatchBuffers {
     void *psi = nullptr;
     void *bel = nullptr;
     double *msg = nullptr;
+    uint32_t *ev = nullptr;         // hard evidence: (mask, value) per planner node, or null (jtp_set_evidence)
     uint32_t *sync = nullptr;       // dataflow launches: abort flag and ticket counters
     uint32_t epoch = 0;             // propagates enqueued so far; its parity selects the message arena half
     uint32_t flow_runs = 0;         // of which dataflow (ticket counters only grow)
@@ -178,6 +179,7 @@ struct jtp_plan {
     uint32_t *host_abort = nullptr; // pinned: set by a workgroup that gave up waiting
     int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
     bool fake_comm = false;         // JTP_FAKE_COMM
+    bool psi_dirty = false;         // shared potentials were written (on stream 0) since the last propagate
     std::vector<MargBatch *> marg_cache;
     // factor tables on their way to jt_eval_product: slices of one buffer handed out in turn, so that
     // evaluating clique after clique needs no synchronisation until the buffer wraps
@@ -252,6 +254,7 @@ void jtp_plan_destroy(jtp_plan *pl) {
             if (b.psi && (&b == &pl->bufs[0] || b.psi != pl->bufs[0].psi)) (void)hipFree(b.psi);
             if (b.bel) (void)hipFree(b.bel);
             if (b.msg) (void)hipFree(b.msg);
+            if (b.ev) (void)hipFree(b.ev);
             if (b.sync) (void)hipFree(b.sync);
         }
         if (pl->host_abort) (void)hipHostFree(pl->host_abort);
@@ -326,7 +329,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     const size_t abytes = (size_t)std::max<int64_t>(hp.arena_elems, 256) * pl->esize;
     // two halves, used by alternate propagates (jtp_internal.h: JT_UNWRITTEN)
     const size_t mbytes = (size_t)std::max<int64_t>(hp.msg_doubles, 2) * 8 * 2;
-    const bool share_psi = getenv("JTP_SHARE_PSI") && atoi(getenv("JTP_SHARE_PSI"));     // experiment: one potential arena for all evidence sets
+    const bool share_psi = (hp.flags & JTP_SHARE_POTENTIALS) != 0;     // one potential arena for all evidence sets
     for (auto &b : pl->bufs) {
         if (share_psi && &b != &pl->bufs[0]) b.psi = pl->bufs[0].psi;
         else CREATE_TRY(hipMalloc(&b.psi, abytes));
@@ -387,6 +390,13 @@ const char *jtp_plan_describe(jtp_plan *pl) {
 
 // ------------------------------------------------------------------------------------------ data in
 
+// potentials are written through evidence set 0 when the plan shares them
+static int check_writable(jtp_plan *pl, int batch) {
+    if ((pl->hp.flags & JTP_SHARE_POTENTIALS) && batch != 0)
+        return set_err(JTP_EINVAL, "the plan shares its potentials between evidence sets: set them through evidence set 0");
+    return JTP_OK;
+}
+
 static int check_ready(jtp_plan *pl, int batch) {
     if (!pl) return set_err(JTP_EINVAL, "null plan");
     if (!pl->device) return set_err(JTP_EHIP, "plan was created with JTP_PLAN_ONLY: no device work possible");
@@ -398,6 +408,9 @@ int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *hos
                       int32_t host_dtype) {
     int rc = check_ready(pl, batch);
     if (rc) return rc;
+    rc = check_writable(pl, batch);
+    if (rc) return rc;
+    pl->psi_dirty = true;
     HostPlan &hp = pl->hp;
     if (node < 0 || node >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", node);
     if (hp.pn[node].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", node, hp.pn[node].owner);
@@ -433,6 +446,9 @@ int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *hos
 int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32_t n_factors, const jtp_factor *factors) {
     int rc = check_ready(pl, batch);
     if (rc) return rc;
+    rc = check_writable(pl, batch);
+    if (rc) return rc;
+    pl->psi_dirty = true;
     HostPlan &hp = pl->hp;
     if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
     if (hp.pn[clique].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
@@ -536,6 +552,9 @@ static uint64_t host_splitmix64(uint64_t x) {
 int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double *scale) {
     int rc = check_ready(pl, batch);
     if (rc) return rc;
+    rc = check_writable(pl, batch);
+    if (rc) return rc;
+    pl->psi_dirty = true;
     HostPlan &hp = pl->hp;
     HIP_TRY(hipSetDevice(hp.device));
     hipStream_t s = pl->streams[batch % pl->streams.size()];
@@ -605,12 +624,52 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
     return JTP_OK;
 }
 
+int jtp_set_evidence(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *var_ids, const int32_t *states) {
+    int rc = check_ready(pl, batch);
+    if (rc) return rc;
+    HostPlan &hp = pl->hp;
+    if (n < 0 || (n > 0 && (!var_ids || !states))) return set_err(JTP_EINVAL, "null argument");
+    BatchBuffers &b = pl->bufs[batch];
+    std::vector<uint32_t> ev(2 * hp.pn.size(), 0u);
+    std::vector<char> seen(hp.n_vars, 0);
+    for (int i = 0; i < n; ++i) {
+        const int v = var_ids[i];
+        if (v < 0 || v >= hp.n_vars) return set_err(JTP_EINVAL, "evidence %d: variable %d out of range", i, v);
+        if (states[i] < 0 || states[i] >= hp.card[v]) return set_err(JTP_EINVAL, "evidence %d: state %d of variable %d (cardinality %d)", i, states[i], v, hp.card[v]);
+        if (seen[v]) return set_err(JTP_EINVAL, "variable %d observed twice", v);
+        seen[v] = 1;
+        // the indicator goes into ONE clique that contains the variable: the first in the caller's
+        // numbering (every rank makes the same choice; the owner applies it)
+        int host = -1;
+        for (int c = 0; c < hp.n_cliques && host < 0; ++c)
+            for (int u : hp.pn[c].vars)
+                if (u == v) host = c;
+        if (host < 0) return set_err(JTP_EINVAL, "variable %d is in no clique", v);
+        const PNode &p = hp.pn[host];
+        for (size_t j = 0; j < p.vars.size(); ++j)
+            if (p.vars[j] == v) {
+                ev[2 * host] |= ((1u << p.nb[j]) - 1u) << p.pos[j];
+                ev[2 * host + 1] |= (uint32_t)states[i] << p.pos[j];
+            }
+    }
+    HIP_TRY(hipSetDevice(hp.device));
+    hipStream_t s = pl->streams[batch % pl->streams.size()];
+    HIP_TRY(hipStreamSynchronize(s));                      // a propagate in flight may still read the old table
+    if (!b.ev) HIP_TRY(hipMalloc((void **)&b.ev, ev.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(b.ev, ev.data(), ev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return JTP_OK;
+}
+
 int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
     int rc = check_ready(pl, batch_begin);
     if (rc) return rc;
     HostPlan &hp = pl->hp;
     if (batch_end <= batch_begin || batch_end > hp.n_batch) return set_err(JTP_EINVAL, "bad batch range [%d,%d)", batch_begin, batch_end);
     HIP_TRY(hipSetDevice(hp.device));
+    if ((hp.flags & JTP_SHARE_POTENTIALS) && pl->psi_dirty) {
+        HIP_TRY(hipStreamSynchronize(pl->streams[0]));        // the shared tables were written on stream 0
+        pl->psi_dirty = false;
+    }
     const bool prof = pl->prof_steps > 0;
     const size_t ev_per_step = pl->prof_per_launch ? 2 * hp.launches.size() : 3;
     if (prof) {
@@ -640,6 +699,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         fl.cur_off = bb.cur_off(half);
         fl.oth_off = half - fl.cur_off;
         fl.dbg = getenv("JTP_FLOW_DEBUG") ? (uint32_t)atoi(getenv("JTP_FLOW_DEBUG")) : 0u;
+        fl.ev = bb.ev;
         if (flow) {
             bb.flow_runs++;
             bb.unchecked = true;

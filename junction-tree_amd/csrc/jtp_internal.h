@@ -89,6 +89,8 @@ struct JtFlow {
     uint32_t dbg;              // timing experiments (JTP_FLOW_DEBUG): 4 = no waits (wrong results), 8 = every wait
                                // times out after 20 ms (exercises the fallback to one launch per level)
     uint32_t blk_base;         // index of the launch's first workgroup in the plan's block list (time stamps)
+    const uint32_t *ev;        // hard evidence of this evidence set: per planner node (mask, value) over the
+                               // clique's index bits, or null: entries with (x & mask) != value count as 0
 };
 
 // one workgroup: which task, and the chunk's decoded bases (so the kernel does no bit decode)

@@ -126,6 +126,13 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     const int total = tk.total;                       // loop iterations of this workgroup (>= U)
     const int dbg = tk.debug;
     const int rmask = (1 << tk.nR) - 1;               // an outgoing-message epilogue follows every 2^nR
+    // hard evidence of this evidence set on this clique (jtp_set_evidence): table entries whose index
+    // contradicts it count as zero (read here, before the first store: see the scalar-cache note below)
+    uint32_t ev_mask = 0, ev_val = 0;
+    if (fl.ev != nullptr) {
+        ev_mask = fl.ev[2 * tk.pnode];
+        ev_val = fl.ev[2 * tk.pnode + 1];
+    }
 
     // ---- element loads run U iterations ahead of their use.  Iteration i's offsets are row i of
     //      the task's iteration table (host built, held in registers below): the loops do no index
@@ -438,6 +445,12 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         }
         const int li = i;
         const uint32_t xoff = (uint32_t)__builtin_amdgcn_readlane(trow[0], li);
+        {
+            const uint32_t x0 = xF + xoff;                 // index of this thread's first element in the clique table
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (((x0 + e) & ev_mask) != ev_val) p[e] = 0.0;
+        }
         int ioff[4], ooff[3];
 #pragma unroll
         for (int k = 0; k < 4; ++k) ioff[k] = k < NIN ? __builtin_amdgcn_readlane(trow[1 + k], li) : 0;

@@ -17,6 +17,7 @@ JTP_PLAN_ONLY = 1
 JTP_SPLIT_VARIANTS = 2
 JTP_KEEP_ROOT = 4
 JTP_LEVEL_LAUNCHES = 8
+JTP_SHARE_POTENTIALS = 32
 JTP_FLOW_TICKETS = 16
 N_VARIANTS = 17
 
@@ -86,6 +87,7 @@ SYMBOLS = {
                                     C.POINTER(C.c_int64), C.c_int32]),
     "jtp_set_potential_product": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Factor)]),
     "jtp_fill_synthetic": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_double)]),
+    "jtp_set_evidence": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "jtp_propagate": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "jtp_sync": (C.c_int, [C.c_void_p]),
     "jtp_get_belief": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),

@@ -57,7 +57,7 @@ class Plan:
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
                  layout_policy=0, split_variants=False, keep_root=False, level_launches=False,
-                 flow_tickets=False):
+                 flow_tickets=False, share_potentials=False):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
@@ -115,7 +115,8 @@ class Plan:
         d.flags = ((_capi.JTP_PLAN_ONLY if plan_only else 0) | (_capi.JTP_SPLIT_VARIANTS if split_variants else 0)
                    | (_capi.JTP_KEEP_ROOT if keep_root else 0)
                    | (_capi.JTP_LEVEL_LAUNCHES if level_launches else 0)
-                   | (_capi.JTP_FLOW_TICKETS if flow_tickets else 0))
+                   | (_capi.JTP_FLOW_TICKETS if flow_tickets else 0)
+                   | (_capi.JTP_SHARE_POTENTIALS if share_potentials else 0))
         d.lds_budget = lds_budget
         d.block_log2 = block_log2
         d.layout_policy = layout_policy
@@ -178,6 +179,15 @@ class Plan:
             recs[i].var_ids = C.cast(ids, C.POINTER(C.c_int32))
             recs[i].shape = C.cast(shape, C.POINTER(C.c_int64))
         _capi.check(self._lib.jtp_set_potential_product(self._handle, batch, self.abi_of[node], len(arrays), recs))
+
+    def set_evidence(self, observed, batch=0):
+        """Hard evidence of evidence set `batch`: `observed` maps variable label -> observed state; it
+        replaces the set's previous evidence ({} clears it) and applies from the next propagate."""
+        labels = list(observed)
+        ids = _int_array([self.var_id[lab] for lab in labels])
+        states = _int_array([int(observed[lab]) for lab in labels])
+        _capi.check(self._lib.jtp_set_evidence(self._handle, batch, len(labels), C.cast(ids, C.POINTER(C.c_int32)),
+                                               C.cast(states, C.POINTER(C.c_int32))))
 
     def fill_synthetic(self, seed, scales=None, batch=0):
         """Device-side counter-based potentials (see synthetic.synth_values).  `scales` is

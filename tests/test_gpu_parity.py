@@ -534,6 +534,58 @@ def test_dataflow_timeout_falls_back_to_level_launches(monkeypatch):
         plan.close()
 
 
+@pytest.mark.parametrize("share", [True, False])
+def test_hard_evidence_sets(share):
+    """jtp_set_evidence: evidence sets that differ only by what is observed, with ONE copy of the clique
+    tables (JTP_SHARE_POTENTIALS, BASELINE config 5 in miniature) or with a copy each.  Expected values:
+    the oracle on potentials with a one-hot indicator multiplied into one clique containing the variable
+    (what apply_evidence amounts to, tests/test_computation.py:411-459 of the reference)."""
+    for spec, dtype in ((synthetic.wide_binary_tree(n_cliques=15, width=12, sep=6, card=2, seed=2), "f64"),
+                        (synthetic.random_tree(n_cliques=9, width=5, sep=2, card=3, seed=4), "f64"),
+                        (synthetic.wide_binary_tree(n_cliques=7, width=13, sep=6, card=2, seed=6), "f32")):
+        n, nb = spec["n_cliques"], 5
+        np_dt = np.float32 if dtype == "f32" else np.float64
+        base = synthetic.potentials_for(spec, seed=4, dtype=np_dt)
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, n_batch=nb, share_potentials=share)
+        for b in range(nb if not share else 1):
+            for c in range(n):
+                plan.set_potential(c, base[c], batch=b)
+        if share:
+            with pytest.raises(ValueError):
+                plan.set_potential(0, base[0], batch=1)
+        labels = sorted(spec["sizes"])
+        observed = []
+        for b in range(nb):
+            rng = np.random.default_rng(1000 + b)
+            obs = {} if b == 0 else {labels[i]: int(rng.integers(0, spec["sizes"][labels[i]]))
+                                     for i in rng.choice(len(labels), size=min(4, b + 1), replace=False)}
+            observed.append(obs)
+            plan.set_evidence(obs, batch=b)
+        for rep in range(2):
+            plan.propagate(0, nb)
+            for b in range(nb):
+                pots = [np.asarray(p, dtype=np.float64).copy() for p in base]
+                for var, state in observed[b].items():
+                    host = next(c for c in range(n) if var in spec["node_vars"][c])
+                    axis = spec["node_vars"][host].index(var)
+                    ind = np.zeros(spec["sizes"][var])
+                    ind[state] = 1.0
+                    shape = [1] * pots[host].ndim
+                    shape[axis] = spec["sizes"][var]
+                    pots[host] = pots[host] * ind.reshape(shape)
+                want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+                for node in range(len(spec["node_vars"])):
+                    close(plan.belief(node, batch=b), want[node], rtol=RTOL32 if dtype == "f32" else RTOL64,
+                          what="share %r batch %d node %d" % (share, b, node))
+                assert abs(plan.z(batch=b) - z) <= (1e-6 if dtype == "f32" else 1e-11) * abs(z)
+            observed[1], observed[2] = observed[2], observed[1]          # evidence can be replaced
+            plan.set_evidence(observed[1], batch=1)
+            plan.set_evidence(observed[2], batch=2)
+        with pytest.raises(ValueError):
+            plan.set_evidence({labels[0]: spec["sizes"][labels[0]]})      # state out of range
+        plan.close()
+
+
 def test_grid_mrf_through_public_api_vs_bruteforce():
     """Loopy pairwise models (BASELINE config 3 family at brute-forceable size): 3x3, 4x4 and
     3x3x2 binary lattices through create_junction_tree / propagate (the reference is wrong or

@@ -8,6 +8,7 @@ rm -rf $OUT; mkdir -p $OUT
 timeout 300 python3 bench.py --steps 30 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python3 bench.py --steps 30 --warmup 3 --cpu-sample 0 --level-launches --per-launch > $OUT/bench_level.json 2> $OUT/per_launch.txt
 timeout 300 python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-profile --batch 4 > $OUT/bench_batch4.json 2>/dev/null
+timeout 300 python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-profile --batch 16 --share > $OUT/bench_c5_shared.json 2>/dev/null
 timeout 600 python3 bench.py --steps 5 --warmup 1 --config c2 > $OUT/bench_c2.json 2>/dev/null
 JTP_DEBUG=2 timeout 300 python3 tools/stamps.py > $OUT/stage_times.txt 2>&1
 timeout 300 python3 tools/rank_time.py 8 20 > $OUT/rank_time_8.txt 2>&1
