@@ -155,3 +155,27 @@ class JunctionTree:
         plan.propagate()
         # marginalize (junctiontree.py:229-274) on the device, all factors in one launch
         return plan.marginals([(mc, list(fvars)) for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)])
+
+    def propagate_evidence_sets(self, xs, evidence_sets):
+        """`propagate` for several hard-evidence sets over the same factor values (no counterpart in the
+        reference, whose users loop over `propagate` after slicing the factors, `README.md:155-165`):
+        `evidence_sets` is a list of {variable: observed state}; returns one list of factor marginals
+        per set, each factor with its full shape (entries contradicting the evidence are zero) and
+        every table of set e summing to P(evidence e) * Z.  The clique tables are formed once and
+        shared by all sets (JTP_SHARE_POTENTIALS); the sets run concurrently, one HIP stream each."""
+        from . import engine
+
+        ct = self.clique_tree
+        if not evidence_sets:
+            return []
+        all_f32 = all(isinstance(x, np.ndarray) and x.dtype == np.float32 for x in xs)
+        node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in self.separators]
+        plan = engine.plan_for(self.tree, node_vars, ct.factor_graph.sizes, "f32" if all_f32 else "f64",
+                               n_batch=len(evidence_sets), share_potentials=True, **self._opts)
+        for c, members in enumerate(ct._members()):
+            plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
+        for b, observed in enumerate(evidence_sets):
+            plan.set_evidence(observed, batch=b)
+        plan.propagate(0, len(evidence_sets))
+        requests = [(mc, list(fvars)) for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)]
+        return [plan.marginals(requests, batch=b) for b in range(len(evidence_sets))]

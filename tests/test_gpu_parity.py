@@ -67,6 +67,37 @@ def test_reference_networks_propagate(golden):
     np.testing.assert_allclose(out[7].sum(axis=(0, 1)), k["P_H_atol0.01"], atol=0.01)
 
 
+def test_evidence_sets_through_the_public_api(golden):
+    """JunctionTree.propagate_evidence_sets: each set must equal a plain propagate() of the same network
+    with a one-hot indicator multiplied into one factor that contains the observed variable."""
+    g = golden("networks.npz")
+    rng = np.random.default_rng(5)
+    for name, net in g.meta["networks"].items():
+        sizes = dict(net["sizes"])
+        tree = jt.create_junction_tree(net["factors"], sizes)
+        values = g.arrs(net["values"])
+        variables = sorted(sizes)
+        evidence_sets = [{}]
+        for k in (1, 2, 3):
+            picked = rng.choice(len(variables), size=min(k, len(variables)), replace=False)
+            evidence_sets.append({variables[i]: int(rng.integers(0, sizes[variables[i]])) for i in picked})
+        got = tree.propagate_evidence_sets(values, evidence_sets)
+        assert len(got) == len(evidence_sets)
+        for observed, out in zip(evidence_sets, got):
+            xs = [np.array(v, dtype=np.float64) for v in values]
+            for var, state in observed.items():
+                f = next(i for i, fv in enumerate(net["factors"]) if var in fv)
+                ind = np.zeros(sizes[var])
+                ind[state] = 1.0
+                shape = [1] * xs[f].ndim
+                shape[net["factors"][f].index(var)] = sizes[var]
+                xs[f] = xs[f] * ind.reshape(shape)
+            want = tree.propagate(xs)
+            for o, w, v in zip(out, want, values):
+                assert o.shape == np.shape(v)
+                close(o, w, what="%s %r" % (name, observed))
+
+
 def test_hand_built_tree_like_reference_test(golden):
     g = golden("networks.npz")
     net = g.meta["networks"]["abcdefgh"]
