@@ -129,7 +129,8 @@ def main():
 
     if args.config == "c2":
         args.dtype, args.cpu_sample = "f64", 0
-        spec = synthetic.chain_tree(n_cliques=1000 if args.cliques == 256 else args.cliques, card=64, width=3)
+        spec = synthetic.chain_tree(n_cliques=1000 if args.cliques == 256 else args.cliques,
+                                    card=64 if args.card == 2 else args.card, width=3 if args.width == 20 else args.width)
     else:
         spec = synthetic.wide_binary_tree(n_cliques=args.cliques, width=args.width, sep=args.sep,
                                           card=args.card, seed=0)

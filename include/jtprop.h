@@ -78,7 +78,10 @@ typedef struct jtp_tree_desc {
     uint32_t flags;                 /* JTP_PLAN_ONLY | JTP_SPLIT_VARIANTS | JTP_KEEP_ROOT | JTP_LEVEL_LAUNCHES | ... */
     int32_t lds_budget;             /* bytes of LDS per workgroup the planner may use, 0=default */
     int32_t block_log2;             /* log2 of target elements per workgroup, 0 = automatic  */
-    int32_t layout_policy;          /* 0 = default heuristic, 1 = keep host axis order       */
+    int32_t layout_policy;          /* bit order of the clique tables: 0 = chosen per clique (2 or 3 by the size of
+                                       its messages), 1 = host axis order, 2 = variables of the fewest messages
+                                       lowest (least message traffic), 3 = message variables in the thread part
+                                       (cheapest reduction)                                   */
 } jtp_tree_desc;
 
 /* Counters of the last jtp_propagate (device time needs jtp_set_profiling(plan, 1)). */

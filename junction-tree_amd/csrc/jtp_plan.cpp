@@ -281,6 +281,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     hp.lds_budget = d->lds_budget;
     hp.block_log2 = d->block_log2;
     hp.layout_policy = d->layout_policy;
+    if (getenv("JTP_LAYOUT_POLICY")) hp.layout_policy = atoi(getenv("JTP_LAYOUT_POLICY"));     // experiments
     hp.VEC = d->dtype == JTP_F32 ? 4 : 2;
     hp.EB = d->dtype == JTP_F32 ? 2 : 1;
     hp.TB = hp.EB + 8;
@@ -464,8 +465,44 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         if (p.psep >= 0) seps.push_back(p.psep);
         for (int k : p.children) seps.push_back(hp.pn[k].psep);
         std::vector<int> order;                       // LSB first
-        if (hp.layout_policy == 1 || seps.empty()) {
+        // Policy 0 chooses per clique between the two heuristics below.  "Epilogue first" (policy 3) suits
+        // cliques whose messages are small beside the table (C4: 3 x 8 KiB against 4 MiB); "traffic first"
+        // (policy 2) those whose messages are not, and chain-like cliques, whose levels are latency bound
+        // and gain from fewer partial copies.  Measured crossover on trees of 64 cliques of 2^20..2^23
+        // entries, cardinalities 2..16: message bytes / table bytes ~ 0.1-0.2 for branching cliques of
+        // binary variables, 0.03-0.07 with wider ones; chains of any shape tested (cardinality 4..128)
+        // were 1.2-1.7x faster traffic first.
+        int policy = hp.layout_policy;
+        if (policy == 0 && !seps.empty()) {
+            double msg_bytes = 0;
+            for (int sp : seps) {
+                int sb = 0;
+                for (int v : hp.ps[sp].vars) sb += hp.vbits[v];
+                msg_bytes += 8.0 * (double)((int64_t)1 << sb);
+            }
+            int cb = 0;
+            for (int v : host) cb += hp.vbits[v];
+            const double r = msg_bytes / ((double)((int64_t)1 << std::max(cb, hp.TB + JT_MIN_ITER_LOG2)) * esize);
+            // (wide variables move the crossover down: the classes of policy 3 cannot split a variable)
+            const double thr = (double)cb / std::max<size_t>(host.size(), 1) >= 2.0 ? 0.04 : 0.12;
+            policy = (r >= thr || (p.children.size() <= 1 && r >= 0.01)) ? 2 : 3;
+        }
+        p.layout = policy;
+        if (policy == 1 || seps.empty()) {
             order.assign(host.rbegin(), host.rend());
+        } else if (policy == 2) {
+            // Message traffic first (separators nearly as large as the cliques: every message entry is
+            // used only a few times): variables in the fewest messages go lowest, so that the elements
+            // one workgroup covers (thread part + loops) touch as few distinct entries of each message as
+            // possible - a variable absent from a message costs that message's sub-box nothing.
+            std::vector<std::pair<int, int>> keyed;           // (messages containing v, position in host order)
+            for (size_t i = 0; i < host.size(); ++i) {
+                int cnt = 0;
+                for (int sp : seps) cnt += find_var(hp.ps[sp].vars, host[i]) >= 0;
+                keyed.push_back({cnt, (int)i});
+            }
+            std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+            for (auto &kv : keyed) order.push_back(host[kv.second]);
         } else {
             // Classes: priv = in no separator; ponly = only in the parent's; xorc = in some but not
             // all child separators; allc = in every child separator (leaf: in the parent's).
@@ -1004,7 +1041,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         if (i) o << ",";
         o << "{\"real\":" << p.real << ",\"parent\":" << p.parent << ",\"psep\":" << p.psep << ",\"depth\":" << p.depth
           << ",\"owner\":" << p.owner << ",\"nbits\":" << p.nbits << ",\"arena_off\":" << p.arena_off
-          << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"vars\":";
+          << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"vars\":";
         json_vec(o, p.vars);
         o << ",\"pos\":";
         json_vec(o, p.pos);

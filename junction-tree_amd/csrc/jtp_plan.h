@@ -16,6 +16,7 @@ struct PNode {                       // a clique of the (binarised) tree
     int psep = -1;                   // separator to the parent (index into HostPlan::ps)
     std::vector<int> children;       // child pnodes in message order
     int depth = 0;
+    int layout = 0;                  // bit-order heuristic used for this clique (jtp_tree_desc.layout_policy)
     int owner = 0;                   // owning rank
     int64_t arena_off = -1;          // element offset in the potential/belief arenas (real, owned)
     int collect_task = -1, distribute_task = -1;

@@ -173,6 +173,7 @@ def test_refsafe_synthetic_trees_f64_and_f32(golden):
     {"layout_policy": 1, "block_log2": 10, "lds_budget": 128}, {"block_log2": 12, "lds_budget": 2048},
     {"split_variants": True}, {"split_variants": True, "block_log2": 10}, {"keep_root": True},
     {"level_launches": True}, {"level_launches": True, "block_log2": 10, "lds_budget": 256},
+    {"layout_policy": 2}, {"layout_policy": 3}, {"layout_policy": 2, "block_log2": 10, "level_launches": True},
 ])
 def test_planner_options_do_not_change_results(opts):
     specs = [
@@ -209,7 +210,7 @@ def test_reduce_tasks_on_device(monkeypatch, level_launches):
         pots = synthetic.potentials_for(spec, seed=5)
         want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
         plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", block_log2=10,
-                           level_launches=level_launches)
+                           level_launches=level_launches, layout_policy=3)     # (the layout with the most partial copies)
         assert sum(t["kind"] for t in plan.describe()["tasks"]) > 0
         for c in range(spec["n_cliques"]):
             plan.set_potential(c, pots[c])

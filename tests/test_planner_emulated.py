@@ -75,6 +75,7 @@ def test_divergent_cases(golden):
 @pytest.mark.parametrize("opts", [
     {}, {"block_log2": 10}, {"block_log2": 11, "lds_budget": 256}, {"layout_policy": 1},
     {"layout_policy": 1, "block_log2": 10, "lds_budget": 128}, {"keep_root": True},
+    {"layout_policy": 2}, {"layout_policy": 3, "block_log2": 11}, {"layout_policy": 2, "block_log2": 10, "lds_budget": 256},
 ])
 def test_synthetic_trees(opts):
     specs = [
@@ -106,7 +107,7 @@ def test_reduce_tasks_sum_partial_copies(monkeypatch, red_min):
     n_red = 0
     for spec in specs:
         pots = synthetic.potentials_for(spec, seed=5)
-        desc = check(spec["tree"], pots, spec["node_vars"], spec["sizes"], block_log2=10)
+        desc = check(spec["tree"], pots, spec["node_vars"], spec["sizes"], block_log2=10, layout_policy=3)
         n_red += sum(t["kind"] for t in desc["tasks"])
         for s in desc["pseps"]:
             for d in ("up", "dn"):
