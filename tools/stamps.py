@@ -3,7 +3,21 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
 from junctiontree_amd import _capi, engine, synthetic
-if len(sys.argv) > 1 and sys.argv[1] == "c2":
+if len(sys.argv) > 1 and sys.argv[1] == "c3":
+    import junctiontree_amd as jt
+    H, W, K = 6, int(sys.argv[2]) if len(sys.argv) > 2 else 60, 8
+    names = {(i, j): i * W + j for i in range(H) for j in range(W)}
+    factors = []
+    for i in range(H):
+        for j in range(W):
+            if i + 1 < H: factors.append([names[i, j], names[i + 1, j]])
+            if j + 1 < W: factors.append([names[i, j], names[i, j + 1]])
+    sizes = {v: K for v in names.values()}
+    tree = jt.create_junction_tree(factors, sizes)
+    node_vars = [list(c) for c in tree.clique_tree.maxcliques] + [list(s) for s in tree.separators]
+    plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32")
+    spec = {"scales": [8.0 ** -(len(c) - 1) for c in tree.clique_tree.maxcliques]}
+elif len(sys.argv) > 1 and sys.argv[1] == "c2":
     spec = synthetic.chain_tree(n_cliques=int(sys.argv[2]) if len(sys.argv) > 2 else 64, card=64, width=3)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64")
 else:
@@ -19,7 +33,10 @@ _capi.check(plan._lib.jtp_debug_read_msg(plan._handle, 0, base, nb * 8, buf.ctyp
 st = buf.reshape(nb, 8)[:, :6] * 0.01      # 100 MHz ticks -> microseconds
 attempts = buf.reshape(nb, 8)[:, 6]
 phase_t0 = {}
+only_big = len(sys.argv) > 1 and sys.argv[1] == "c3"
 for L in d["launches"]:
+    if only_big and L["nblocks"] < 4096:
+        continue
     if L["variant"] == 16:          # reduce tasks carry no time stamps
         continue
     s = st[L["blk_off"]:L["blk_off"] + L["nblocks"]]
