@@ -697,7 +697,8 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         fl.sync = bb.sync;
         fl.host_abort = pl->host_abort;
         fl.cur_off = bb.cur_off(half);
-        fl.oth_off = half - fl.cur_off;
+        // (a plan that launches per level never waits on entries: it need not mark the other half)
+        fl.oth_off = pl->flow ? half - fl.cur_off : -1;
         fl.dbg = getenv("JTP_FLOW_DEBUG") ? (uint32_t)atoi(getenv("JTP_FLOW_DEBUG")) : 0u;
         fl.ev = bb.ev;
         if (flow) {

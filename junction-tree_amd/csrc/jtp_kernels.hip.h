@@ -384,7 +384,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             }
 #pragma nounroll
             for (int b = 0; b < 6; ++b) {
-                if ((red_lane >> b) & 1) {
+                if (((red_lane >> b) & 1) && !(dbg & 4)) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e)
                         if ((e & red_e) == 0) acc[j][e] += jt_shfl_xor(acc[j][e], 1 << b);
@@ -392,7 +392,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             }
             const bool rep = (lane & red_lane) == 0;
             const int slot = oo[j] + thr[NIN + j];
-            const int nph = 1 << __builtin_popcount((unsigned)red_wave);
+            const int nph = (dbg & 8) ? 1 : 1 << __builtin_popcount((unsigned)red_wave);
             // waves that share slots (wave bits not in the message) take turns, in wave order
             int myph = 0;
             if (red_wave == 1) myph = wave & 1;
