@@ -404,7 +404,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                     for (int e = 0; e < VEC; ++e) {
                         if ((e & red_e) == 0) {
                             const int eo = ((e & 1) ? o_ew0[j] : 0) + ((e & 2) ? o_ew1[j] : 0);
-                            out_sub[j][slot + eo] += acc[j][e];
+                            // one slot, one lane per phase: an LDS add without return (ds_add_f64) is the same
+                            // sum in the same order as read-add-write, minus the wait for the read
+                            __hip_atomic_fetch_add(&out_sub[j][slot + eo], acc[j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 }
