@@ -15,7 +15,7 @@ __device__ __forceinline__ void dma16(const void *gsrc, uint32_t lds_dst) {
 // each workgroup streams `iters` rows of 4 KiB: consecutive rows (stride 1), or every `stride`-th row of its
 // 4 MiB table (the loop bits of a clique are not always its lowest free bits)
 template <int STORE>
-__global__ __launch_bounds__(256) void dma_stream(const float *__restrict__ in, float *__restrict__ outp, double *__restrict__ out, int iters, int stride) {
+__global__ __launch_bounds__(256) void dma_stream(const float *__restrict__ in, float *__restrict__ outp, double *__restrict__ out, int iters, int stride, size_t wshift) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // table = 1024 rows; workgroups per table = 1024 / iters; workgroup j of a table starts at row j (strided) or j * iters
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void dma_stream(const float *__restrict__ in, 
     const size_t row0 = table * 1024 + (stride > 1 ? j : j * iters);
     const size_t rs = (size_t)(stride > 1 ? per_table : 1) * 1024;          // floats between this workgroup's rows
     const float *base = in + row0 * 1024 + tid * 4;
-    float *obase = outp + row0 * 1024 + tid * 4;
+    float *obase = outp + wshift + row0 * 1024 + tid * 4;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + (uint32_t)wave * 4096;
     const char *ring = smem + wave * 4096 + lane * 16;
     for (int u = 0; u < 4; ++u) dma16(base + u * rs, __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
@@ -53,18 +53,29 @@ __global__ __launch_bounds__(256) void dma_stream(const float *__restrict__ in, 
 int main() {
     const size_t bytes = (size_t)1 << 30;
     float *a, *b; double *o;
-    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, 8));
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes + (16 << 20))); CK(hipMalloc(&o, 8));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int lds : {16384, 37120}) for (int iters : {64, 16}) for (int stride : {1, 2}) {
+    for (size_t wshift : {(size_t)0, (size_t)64, (size_t)1024, (size_t)16384, (size_t)(1 << 18), (size_t)(3 << 19)}) {     // write stream shifted by this many floats
+        float ms;
+        const int iters = 64, blocks = (int)(bytes / ((size_t)iters * 4096));
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(dma_stream<1>, dim3(blocks), dim3(256), 37120, 0, (const float *)a, b, o, iters, 1, wshift);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("read+write, write stream shifted by %8zu bytes: %.0f GB/s\n", wshift * 4, 10.0 * 2 * bytes / ms / 1e6);
+        }
+    }
+    for (int lds : {37120}) for (int iters : {64}) for (int stride : {1, 2}) {
         const int blocks = (int)(bytes / ((size_t)iters * 4096));
         if (lds > 65536) continue;
         for (int mode = 0; mode < 2; ++mode) for (int rep = 0; rep < 2; ++rep) {
             float ms;
             CK(hipEventRecord(e0));
             for (int i = 0; i < 10; ++i) {
-                if (mode == 0) hipLaunchKernelGGL(dma_stream<0>, dim3(blocks), dim3(256), lds, 0, (const float *)a, b, o, iters, stride);
-                else hipLaunchKernelGGL(dma_stream<1>, dim3(blocks), dim3(256), lds, 0, (const float *)a, b, o, iters, stride);
+                if (mode == 0) hipLaunchKernelGGL(dma_stream<0>, dim3(blocks), dim3(256), lds, 0, (const float *)a, b, o, iters, stride, (size_t)0);
+                else hipLaunchKernelGGL(dma_stream<1>, dim3(blocks), dim3(256), lds, 0, (const float *)a, b, o, iters, stride, (size_t)0);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1));
