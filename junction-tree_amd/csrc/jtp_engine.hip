@@ -63,7 +63,9 @@ static int comm_rank = 0, comm_size = 1;
 
 static int load() {
     if (lib) return JTP_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // JTP_RCCL_LIB: another library with the same eight entry points (tests/mock_rccl: several processes on
+    // one GPU exchanging through /dev/shm, to exercise the multi-rank path where there is no second GPU)
+    const char *names[] = {getenv("JTP_RCCL_LIB") ? getenv("JTP_RCCL_LIB") : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (lib) break;

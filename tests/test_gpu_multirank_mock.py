@@ -1,0 +1,123 @@
+"""The multi-rank path end to end on ONE GPU: W processes, each a rank with its share of the tree, real
+kernels and the real exchange schedule; only the transport is replaced - tests/mock_rccl moves the
+ncclSend/ncclRecv payloads through /dev/shm (JTP_RCCL_LIB), because RCCL refuses several ranks on one
+device and the test box has a single GPU.  Checks, over three consecutive propagates (the message arena
+alternates between its halves), every belief of every rank against the oracle, with the default
+dataflow launches and with one launch per level, with and without reduce tasks at the cuts."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+MOCK_SRC = os.path.join(HERE, "mock_rccl", "mock_rccl.cpp")
+MOCK_LIB = os.path.join(HERE, "mock_rccl", "libmockrccl.so")
+
+
+def _build_mock():
+    if not os.path.exists(MOCK_LIB) or os.path.getmtime(MOCK_LIB) < os.path.getmtime(MOCK_SRC):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-fPIC", "-shared", MOCK_SRC, "-o", MOCK_LIB])
+    return MOCK_LIB
+
+
+def _worker(rank, world, port_file, recipe, kwargs, opts, env, queue):
+    for p in (os.path.join(ROOT, "junction-tree_amd"), os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(env)
+    import ctypes as C
+    from junctiontree_amd import _capi, engine, partition, synthetic
+    from junctiontree_amd.rendezvous import Rendezvous
+    try:
+        lib = _capi.lib()
+        rdzv = Rendezvous(rank, world, "127.0.0.1", 0, timeout=120.0, port_file=port_file)
+        uid = None
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            _capi.check(lib.jtp_comm_unique_id(buf))
+            uid = buf.raw
+        uid = rdzv.broadcast(uid)
+        _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid), 0))
+        spec = getattr(synthetic, recipe)(**kwargs)
+        n = spec["n_cliques"]
+        weights = [float(np.prod([spec["sizes"][v] for v in spec["node_vars"][c]])) for c in range(n)]
+        owner = partition.subtree_owners(spec["parent"], weights, world)
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", n_ranks=world, rank=rank,
+                           owner=owner, **opts)
+        results = []
+        for rep in range(3):
+            pots = synthetic.potentials_for(spec, seed=40 + rep)
+            for c in range(n):
+                if owner[c] == rank:
+                    plan.set_potential(c, pots[c])
+            rdzv.barrier()
+            plan.propagate()
+            mine = {c: plan.belief(c) for c in range(n) if owner[c] == rank}
+            z = plan.z() if plan.owns(plan.root) else None
+            results.append((mine, z))
+        n_comm = len(plan.describe()["comm"])
+        fallbacks = plan.stats()["flow_fallbacks"]
+        plan.close()
+        rdzv.barrier()
+        lib.jtp_comm_destroy()
+        rdzv.close()
+        queue.put((rank, "ok", results, owner, n_comm, fallbacks))
+    except Exception as exc:                        # noqa: BLE001
+        queue.put((rank, "error", repr(exc), None, 0, 0))
+        raise
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,recipe,kwargs,opts,env", [
+    (2, "wide_binary_tree", {"n_cliques": 15, "width": 13, "sep": 6, "card": 2, "seed": 1}, {}, {}),
+    (4, "wide_binary_tree", {"n_cliques": 31, "width": 14, "sep": 7, "card": 2, "seed": 2}, {"block_log2": 11}, {"JTP_REDUCE_MIN": "2"}),
+    (3, "random_tree", {"n_cliques": 14, "width": 11, "sep": 5, "card": 2, "seed": 3}, {"level_launches": True}, {}),
+    (2, "chain_tree", {"n_cliques": 9, "card": 8, "width": 3}, {}, {}),
+])
+def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opts, env, tmp_path):
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import jt_oracle as oracle
+    from junctiontree_amd import synthetic
+
+    env = dict(env, JTP_RCCL_LIB=_build_mock())
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port_file = str(tmp_path / "rdzv_port")
+    procs = [ctx.Process(target=_worker, args=(r, world, port_file, recipe, kwargs, opts, env, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            rank, status, results, owner, n_comm, fallbacks = queue.get(timeout=300)
+            assert status == "ok", results
+            got[rank] = (results, owner, n_comm, fallbacks)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    spec = getattr(synthetic, recipe)(**kwargs)
+    n = spec["n_cliques"]
+    owner = got[0][1]
+    assert len(set(owner)) == world
+    for rep in range(3):
+        pots = synthetic.potentials_for(spec, seed=40 + rep)
+        want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+        seen = {}
+        for rank in range(world):
+            mine, zr = got[rank][0][rep]
+            seen.update(mine)
+            if zr is not None:
+                assert abs(zr - z) <= 1e-11 * abs(z)
+        assert sorted(seen) == list(range(n))
+        for c in range(n):
+            np.testing.assert_allclose(seen[c], want[c], rtol=1e-11, atol=1e-13 * np.max(np.abs(want[c])))
+    cuts = sum(1 for c in range(n) if spec["parent"][c] >= 0 and owner[c] != owner[spec["parent"][c]])
+    assert sum(got[r][2] for r in range(world)) == 4 * cuts and cuts >= world - 1
+    assert all(got[r][3] == 0 for r in range(world))
