@@ -608,6 +608,14 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
     *(volatile uint32_t *)pl->host_abort = 0;
     pl->flow = false;
     pl->flow_fallbacks++;
+    if (pl->hp.n_ranks > 1) {
+        // the other ranks have moved on with whatever this rank sent them: no local repair is possible
+        for (auto s : pl->streams) (void)hipStreamSynchronize(s);
+        for (auto &b : pl->bufs) b.unchecked = false;
+        return set_err(JTP_EHIP, "a dataflow launch of rank %d timed out waiting for a message (is the GPU shared with other "
+                                 "work? then set JTP_FLOW_TICKETS=1); the results of this propagate are invalid on every rank; "
+                                 "this plan launches per level from now on", pl->hp.rank);
+    }
     for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
     for (size_t i = 0; i < pl->bufs.size(); ++i) {
         BatchBuffers &b = pl->bufs[i];
@@ -712,7 +720,9 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         // workgroup should start, and the other way round (seen: --batch 4 hit the 2 s time-out).  A
         // ticket is drawn by a workgroup that is already running, so the lowest unfinished record of every
         // kernel is always being worked on, whatever else shares the device.
-        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->streams.size() > 1;
+        // (JTP_FLOW_TICKETS=1 in the environment: for processes that share their GPU with other work)
+        static const bool env_tickets = getenv("JTP_FLOW_TICKETS") && atoi(getenv("JTP_FLOW_TICKETS"));
+        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->streams.size() > 1 || env_tickets;
         for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {
             if (st.kind == 0 && flow) {
                 const Segment &sg = hp.segments[st.first];

@@ -83,7 +83,8 @@ def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opt
     import jt_oracle as oracle
     from junctiontree_amd import synthetic
 
-    env = dict(env, JTP_RCCL_LIB=_build_mock())
+    # (ranks share the GPU here: ticket order, see DESIGN.md 5 - on a GPU of its own a rank runs blockIdx order)
+    env = dict(env, JTP_RCCL_LIB=_build_mock(), JTP_FLOW_TICKETS="1")
     ctx = mp.get_context("spawn")
     queue = ctx.Queue()
     port_file = str(tmp_path / "rdzv_port")
