@@ -109,6 +109,8 @@ def main():
     if ndev <= 0:
         raise SystemExit("no HIP device visible: bench.py measures the GPU path only")
     device = local_rank % ndev                      # one process per GPU (ranks > GPUs only in smoke runs)
+    if world > ndev:                                # ranks sharing a GPU: dataflow launches need ticket order
+        os.environ["JTP_FLOW_TICKETS"] = "1"
 
     from junctiontree_amd.rendezvous import Rendezvous
     master_port = int(os.environ.get("MASTER_PORT", "29500"))

@@ -200,6 +200,9 @@ int jtp_get_stats(jtp_plan *plan, jtp_stats *stats);
 int jtp_get_launch_ms(jtp_plan *plan, double *ms, int32_t n);
 /* Diagnostic: copy `n` doubles at offset `off` of evidence set `batch`'s message arena to the host. */
 int jtp_debug_read_msg(jtp_plan *plan, int32_t batch, int64_t off, int64_t n, double *host);
+/* Test hooks.  knob "flow_debug": JtFlow::dbg of the following propagates (8 = every dataflow wait times
+ * out after 20 ms: exercises the fall-back to one launch per level); "flow": 0 = launch per level from now on. */
+int jtp_debug_set(jtp_plan *plan, const char *knob, int64_t value);
 /* Name of kernel variant i as it appears in rocprofv3 traces, or NULL past the last one. */
 const char *jtp_kernel_name(int32_t variant);
 

@@ -163,9 +163,16 @@ struct MargBatch {
     }
 };
 
+// device plans alive in this process, per device: dataflow kernels of two plans running at once need
+// ticket order (see jtp_propagate)
+static int g_live_plans[64];
+
 struct jtp_plan {
     HostPlan hp;
     bool device = false;
+    bool counted = false;           // included in g_live_plans
+    uint32_t flow_debug = 0;        // JTP_FLOW_DEBUG at plan creation, or jtp_debug_set(plan, "flow_debug", v)
+    bool env_tickets = false;       // JTP_FLOW_TICKETS at plan creation
     std::vector<hipStream_t> streams;
     std::vector<BatchBuffers> bufs;
     JtTask *d_tasks = nullptr;
@@ -249,6 +256,7 @@ const char *jtp_kernel_name(int32_t variant) {
 
 void jtp_plan_destroy(jtp_plan *pl) {
     if (!pl) return;
+    if (pl->counted) g_live_plans[pl->hp.device & 63]--;
     if (pl->device) {
         (void)hipSetDevice(pl->hp.device);
         for (auto s : pl->streams) (void)hipStreamSynchronize(s);
@@ -323,6 +331,8 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         }                                                                                                \
     } while (0)
     pl->device = true;
+    pl->flow_debug = getenv("JTP_FLOW_DEBUG") ? (uint32_t)atoi(getenv("JTP_FLOW_DEBUG")) : 0u;
+    pl->env_tickets = getenv("JTP_FLOW_TICKETS") && atoi(getenv("JTP_FLOW_TICKETS"));
     CREATE_TRY(hipSetDevice(hp.device));
     const int nstreams = std::min(hp.n_batch, 16);
     pl->streams.resize(nstreams);
@@ -380,6 +390,8 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     }
     CREATE_TRY(hipStreamSynchronize(pl->streams[0]));
 #undef CREATE_TRY
+    g_live_plans[hp.device & 63]++;
+    pl->counted = true;
     *out = pl;
     return JTP_OK;
 }
@@ -617,8 +629,11 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
                                  "this plan launches per level from now on", pl->hp.rank);
     }
     for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
+    // only the sets that are run again lose their messages: a set whose propagate was already checked keeps
+    // its arena (its separator beliefs are read from there), and no later launch of this plan waits on markers
     for (size_t i = 0; i < pl->bufs.size(); ++i) {
         BatchBuffers &b = pl->bufs[i];
+        if (!b.unchecked) continue;
         HIP_TRY(hipMemset(b.sync, 0, (size_t)pl->hp.sync_words * 4));
         HIP_TRY(hipMemsetD32((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 4));
         b.epoch = 0;
@@ -631,6 +646,23 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
         if (rc) return rc;
     }
     for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
+    return JTP_OK;
+}
+
+// Before anything is read out: if a dataflow propagate of this evidence set has not been checked yet, wait
+// for it and look at the abort flag FIRST, so that a propagate that had to be run again per level is run
+// again before the read-out kernels copy anything (they used to copy the aborted propagate's data).
+static int settle(jtp_plan *pl, int batch) {
+    if (!pl->bufs[batch].unchecked) return JTP_OK;
+    HIP_TRY(hipStreamSynchronize(pl->streams[batch % pl->streams.size()]));
+    return check_flow(pl, batch);
+}
+
+int jtp_debug_set(jtp_plan *pl, const char *knob, int64_t value) {
+    if (!pl || !knob) return set_err(JTP_EINVAL, "null argument");
+    if (!strcmp(knob, "flow_debug")) pl->flow_debug = (uint32_t)value;      // fault injection (tests): see JtFlow::dbg
+    else if (!strcmp(knob, "flow")) pl->flow = value != 0 && !pl->hp.segments.empty();
+    else return set_err(JTP_EINVAL, "unknown knob %s", knob);
     return JTP_OK;
 }
 
@@ -709,7 +741,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         fl.cur_off = bb.cur_off(half);
         // (a plan that launches per level never waits on entries: it need not mark the other half)
         fl.oth_off = pl->flow ? half - fl.cur_off : -1;
-        fl.dbg = getenv("JTP_FLOW_DEBUG") ? (uint32_t)atoi(getenv("JTP_FLOW_DEBUG")) : 0u;
+        fl.dbg = pl->flow_debug;
         fl.ev = bb.ev;
         if (flow) {
             bb.flow_runs++;
@@ -720,9 +752,11 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         // workgroup should start, and the other way round (seen: --batch 4 hit the 2 s time-out).  A
         // ticket is drawn by a workgroup that is already running, so the lowest unfinished record of every
         // kernel is always being worked on, whatever else shares the device.
-        // (JTP_FLOW_TICKETS=1 in the environment: for processes that share their GPU with other work)
-        static const bool env_tickets = getenv("JTP_FLOW_TICKETS") && atoi(getenv("JTP_FLOW_TICKETS"));
-        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->streams.size() > 1 || env_tickets;
+        // The same holds for two plans of one process whose propagates overlap (plan_for caches plans, each on
+        // its own stream), hence tickets whenever another device plan is alive on this device.
+        // (JTP_FLOW_TICKETS=1 in the environment: for processes that share their GPU with other processes)
+        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->streams.size() > 1 || pl->env_tickets ||
+                             g_live_plans[hp.device & 63] > 1;
         for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {
             if (st.kind == 0 && flow) {
                 const Segment &sg = hp.segments[st.first];
@@ -795,6 +829,8 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
     if (node < 0 || node >= hp.n_nodes) return set_err(JTP_EINVAL, "node %d out of range", node);
     if (host_dtype != JTP_F32 && host_dtype != JTP_F64) return set_err(JTP_EINVAL, "bad host dtype");
     HIP_TRY(hipSetDevice(hp.device));
+    rc = settle(pl, batch);
+    if (rc) return rc;
     hipStream_t s = pl->streams[batch % pl->streams.size()];
     BatchBuffers &b = pl->bufs[batch];
     const size_t hsz = host_dtype == JTP_F32 ? 4 : 8;
@@ -851,86 +887,25 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
     return check_flow(pl, batch);
 }
 
+int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cliques, const int32_t *var_off,
+                      const int32_t *var_ids, const int64_t *out_off, double *host);
+
+// One marginal = a request list of one (its device tables are kept with the plan like any other list's:
+// no allocation per call, nothing to leak on an error path).
 int jtp_get_marginal(jtp_plan *pl, int32_t batch, int32_t clique, const int32_t *out_vars, int32_t n_out, double *host) {
     int rc = check_ready(pl, batch);
     if (rc) return rc;
-    HostPlan &hp = pl->hp;
-    if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
-    if (hp.pn[clique].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
-    if (n_out < 0 || n_out > JT_MAX_VARS) return set_err(JTP_EINVAL, "bad variable count");
-    std::vector<int> ov(out_vars, out_vars + n_out);
-    for (int i = 0; i < n_out; ++i)
-        for (int j = 0; j < i; ++j)
-            if (ov[i] == ov[j]) return set_err(JTP_EINVAL, "variable %d requested twice", ov[i]);
-    JtTask tk;
-    int out_bits = 0, npart = 1;
-    std::vector<JtBlock> blocks;
-    std::vector<int32_t> itab;
-    std::string err;
-    rc = jtp_plan_marginal_task(hp, clique, ov, tk, itab, out_bits, npart, blocks, err);
-    if (rc) return set_err(rc, "%s", err.c_str());
-    HIP_TRY(hipSetDevice(hp.device));
-    hipStream_t s = pl->streams[batch % pl->streams.size()];
-    BatchBuffers &b = pl->bufs[batch];
-    const int64_t pstride = (int64_t)1 << out_bits;
-    double *scratch = nullptr;
-    JtTask *d_task = nullptr;
-    JtBlock *d_blk = nullptr;
-    int *d_tab = nullptr;
-    HIP_TRY(hipMalloc((void **)&scratch, (size_t)pstride * npart * 8));
-    HIP_TRY(hipMalloc((void **)&d_tab, itab.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpyAsync(d_tab, itab.data(), itab.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMalloc((void **)&d_task, sizeof(JtTask)));
-    HIP_TRY(hipMalloc((void **)&d_blk, blocks.size() * sizeof(JtBlock)));
-    tk.msg[JT_MAX_IN].off = 0;
-    HIP_TRY(hipMemcpyAsync(d_task, &tk, sizeof tk, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_blk, blocks.data(), blocks.size() * sizeof(JtBlock), hipMemcpyHostToDevice, s));
-    if (tk.lds_bytes > 64 * 1024) {
-        const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_COLLECT0) : (const void *)KernelTable<double>::get(JT_K_COLLECT0);
-        HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tk.lds_bytes));
+    if (n_out < 0 || n_out > JT_MAX_VARS || (n_out > 0 && !out_vars) || !host) return set_err(JTP_EINVAL, "bad variable list");
+    if (clique < 0 || clique >= pl->hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
+    int64_t elems = 1;
+    for (int i = 0; i < n_out; ++i) {
+        if (out_vars[i] < 0 || out_vars[i] >= pl->hp.n_vars) return set_err(JTP_EINVAL, "variable %d out of range", out_vars[i]);
+        elems *= pl->hp.card[out_vars[i]];
     }
-    // marginalise the BELIEF table: it is the "potential" argument of a childless collect
-    JtFlow plain;
-    memset(&plain, 0, sizeof plain);
-    plain.oth_off = -1;                      // a one-off output buffer: one half, nothing to mark
-    launch_variant(pl, JT_K_COLLECT0, (int)blocks.size(), tk.lds_bytes, s, d_task, d_blk, d_tab, b.bel, b.bel, scratch, plain);
-    HIP_TRY(hipGetLastError());
-    JtPackDesc d;
-    memset(&d, 0, sizeof d);
-    d.nvars = n_out;
-    d.nbits = out_bits;
-    int64_t stride = 1;
-    {
-        int bit = 0;
-        std::vector<int> pos(n_out);
-        for (int i = n_out - 1; i >= 0; --i) {           // last requested variable = lowest bits
-            pos[i] = bit;
-            bit += hp.vbits[ov[i]];
-        }
-        for (int i = n_out - 1; i >= 0; --i) {
-            d.pos[i] = (uint8_t)pos[i];
-            d.nb[i] = (uint8_t)hp.vbits[ov[i]];
-            d.card[i] = hp.card[ov[i]];
-            d.hstride[i] = stride;
-            stride *= hp.card[ov[i]];
-        }
-    }
-    d.host_elems = stride;
-    rc = ensure_stage(pl, (size_t)stride * 8);
-    if (rc == JTP_OK) {
-        const int grid = (int)std::min<int64_t>((stride + 255) / 256, 4096);
-        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, scratch, npart, (const double *)nullptr, 0, pstride, (double *)pl->stage);
-        hipError_t e1 = hipGetLastError();
-        hipError_t e2 = hipMemcpyAsync(host, pl->stage, (size_t)stride * 8, hipMemcpyDeviceToHost, s);
-        hipError_t e3 = hipStreamSynchronize(s);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
-            rc = set_err(JTP_EHIP, "marginal read-back failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
-    }
-    (void)hipFree(scratch);
-    (void)hipFree(d_task);
-    (void)hipFree(d_blk);
-    (void)hipFree(d_tab);
-    return rc != JTP_OK ? rc : check_flow(pl, batch);
+    const int32_t var_off[2] = {0, n_out};
+    const int64_t out_off[2] = {0, elems};
+    const int32_t none = 0;
+    return jtp_get_marginals(pl, batch, 1, &clique, var_off, n_out > 0 ? out_vars : &none, out_off, host);
 }
 
 int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cliques, const int32_t *var_off,
@@ -948,6 +923,8 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
     }
     HostPlan &hp = pl->hp;
     HIP_TRY(hipSetDevice(hp.device));
+    rc = settle(pl, batch);
+    if (rc) return rc;
     hipStream_t s = pl->streams[batch % pl->streams.size()];
     BatchBuffers &b = pl->bufs[batch];
     std::vector<int32_t> key;
@@ -956,8 +933,13 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
     for (int i = 0; i <= n; ++i) key.push_back(var_off[i] - var_off[0]);
     key.insert(key.end(), var_ids + var_off[0], var_ids + var_off[n]);
     MargBatch *mb = nullptr;
-    for (MargBatch *c : pl->marg_cache)
-        if (c->key == key) mb = c;
+    for (size_t i = 0; i < pl->marg_cache.size(); ++i)
+        if (pl->marg_cache[i]->key == key) {                // most recently used last
+            mb = pl->marg_cache[i];
+            pl->marg_cache.erase(pl->marg_cache.begin() + i);
+            pl->marg_cache.push_back(mb);
+            break;
+        }
     if (!mb) {
         std::vector<JtTask> tasks;
         std::vector<JtBlock> blocks;
@@ -1045,7 +1027,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
             delete mb;
             return set_err(e == hipErrorOutOfMemory ? JTP_ENOMEM : JTP_EHIP, "marginal tables: %s", hipGetErrorString(e));
         }
-        if (pl->marg_cache.size() >= 4) {                   // a model asks for one or two lists; keep the last few
+        if (pl->marg_cache.size() >= 32) {                  // a model asks for a few lists (and Z); keep the last used
             pl->marg_cache.front()->release();
             delete pl->marg_cache.front();
             pl->marg_cache.erase(pl->marg_cache.begin());

@@ -896,35 +896,38 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         hp.launches.push_back(L);
         hp.steps.push_back(st);
     };
-    for (int level = maxdepth; level >= 0; --level) {          // collect
-        for (int c : by_level(level)) {                        // receive what this level consumes
-            if (hp.pn[c].owner != hp.rank) continue;
-            for (int k : hp.pn[c].children)
-                if (hp.pn[k].owner != hp.rank) comm_op(0, hp.pn[k].psep, 1, hp.pn[k].owner);
+    // Exchange order: ncclSend/ncclRecv (and every transport standing in for them) pair the operations
+    // between two ranks in ISSUE order, so both sides of a cut must enumerate the cut edges of one level
+    // in the same order whatever the numbering of the cliques: always by the CHILD clique of the edge
+    // (ascending), never by the parent's position.
+    auto cut_children = [&](int child_level, bool mine_is_child) {
+        std::vector<int> v;                                    // children (ascending) of cut edges at this level
+        for (int k : by_level(child_level)) {
+            const PNode &ch = hp.pn[k];
+            if (ch.parent < 0) continue;
+            const int po = hp.pn[ch.parent].owner;
+            if (po == ch.owner) continue;
+            if (mine_is_child ? ch.owner == hp.rank : po == hp.rank) v.push_back(k);
         }
+        return v;
+    };
+    for (int level = maxdepth; level >= 0; --level) {          // collect
+        for (int k : cut_children(level + 1, false))           // receive what this level consumes
+            comm_op(0, hp.pn[k].psep, 1, hp.pn[k].owner);
         if (level >= 1) {
             emit_launches(0, level);
             emit_reduce(0, level);
         }
-        for (int c : by_level(level)) {                        // send what this level produced
-            const PNode &p = hp.pn[c];
-            if (p.owner != hp.rank || p.parent < 0) continue;
-            if (hp.pn[p.parent].owner != hp.rank) comm_op(1, p.psep, 1, hp.pn[p.parent].owner);
-        }
+        for (int c : cut_children(level, true))                // send what this level produced
+            comm_op(1, hp.pn[c].psep, 1, hp.pn[hp.pn[c].parent].owner);
     }
     for (int level = 0; level <= maxdepth; ++level) {          // distribute
-        for (int c : by_level(level)) {
-            const PNode &p = hp.pn[c];
-            if (p.owner != hp.rank || p.parent < 0) continue;
-            if (hp.pn[p.parent].owner != hp.rank) comm_op(0, p.psep, 0, hp.pn[p.parent].owner);
-        }
+        for (int c : cut_children(level, true))
+            comm_op(0, hp.pn[c].psep, 0, hp.pn[hp.pn[c].parent].owner);
         emit_launches(1, level);
         emit_reduce(1, level);
-        for (int c : by_level(level)) {
-            if (hp.pn[c].owner != hp.rank) continue;
-            for (int k : hp.pn[c].children)
-                if (hp.pn[k].owner != hp.rank) comm_op(1, hp.pn[k].psep, 0, hp.pn[k].owner);
-        }
+        for (int k : cut_children(level + 1, false))
+            comm_op(1, hp.pn[k].psep, 0, hp.pn[k].owner);
     }
     flush_comm();
     // ---- dataflow schedule: runs of launches of one phase become one segment --------------------

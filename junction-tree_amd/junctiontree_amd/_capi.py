@@ -101,6 +101,7 @@ SYMBOLS = {
     "jtp_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "jtp_get_launch_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "jtp_debug_read_msg": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
+    "jtp_debug_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "jtp_kernel_name": (C.c_char_p, [C.c_int32]),
     "jtp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "jtp_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),

@@ -267,6 +267,10 @@ class Plan:
         _capi.check(self._lib.jtp_set_profiling_granularity(self._handle, 1 if per_launch else 0))
         _capi.check(self._lib.jtp_set_profiling(self._handle, int(keep)))
 
+    def debug_set(self, knob, value):
+        """Test hook (`jtp_debug_set`): e.g. ("flow_debug", 8) makes every dataflow wait time out."""
+        _capi.check(self._lib.jtp_debug_set(self._handle, knob.encode(), int(value)))
+
     def launch_ms(self):
         """Mean device time of every launch of the schedule (ms), with its description."""
         d = self.describe()
@@ -331,7 +335,9 @@ def plan_for(tree, node_vars, sizes, dtype, **kwargs):
     plan = _cache.get(key)
     if plan is None:
         if len(_cache) >= 16:
-            _cache.pop(next(iter(_cache))).close()
+            # forget the oldest; it is destroyed when its last holder lets go (JunctionTree.plan() hands
+            # these objects out, so closing here could pull a plan from under its user)
+            _cache.pop(next(iter(_cache)))
         plan = Plan(tree, node_vars, sizes, dtype=dtype, **kwargs)
         _cache[key] = plan
     return plan

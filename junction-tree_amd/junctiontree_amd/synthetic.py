@@ -121,6 +121,30 @@ def random_tree(n_cliques=64, width=12, sep=6, card=2, seed=0):
     return _grow(parent, width, sep, card, rng)
 
 
+def renumber(spec, perm):
+    """The same junction tree with clique c renamed perm[c] (separators keep their numbers): the
+    numbering `construct_junction_tree` produces is arbitrary, the recipes above number breadth first.
+    `parent` and `scales` follow the new numbering; the root is perm[0]."""
+    n = spec["n_cliques"]
+    perm = [int(x) for x in perm]
+    assert sorted(perm) == list(range(n))
+    old_parent = spec["parent"]
+    kids = [[] for _ in range(n)]
+    for c in range(1, n):
+        kids[old_parent[c]].append(c)
+    sub = [None] * n
+    for c in range(n - 1, -1, -1):          # children have larger OLD indices
+        sub[c] = [perm[c]] + [(n + k - 1, sub[k]) for k in kids[c]]
+    node_vars = [None] * n + [list(v) for v in spec["node_vars"][n:]]
+    parent, scales = [None] * n, [None] * n
+    for c in range(n):
+        node_vars[perm[c]] = list(spec["node_vars"][c])
+        parent[perm[c]] = perm[old_parent[c]] if old_parent[c] >= 0 else -1
+        scales[perm[c]] = spec["scales"][c]
+    return {"tree": sub[0], "n_cliques": n, "node_vars": node_vars, "sizes": dict(spec["sizes"]),
+            "parent": parent, "scales": scales}
+
+
 def potentials_for(spec, seed=1, dtype=np.float64):
     """Clique potentials for a spec from the recipes above (scaled so Z is O(1)) followed
     by all-ones separators, i.e. the `potentials` list `compute_beliefs` expects."""

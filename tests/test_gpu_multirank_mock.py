@@ -23,6 +23,15 @@ def _build_mock():
     return MOCK_LIB
 
 
+def _spec(synthetic, recipe, kwargs):
+    kwargs = dict(kwargs)
+    perm_seed = kwargs.pop("renumber", None)
+    spec = getattr(synthetic, recipe)(**kwargs)
+    if perm_seed is not None:           # arbitrary clique numbering (the recipes number breadth first)
+        spec = synthetic.renumber(spec, np.random.default_rng(perm_seed).permutation(spec["n_cliques"]))
+    return spec
+
+
 def _worker(rank, world, port_file, recipe, kwargs, opts, env, queue):
     for p in (os.path.join(ROOT, "junction-tree_amd"), os.path.join(ROOT, "oracle"), HERE):
         if p not in sys.path:
@@ -41,7 +50,7 @@ def _worker(rank, world, port_file, recipe, kwargs, opts, env, queue):
             uid = buf.raw
         uid = rdzv.broadcast(uid)
         _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid), 0))
-        spec = getattr(synthetic, recipe)(**kwargs)
+        spec = _spec(synthetic, recipe, kwargs)
         n = spec["n_cliques"]
         weights = [float(np.prod([spec["sizes"][v] for v in spec["node_vars"][c]])) for c in range(n)]
         owner = partition.subtree_owners(spec["parent"], weights, world)
@@ -76,6 +85,7 @@ def _worker(rank, world, port_file, recipe, kwargs, opts, env, queue):
     (4, "wide_binary_tree", {"n_cliques": 31, "width": 14, "sep": 7, "card": 2, "seed": 2}, {"block_log2": 11}, {"JTP_REDUCE_MIN": "2"}),
     (3, "random_tree", {"n_cliques": 14, "width": 11, "sep": 5, "card": 2, "seed": 3}, {"level_launches": True}, {}),
     (2, "chain_tree", {"n_cliques": 9, "card": 8, "width": 3}, {}, {}),
+    (3, "random_tree", {"n_cliques": 26, "width": 11, "sep": 5, "card": 2, "seed": 8, "renumber": 2}, {}, {}),
 ])
 def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opts, env, tmp_path):
     import multiprocessing as mp
@@ -103,7 +113,7 @@ def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opt
             if p.is_alive():
                 p.kill()
     assert all(p.exitcode == 0 for p in procs)
-    spec = getattr(synthetic, recipe)(**kwargs)
+    spec = _spec(synthetic, recipe, kwargs)
     n = spec["n_cliques"]
     owner = got[0][1]
     assert len(set(owner)) == world

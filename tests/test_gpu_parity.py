@@ -543,27 +543,52 @@ def test_launch_modes_are_bit_identical():
             assert np.array_equal(a, b)
 
 
-def test_dataflow_timeout_falls_back_to_level_launches(monkeypatch):
-    """Fault injection: every dataflow wait times out (JTP_FLOW_DEBUG=8).  The host must notice at the
-    next synchronisation, run the propagate again with one launch per level, and keep doing so."""
+def test_dataflow_timeout_falls_back_to_level_launches():
+    """Fault injection: every dataflow wait times out (flow_debug 8).  The host must notice at the
+    next synchronisation - or at the next READ-OUT when the caller did not synchronise - run the propagate
+    again with one launch per level, and keep doing so."""
     spec = synthetic.wide_binary_tree(n_cliques=15, width=13, sep=6, card=2, seed=8)
     pots = synthetic.potentials_for(spec, seed=31)
     want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
-    for tickets in (False, True):
+    for tickets, sync in ((False, True), (True, True), (False, False)):
         plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", flow_tickets=tickets)
         for c in range(spec["n_cliques"]):
             plan.set_potential(c, pots[c])
         plan.propagate()
         assert plan.stats()["flow_fallbacks"] == 0 and plan.stats()["n_launches"] == 2
-        monkeypatch.setenv("JTP_FLOW_DEBUG", "8")
-        plan.propagate()
-        monkeypatch.delenv("JTP_FLOW_DEBUG")
-        for node in range(len(spec["node_vars"])):
-            close(plan.belief(node), want[node], what="node %d" % node)
+        for c in range(spec["n_cliques"]):
+            plan.set_potential(c, 2.0 * pots[c])           # the aborted propagate must not leave ITS OLD results
+        plan.debug_set("flow_debug", 8)
+        plan.propagate(sync=sync)
+        plan.debug_set("flow_debug", 0)
+        scale = 2.0 ** spec["n_cliques"]
+        for node in range(len(spec["node_vars"])):          # (sync=False: the read-out itself has to notice)
+            close(plan.belief(node), scale * want[node], what="node %d" % node)
         assert plan.stats()["flow_fallbacks"] == 1 and plan.stats()["n_launches"] > 2
         plan.propagate()
-        assert abs(plan.z() - z) <= 1e-11 * abs(z) and plan.stats()["flow_fallbacks"] == 1
+        assert abs(plan.z() - scale * z) <= 1e-11 * abs(scale * z) and plan.stats()["flow_fallbacks"] == 1
         plan.close()
+
+
+def test_fallback_keeps_the_messages_of_sets_already_checked():
+    """A time-out in one evidence set must not wipe the separator messages of a set whose propagate had
+    already been checked (round-1 defect: its separator beliefs then read as marker NaNs)."""
+    spec = synthetic.wide_binary_tree(n_cliques=7, width=12, sep=6, card=2, seed=3)
+    pots = synthetic.potentials_for(spec, seed=2)
+    want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", n_batch=2)
+    for b in range(2):
+        for c in range(spec["n_cliques"]):
+            plan.set_potential(c, pots[c], batch=b)
+    plan.propagate(0, 1)                                     # set 0: finished and checked
+    plan.debug_set("flow_debug", 8)
+    plan.propagate(1, 2)                                     # set 1: times out, is run again per level
+    plan.debug_set("flow_debug", 0)
+    assert plan.stats()["flow_fallbacks"] == 1
+    for b in (1, 0):
+        for node in range(len(spec["node_vars"])):
+            close(plan.belief(node, batch=b), want[node], what="batch %d node %d" % (b, node))
+    plan.close()
 
 
 @pytest.mark.parametrize("share", [True, False])

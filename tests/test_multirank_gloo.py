@@ -36,7 +36,11 @@ def _worker(rank, world, port, recipe, kwargs, queue):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        kwargs = dict(kwargs)
+        perm_seed = kwargs.pop("renumber", None)
         spec = getattr(synthetic, recipe)(**kwargs)
+        if perm_seed is not None:       # arbitrary clique numbering, as construct_junction_tree produces
+            spec = synthetic.renumber(spec, np.random.default_rng(perm_seed).permutation(spec["n_cliques"]))
         n = spec["n_cliques"]
         weights = [float(np.prod([spec["sizes"][v] for v in spec["node_vars"][c]])) for c in range(n)]
         owner = partition.subtree_owners(spec["parent"], weights, world)
@@ -88,7 +92,7 @@ def _worker(rank, world, port, recipe, kwargs, queue):
             assert sorted(seen) == list(range(n))
             for c in range(n):
                 np.testing.assert_allclose(seen[c], want[c], rtol=1e-11, atol=1e-14)
-            cuts = sum(1 for c in range(1, n) if owner[c] != owner[spec["parent"][c]])
+            cuts = sum(1 for c in range(n) if spec["parent"][c] >= 0 and owner[c] != owner[spec["parent"][c]])
             # every cut edge carries one message up and one down, seen once by each side
             assert sum(g[1] for g in gathered) == 4 * cuts
             queue.put(("ok", cuts))
@@ -103,6 +107,7 @@ def _worker(rank, world, port, recipe, kwargs, queue):
     ("wide_binary_tree", {"n_cliques": 15, "width": 12, "sep": 6, "card": 2, "seed": 1}),
     ("random_tree", {"n_cliques": 14, "width": 11, "sep": 5, "card": 2, "seed": 3}),
     ("wide_binary_tree", {"n_cliques": 15, "width": 13, "sep": 6, "card": 2, "seed": 4, "reduce_min": "2"}),
+    ("random_tree", {"n_cliques": 24, "width": 10, "sep": 4, "card": 2, "seed": 7, "renumber": 5}),
 ])
 def test_two_rank_exchange_schedule(recipe, kwargs, monkeypatch):
     import multiprocessing as mp

@@ -228,3 +228,50 @@ def test_random_trees_mixed_cardinalities(seed):
     spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 14)))
     opts = [{}, {"block_log2": 10}, {"layout_policy": 1}, {"keep_root": True}][seed % 4]
     check(spec["tree"], pots, spec["node_vars"], spec["sizes"], **opts)
+
+
+def _comm_sequences(tree, node_vars, sizes, owner, world, **opts):
+    """Per (src, dst): the separators in the order src issues its sends to dst, and the order dst
+    issues its receives from src (an upward and a downward message of one separator are distinct)."""
+    sends, recvs = {}, {}
+    for rank in range(world):
+        plan = engine.Plan(tree, node_vars, sizes, dtype="f64", plan_only=True, n_ranks=world, rank=rank,
+                           owner=owner, **opts)
+        for op in plan.describe()["comm"]:
+            key = (rank, op["peer"]) if op["send"] else (op["peer"], rank)
+            (sends if op["send"] else recvs).setdefault(key, []).append((op["psep"], op["up"], op["count"]))
+        plan.close()
+    return sends, recvs
+
+
+def test_exchange_order_matches_on_both_sides_of_every_cut():
+    """ncclSend/ncclRecv pair operations between two ranks in issue order: for every ordered pair of
+    ranks the sender's sequence must equal the receiver's, whatever the clique numbering (round-1
+    defect: receivers enumerated by parent, senders by child)."""
+    # the advisor's reproducer: two same-level cut children whose parents are numbered the other way round
+    tree = [0, (5, [1, (7, [4])]), (6, [2, (8, [3])])]
+    node_vars = [[0, 1], [1, 2], [0, 3], [3, 4], [2, 5], [1], [0], [2], [3]]
+    sizes = {v: 2 + (v % 3) for v in range(6)}          # unequal separator sizes
+    sends, recvs = _comm_sequences(tree, node_vars, sizes, {0: 0, 1: 0, 2: 0, 3: 1, 4: 1}, 2)
+    assert sends and sends == recvs
+    rng = np.random.default_rng(11)
+    from junctiontree_amd import partition
+    for trial in range(12):
+        base = (synthetic.random_tree(n_cliques=int(rng.integers(8, 40)), width=6, sep=3, card=2, seed=trial)
+                if trial % 2 else synthetic.wide_binary_tree(n_cliques=int(rng.integers(8, 40)), width=6, sep=3, card=2, seed=trial))
+        spec = synthetic.renumber(base, rng.permutation(base["n_cliques"]))
+        world = int(rng.integers(2, 6))
+        if trial % 3 == 0:       # arbitrary owners (parts need not be connected): many cuts per pair
+            owner = [int(o) for o in rng.integers(0, world, spec["n_cliques"])]
+        else:
+            owner = partition.subtree_owners(spec["parent"], [1.0] * spec["n_cliques"], world)
+        for opts in ({}, {"keep_root": True}):
+            sends, recvs = _comm_sequences(spec["tree"], spec["node_vars"], spec["sizes"], owner, world, **opts)
+            assert sends == recvs, "trial %d" % trial
+
+
+def test_renumbered_tree_gives_the_same_beliefs():
+    base = synthetic.random_tree(n_cliques=9, width=7, sep=3, card=2, seed=3)
+    spec = synthetic.renumber(base, np.random.default_rng(0).permutation(9))
+    pots = synthetic.potentials_for(spec, seed=4)
+    check(spec["tree"], pots, spec["node_vars"], spec["sizes"])
