@@ -15,6 +15,9 @@ What is captured:
   evaluate.npz      CliqueGraph.evaluate cases of tests/test_junctiontree.py:38-109.
   refsafe.npz       small synthetic trees from junctiontree_amd.synthetic run through the
                     reference with the colouring protocol of SURVEY.md Appendix C.
+  apply_evidence.npz  computation.apply_evidence (computation.py:11-34) on the inputs of
+                    tests/test_computation.py:377-408 (whose own checks lack the `assert`) and on
+                    further evidence sets, scalar and 0-d potentials included.
   divergent.npz     inputs on which the reference itself is wrong or raises (Appendix B),
                     with brute-force truth, so nobody "fixes" the engine to match them.
 Each .npz holds a JSON string `meta` plus numbered arrays.
@@ -438,6 +441,37 @@ def gen_divergent():
     b.save("divergent.npz")
 
 
+# --------------------------------------------------------------------------- apply_evidence
+
+def gen_apply_evidence():
+    """Outputs of the reference's `apply_evidence` (computation.py:11-34).  Shapes and variables of
+    the first case are DATA of tests/test_computation.py:377-408; the reference's test computes
+    `np.allclose(...)` without asserting, so these captured outputs are what pins the function."""
+    b = Bundle()
+    rng = np.random.default_rng(77)
+    shapes = [(2, 3, 6), (3, 4), (2, 5), (3,), (2,), (6,), (4, 6)]
+    variables = [[3, 5, 7], [5, 9], [3, 1], [5], [3], [7], [2, 7]]
+    cases = []
+    for name, evidence in (("reference_test", {3: 0, 9: 2}), ("none", {}), ("one_last_state", {7: 5}),
+                           ("every_variable", {3: 1, 5: 2, 7: 0, 9: 3, 1: 4, 2: 0}), ("absent_variable", {42: 1})):
+        pots = [rng.standard_normal(s) for s in shapes]
+        out = ref_comp.apply_evidence(pots, variables, evidence)
+        assert all(isinstance(o, list) and len(o) == 1 for o in out)
+        cases.append({"name": name, "variables": variables, "evidence": [[k, v] for k, v in evidence.items()],
+                      "potentials": b.put_list(pots), "ref": b.put_list([o[0] for o in out]),
+                      "ref_types": ["ndarray" if isinstance(o[0], np.ndarray) else type(o[0]).__name__ for o in out]})
+    # scalars: a Python float passes through, a 0-d array is indexed with ()
+    pots = [2.5, np.array(1.5), rng.standard_normal((2, 2))]
+    variables2 = [[], [], [4, 6]]
+    out = ref_comp.apply_evidence(pots, variables2, {4: 1})
+    cases.append({"name": "scalars", "variables": variables2, "evidence": [[4, 1]],
+                  "potentials": b.put_list(pots), "ref": b.put_list([o[0] for o in out]),
+                  "ref_types": ["ndarray" if isinstance(o[0], np.ndarray) else type(o[0]).__name__ for o in out],
+                  "scalar_inputs": [0]})
+    b.meta = {"cases": cases, "source": "junctiontree/computation.py:11-34"}
+    b.save("apply_evidence.npz")
+
+
 # --------------------------------------------------------------------------- timing check
 
 def timing_check():
@@ -465,9 +499,10 @@ if __name__ == "__main__":
         os.environ["PYTHONHASHSEED"] = "0"
         os.execv(sys.executable, [sys.executable] + sys.argv)
     os.makedirs(OUT, exist_ok=True)
-    gen_tree_cases()
-    gen_networks()
-    gen_evaluate()
-    gen_refsafe()
-    gen_divergent()
-    timing_check()
+    only = set(sys.argv[1:])            # e.g. `python oracle/gen_golden.py apply_evidence`: that fixture only
+    steps = [("tree_cases", gen_tree_cases), ("networks", gen_networks), ("evaluate", gen_evaluate),
+             ("refsafe", gen_refsafe), ("apply_evidence", gen_apply_evidence), ("divergent", gen_divergent),
+             ("timing", timing_check)]
+    for name, fn in steps:
+        if not only or name in only:
+            fn()

@@ -1,0 +1,153 @@
+"""BASELINE.json configs at their STATED shapes on a real MI355X, against the oracle (tolerances as in
+test_gpu_parity.close: float64 storage 1e-11, float32 storage 1e-6, elementwise):
+
+  configs[1]  chain of 1000 cliques, width 3, cardinality 64, float64 - every belief vs oracle.beliefs_exact
+  configs[2]  grid MRF, cardinality 8, float32: a 6 x 12 lattice (cliques up to 8^8 entries) vs the oracle, and
+              the full 6 x 167 lattice of SURVEY.md 8d (1002 variables, 9 GiB of tables) through properties
+  configs[4]  evidence sets on the full width-20 tree (256 x 2^20 float32, tables shared by the sets): Z and
+              sampled beliefs of four sets vs the oracle with indicator-multiplied potentials
+(configs[3], the width-20 tree itself, is test_gpu_parity.test_full_size_c4_properties and bench.py.)"""
+import numpy as np
+import pytest
+
+import jt_oracle as oracle
+import junctiontree_amd as jt
+from junctiontree_amd import engine, synthetic
+from test_gpu_parity import RTOL32, RTOL64, close
+
+pytestmark = pytest.mark.gpu
+
+
+def lattice(h, w, card, seed=0, dtype=np.float32):
+    names = {(i, j): i * w + j for i in range(h) for j in range(w)}
+    factors = []
+    for i in range(h):
+        for j in range(w):
+            if i + 1 < h:
+                factors.append([names[i, j], names[i + 1, j]])
+            if j + 1 < w:
+                factors.append([names[i, j], names[i, j + 1]])
+    sizes = {v: card for v in names.values()}
+    rng = np.random.default_rng(seed)
+    scale = card ** (-len(names) / len(factors))            # keeps Z = O(1)
+    values = [(rng.uniform(0.5, 1.5, (card, card)) * scale).astype(dtype) for _ in factors]
+    return factors, sizes, values
+
+
+def test_config2_chain_full_length_vs_oracle():
+    """configs[1] at full length: 1000 x 64^3 doubles (2 GiB of tables; re-rooted: 500 dependent levels per
+    phase inside ONE dataflow launch each, poll back-off and all), every clique and separator belief."""
+    spec = synthetic.chain_tree(n_cliques=1000, card=64, width=3)
+    n = spec["n_cliques"]
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64")
+    plan.fill_synthetic(3, spec["scales"])                   # same numbers as synthetic.potentials_for(seed=3)
+    for _ in range(2):                                       # twice: both halves of the message arena
+        plan.propagate()
+    st = plan.stats()
+    assert st["n_launches"] == 2 and st["flow_fallbacks"] == 0
+    pots = synthetic.potentials_for(spec, seed=3)
+    want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+    del pots
+    assert abs(plan.z() - z) <= RTOL64 * abs(z)
+    for node in range(len(spec["node_vars"])):
+        close(plan.belief(node), want[node], rtol=RTOL64, what="node %d" % node)
+        want[node] = None
+    plan.close()
+
+
+def test_config3_lattice_card8_f32_vs_oracle():
+    """configs[2] at its stated clique shape, reduced length: 6 x 12 lattice, cardinality 8, float32,
+    pairwise factors, own junction-tree builder (cliques up to width 8 = 8^8 entries, separators up to 8^7),
+    through the public API; every factor marginal against the oracle's propagate."""
+    factors, sizes, values = lattice(6, 12, 8)
+    tree = jt.create_junction_tree(factors, sizes)
+    ct = tree.clique_tree
+    assert max(len(c) for c in ct.maxcliques) >= 7
+    out = tree.propagate(values)
+    plan = tree.plan("f32")
+    d = plan.describe()
+    st = plan.stats()
+    # sub-boxes beyond 64 KiB make the engine launch per level (jtp_plan_create); otherwise one launch per phase
+    assert (st["n_launches"] == 2) == (d["max_lds"] <= 64 * 1024), (st["n_launches"], d["max_lds"])
+    want = oracle.propagate(tree.tree, tree.separators, ct.maxcliques, ct.factor_to_maxclique, factors, sizes, values)
+    assert len(out) == len(values)
+    for i, (o, w, v) in enumerate(zip(out, want, values)):
+        assert o.shape == v.shape and o.dtype == np.float64
+        close(o, w, rtol=RTOL32, what="factor %d %r" % (i, factors[i]))
+    z = plan.z()
+    assert abs(z - float(np.sum(want[0]))) <= RTOL32 * z
+
+
+def test_config3_full_lattice_properties():
+    """configs[2] as restated in SURVEY.md 8d: 6 x 167 lattice (1002 variables, 1831 pairwise factors of
+    cardinality 8, float32, ~9 GiB of clique tables): every factor marginal sums to Z, and the single-variable
+    marginals implied by different factors agree (calibration across the whole tree)."""
+    factors, sizes, values = lattice(6, 167, 8)
+    tree = jt.create_junction_tree(factors, sizes)
+    assert len(sizes) == 1002 and len(factors) == 1831
+    assert max(len(c) for c in tree.clique_tree.maxcliques) <= 9
+    out = tree.propagate(values)
+    plan = tree.plan("f32")
+    assert plan.describe()["arena_elems"] * 4 > 4 * 2 ** 30
+    assert plan.stats()["n_launches"] > 2                    # the per-level path (sub-boxes > 64 KiB)
+    z = plan.z()
+    assert np.isfinite(z) and z > 0
+    sums = np.array([o.sum() for o in out])
+    assert np.max(np.abs(sums - z)) <= 5e-6 * z
+    marg, worst = {}, 0.0
+    for f, o in zip(factors, out):
+        for ax, v in enumerate(f):
+            m = o.sum(axis=1 - ax)
+            if v in marg:
+                worst = max(worst, float(np.max(np.abs(m - marg[v]) / marg[v])))
+            else:
+                marg[v] = m
+    assert worst < 5e-6, worst
+    engine.clear_plan_cache()
+
+
+def _with_evidence(spec, base, observed):
+    pots = [np.asarray(p, dtype=np.float64) for p in base]
+    n = spec["n_cliques"]
+    for var, state in observed.items():
+        host = next(c for c in range(n) if var in spec["node_vars"][c])
+        ind = np.zeros(spec["sizes"][var])
+        ind[state] = 1.0
+        shape = [1] * pots[host].ndim
+        shape[spec["node_vars"][host].index(var)] = spec["sizes"][var]
+        pots[host] = pots[host] * ind.reshape(shape)
+    return pots
+
+
+def test_config5_evidence_sets_on_the_width20_tree():
+    """configs[4] on one GPU: 32 evidence sets (16 observed variables each) on the full
+    width-20 tree with ONE copy of the 256 x 2^20 float32 tables.  Four of the sets against the oracle run on
+    indicator-multiplied potentials (Z, sampled clique beliefs and the separators next to them); every set
+    through its own consistency (sampled clique beliefs sum to the set's Z)."""
+    spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+    n, nb = spec["n_cliques"], 32
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", n_batch=nb, share_potentials=True)
+    plan.fill_synthetic(1, spec["scales"])
+    labels = sorted(spec["sizes"])
+    observed = []
+    for b in range(nb):
+        rng = np.random.default_rng(1000 + b)
+        observed.append({labels[i]: int(rng.integers(0, 2)) for i in rng.choice(len(labels), size=16, replace=False)})
+        plan.set_evidence(observed[b], batch=b)
+    plan.propagate(0, nb)
+    zs = [plan.z(batch=b) for b in range(nb)]
+    assert all(np.isfinite(z) and z > 0 for z in zs)
+    rng = np.random.default_rng(0)
+    for b in range(nb):
+        for c in rng.choice(n, size=3, replace=False):
+            assert abs(plan.marginal(int(c), [], batch=b) - zs[b]) <= 2e-6 * zs[b], (b, c)
+    base = synthetic.potentials_for(spec, seed=1, dtype=np.float32)
+    for b in (0, 9, 18, 31):
+        want, z = oracle.beliefs_exact(spec["tree"], _with_evidence(spec, base, observed[b]), spec["node_vars"], return_z=True)
+        assert abs(zs[b] - z) <= RTOL32 * z, b
+        for c in [0, 1, n - 1] + [int(x) for x in rng.choice(np.arange(2, n - 1), size=5, replace=False)]:
+            close(plan.belief(c, batch=b), want[c], rtol=RTOL32, what="set %d clique %d" % (b, c))
+            if c > 0:
+                close(plan.belief(n + c - 1, batch=b), want[n + c - 1], rtol=RTOL32, what="set %d separator of %d" % (b, c))
+        del want
+    plan.close()

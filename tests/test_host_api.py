@@ -1,0 +1,40 @@
+"""Host-side functions of the drop-in API that need neither GPU nor libjtprop compute: checked against
+outputs captured from the unmodified reference (tests/golden/apply_evidence.npz, oracle/gen_golden.py)."""
+import numpy as np
+
+from junctiontree_amd import computation as comp
+
+
+def test_apply_evidence_matches_reference_outputs(golden):
+    """`apply_evidence` (reference: junctiontree/computation.py:11-34).  The reference's own test
+    (tests/test_computation.py:377-408) forgets to assert; the captured outputs pin shape (observed axes
+    kept with length 1), values, the one-element-list wrapping and the scalar pass-through."""
+    g = golden("apply_evidence.npz")
+    for case in g.meta["cases"]:
+        pots = g.arrs(case["potentials"])
+        for i in case.get("scalar_inputs", []):
+            pots[i] = float(pots[i])                    # (a Python float was handed to the reference)
+        evidence = {k: v for k, v in case["evidence"]}
+        keep = [np.copy(p) for p in pots]
+        out = comp.apply_evidence(pots, case["variables"], evidence)
+        assert len(out) == len(pots)
+        for o, r, kind, p, k in zip(out, g.arrs(case["ref"]), case["ref_types"], pots, keep):
+            assert isinstance(o, list) and len(o) == 1, case["name"]
+            assert np.shape(o[0]) == r.shape, case["name"]
+            np.testing.assert_array_equal(np.asarray(o[0]), r, err_msg=case["name"])
+            assert (kind == "ndarray") == isinstance(o[0], np.ndarray), case["name"]
+            np.testing.assert_array_equal(np.asarray(p), k)          # inputs untouched
+
+
+def test_apply_evidence_case_of_the_reference_test(golden):
+    """The equalities the reference's test states (without asserting them), with the axes kept."""
+    g = golden("apply_evidence.npz")
+    case = g.meta["cases"][0]
+    pots = g.arrs(case["potentials"])
+    out = comp.apply_evidence(pots, case["variables"], {3: 0, 9: 2})
+    np.testing.assert_array_equal(out[0][0][0], pots[0][0, :, :])
+    np.testing.assert_array_equal(out[1][0][:, 0], pots[1][:, 2])
+    np.testing.assert_array_equal(out[2][0][0], pots[2][0, :])
+    np.testing.assert_array_equal(out[3][0], pots[3])
+    np.testing.assert_array_equal(out[4][0], pots[4][0:1])
+    np.testing.assert_array_equal(out[6][0], pots[6])
