@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--share", action="store_true",
                     help="with --batch: the evidence sets share one set of clique tables (JTP_SHARE_POTENTIALS) and "
                          "differ by hard evidence on 16 variables each (SURVEY 8d, config 5)")
+    ap.add_argument("--multiset", action="store_true",
+                    help="with --batch: JTP_MULTISET plan - the evidence sets share the tables and every pass over a table "
+                         "serves eight sets (no belief tables; beliefs and marginals are formed on demand)")
     ap.add_argument("--cliques", type=int, default=256)
     ap.add_argument("--width", type=int, default=20)
     ap.add_argument("--sep", type=int, default=10)
@@ -144,8 +147,8 @@ def main():
                        device=device, n_ranks=world, rank=rank, owner=owner, n_batch=args.batch,
                        block_log2=args.block_log2, lds_budget=args.lds_budget,
                        layout_policy=args.layout_policy, split_variants=args.split_variants,
-                       level_launches=args.level_launches, share_potentials=args.share)
-    if args.share:
+                       level_launches=args.level_launches, share_potentials=args.share, multiset=args.multiset)
+    if args.share or args.multiset:
         import numpy as np
         plan.fill_synthetic(1, spec["scales"])
         labels = sorted(spec["sizes"])
@@ -160,6 +163,18 @@ def main():
     for _ in range(args.warmup):
         plan.propagate(sync=False)
     plan.sync()
+    if args.share or args.multiset:
+        # Evidence sets that share their tables: a table need only be read ONCE per batch, whatever the engine does
+        # (a --share plan streams it once per set, mostly out of the Infinity Cache; a --multiset plan once per group
+        # of eight sets).  Algorithmic bytes: tables once per batch; per set its messages and - unless beliefs are
+        # formed on demand (--multiset) - its belief tables.
+        sz = [1] * len(spec["node_vars"])
+        for i, labs in enumerate(spec["node_vars"]):
+            for v in labs:
+                sz[i] *= spec["sizes"][v]
+        tables, seps = sum(sz[:spec["n_cliques"]]) * itemsize, sum(sz[spec["n_cliques"]:]) * 8
+        per_set = 5 * seps + (0 if args.multiset else tables)
+        alg = dict(alg, total=(2 * tables + per_set * args.batch) / args.batch, read=2 * tables / args.batch)
     if not args.no_profile:
         plan.set_profiling(args.steps, per_launch=args.per_launch or args.split_variants)
     barrier()
@@ -201,7 +216,9 @@ def main():
                             "potentials), %d shared variables per edge, balanced binary tree"
                             % (n, args.width, args.card, args.width, args.dtype, args.sep),
                 "algorithmic_bytes_per_step": alg["total"] * args.batch, "messages_per_step": alg["messages"] * args.batch,
-                "evidence_sets_per_step": args.batch, "shared_potentials": bool(args.share),
+                "evidence_sets_per_step": args.batch, "shared_potentials": bool(args.share or args.multiset),
+                "multiset": bool(args.multiset),
+                "engine_table_bytes_per_step": stats["algorithmic_bytes"] if args.multiset else None,
                 "parallelism": "1 GPU" if world == 1 else "subtree-sharded x%d, RCCL send/recv at cuts" % world,
                 "launches_per_step": stats["n_launches"], "Z": z,
             },

@@ -52,6 +52,12 @@ extern "C" {
                                config 5 without 512 copies of the tables, and with the concurrently running
                                sets finding each other's table reads in the last-level cache             */
 
+#define JTP_MULTISET 64u    /* with JTP_SHARE_POTENTIALS: evidence sets are processed EIGHT at a time by one pass over the
+                               shared clique tables (kernel jt_multi_flow): a table row is read from HBM once per
+                               group of sets instead of once per set.  No belief tables are kept: clique beliefs and
+                               marginals are formed on demand from the shared tables and the set's final messages;
+                               jtp_propagate always runs all evidence sets of the plan                        */
+
 typedef struct jtp_plan jtp_plan;
 
 /* Structure of one junction tree.  Mirrors the reference's data model

@@ -117,6 +117,9 @@ struct KernelTable {
             case JT_K_COLLECT_LEVEL: return jt_collect_level<T>;
             case JT_K_DISTRIBUTE_LEVEL: return jt_distribute_level<T>;
             case JT_K_REDUCE_LEVEL: return jt_reduce_level<T>;
+            case JT_K_MULTI_COLLECT: return jt_multi_flow<T>;
+            case JT_K_MULTI_DISTRIBUTE: return jt_multi_flow<T>;
+            case JT_K_SINGLE: return jt_single<T>;
         }
         return nullptr;
     }
@@ -128,6 +131,7 @@ static const char *k_names[JT_K_COUNT] = {
     "jt_distribute<T, 0, 0>", "jt_distribute<T, 0, 1>", "jt_distribute<T, 0, 2>", "jt_distribute<T, 0, 3>",
     "jt_distribute<T, 1, 0>", "jt_distribute<T, 1, 1>", "jt_distribute<T, 1, 2>", "jt_distribute<T, 1, 3>",
     "jt_collect_level<T>", "jt_distribute_level<T>", "jt_collect_flow<T>", "jt_distribute_flow<T>", "jt_reduce_level<T>",
+    "jt_multi_flow<T>", "jt_multi_flow<T>", "jt_single<T>",
 };
 
 struct BatchBuffers {
@@ -173,6 +177,17 @@ struct jtp_plan {
     bool counted = false;           // included in g_live_plans
     uint32_t flow_debug = 0;        // JTP_FLOW_DEBUG at plan creation, or jtp_debug_set(plan, "flow_debug", v)
     bool env_tickets = false;       // JTP_FLOW_TICKETS at plan creation
+    // multi-set plans (JTP_MULTISET): evidence sets in groups of JT_MSETS, one allocation each for all sets'
+    // message arenas, evidence tables and sync areas (bufs[b] point into them; bufs[b].psi/.bel are shared)
+    bool multiset = false;
+    int n_groups = 0;
+    double *msg_all = nullptr;
+    uint32_t *ev_all = nullptr, *sync_all = nullptr;
+    int64_t set_stride = 0;         // doubles between consecutive sets' arenas (both halves)
+    uint32_t ev_stride = 0;         // uint32 per set's evidence table
+    // read-out of multi-set plans: belief task of each clique, built on first use
+    struct BeliefTask { JtTask *d_task = nullptr; JtBlock *d_blk = nullptr; int *d_tab = nullptr; int nblocks = 0, lds = 0; };
+    std::vector<BeliefTask> belief_tasks;
     std::vector<hipStream_t> streams;
     std::vector<BatchBuffers> bufs;
     JtTask *d_tasks = nullptr;
@@ -260,6 +275,20 @@ void jtp_plan_destroy(jtp_plan *pl) {
     if (pl->device) {
         (void)hipSetDevice(pl->hp.device);
         for (auto s : pl->streams) (void)hipStreamSynchronize(s);
+        if (pl->multiset) {
+            if (!pl->bufs.empty()) {
+                if (pl->bufs[0].psi) (void)hipFree(pl->bufs[0].psi);
+                if (pl->bufs[0].bel) (void)hipFree(pl->bufs[0].bel);
+            }
+            if (pl->msg_all) (void)hipFree(pl->msg_all);
+            if (pl->ev_all) (void)hipFree(pl->ev_all);
+            if (pl->sync_all) (void)hipFree(pl->sync_all);
+            for (auto &bt : pl->belief_tasks) {
+                if (bt.d_task) (void)hipFree(bt.d_task);
+                if (bt.d_blk) (void)hipFree(bt.d_blk);
+                if (bt.d_tab) (void)hipFree(bt.d_tab);
+            }
+        } else
         for (auto &b : pl->bufs) {
             if (b.psi && (&b == &pl->bufs[0] || b.psi != pl->bufs[0].psi)) (void)hipFree(b.psi);
             if (b.bel) (void)hipFree(b.bel);
@@ -290,19 +319,32 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     jtp_plan *pl = new jtp_plan();
     std::string err;
     int rc = jtp_build_plan(desc, pl->hp, err);
+    if (rc == JTP_EUNSUPPORTED && desc && (desc->flags & JTP_MULTISET) && desc->layout_policy == 0) {
+        // sub-boxes too large for one evidence set's LDS region under the default bit order: smallest sub-boxes
+        jtp_tree_desc again = *desc;
+        again.layout_policy = 2;
+        delete pl;
+        pl = new jtp_plan();
+        rc = jtp_build_plan(&again, pl->hp, err);
+    }
     if (rc != JTP_OK) {
         delete pl;
         return set_err(rc, "%s", err.c_str());
     }
     HostPlan &hp = pl->hp;
     pl->esize = hp.dtype == JTP_F32 ? 4 : 8;
+    pl->multiset = hp.multiset;
+    if (pl->multiset && !(hp.flags & JTP_SHARE_POTENTIALS)) {
+        delete pl;
+        return set_err(JTP_EINVAL, "JTP_MULTISET needs JTP_SHARE_POTENTIALS (the evidence sets of a group read one table)");
+    }
     // one launch per level when asked for, for per-shape launches and for the JTP_DEBUG experiments
     pl->flow = !(hp.flags & (JTP_LEVEL_LAUNCHES | JTP_SPLIT_VARIANTS)) && !(getenv("JTP_DEBUG") && (atoi(getenv("JTP_DEBUG")) & 1)) &&
                !(getenv("JTP_FORCE_LEVEL_LAUNCHES") && atoi(getenv("JTP_FORCE_LEVEL_LAUNCHES")));
     // Sub-boxes so large that one or two workgroups fill a CU (config 3: 121 KB): a waiting workgroup
     // then idles a whole CU, and staging is a large share of the traffic, which per-level launches read
     // through L2 while a dataflow launch has to read through to memory.  Measured 39.6 vs 46.9 ms.
-    if (hp.max_lds > 64 * 1024 && !(getenv("JTP_FORCE_FLOW") && atoi(getenv("JTP_FORCE_FLOW")))) pl->flow = false;
+    if (hp.max_lds > 64 * 1024 && !pl->multiset && !(getenv("JTP_FORCE_FLOW") && atoi(getenv("JTP_FORCE_FLOW")))) pl->flow = false;
     if (hp.flags & JTP_PLAN_ONLY) {
         *out = pl;
         return JTP_OK;
@@ -334,7 +376,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     pl->flow_debug = getenv("JTP_FLOW_DEBUG") ? (uint32_t)atoi(getenv("JTP_FLOW_DEBUG")) : 0u;
     pl->env_tickets = getenv("JTP_FLOW_TICKETS") && atoi(getenv("JTP_FLOW_TICKETS"));
     CREATE_TRY(hipSetDevice(hp.device));
-    const int nstreams = std::min(hp.n_batch, 16);
+    const int nstreams = pl->multiset ? 1 : std::min(hp.n_batch, 16);
     pl->streams.resize(nstreams);
     for (auto &s : pl->streams) CREATE_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     pl->bufs.resize(hp.n_batch);
@@ -342,6 +384,34 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     // two halves, used by alternate propagates (jtp_internal.h: JT_UNWRITTEN)
     const size_t mbytes = (size_t)std::max<int64_t>(hp.msg_doubles, 2) * 8 * 2;
     const bool share_psi = (hp.flags & JTP_SHARE_POTENTIALS) != 0;     // one potential arena for all evidence sets
+    if (pl->multiset) {
+        pl->n_groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS;
+        const size_t nsets = (size_t)pl->n_groups * JT_MSETS;          // (the last group is padded with evidence-free sets)
+        pl->set_stride = (int64_t)(mbytes / 8);
+        pl->ev_stride = (uint32_t)(2 * hp.pn.size());
+        void *psi = nullptr, *bel = nullptr;
+        CREATE_TRY(hipMalloc(&psi, abytes));
+        pl->bufs[0].psi = psi;
+        CREATE_TRY(hipMalloc(&bel, abytes));                           // scratch: one belief table at a time, on demand
+        pl->bufs[0].bel = bel;
+        CREATE_TRY(hipMemsetAsync(psi, 0, abytes, pl->streams[0]));
+        CREATE_TRY(hipMemsetAsync(bel, 0, abytes, pl->streams[0]));
+        CREATE_TRY(hipMalloc((void **)&pl->msg_all, mbytes * nsets));
+        CREATE_TRY(hipMemsetD32Async((hipDeviceptr_t)pl->msg_all, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), mbytes * nsets / 4, pl->streams[0]));
+        CREATE_TRY(hipMalloc((void **)&pl->ev_all, (size_t)pl->ev_stride * 4 * nsets));
+        CREATE_TRY(hipMemsetAsync(pl->ev_all, 0, (size_t)pl->ev_stride * 4 * nsets, pl->streams[0]));
+        CREATE_TRY(hipMalloc((void **)&pl->sync_all, (size_t)hp.sync_words * 4 * pl->n_groups));
+        CREATE_TRY(hipMemsetAsync(pl->sync_all, 0, (size_t)hp.sync_words * 4 * pl->n_groups, pl->streams[0]));
+        for (int b = 0; b < hp.n_batch; ++b) {
+            BatchBuffers &bb = pl->bufs[b];
+            bb.psi = psi;
+            bb.bel = bel;
+            bb.msg = pl->msg_all + (int64_t)b * pl->set_stride;
+            bb.ev = pl->ev_all + (size_t)b * pl->ev_stride;
+            bb.sync = pl->sync_all + (size_t)(b / JT_MSETS) * hp.sync_words;
+        }
+        pl->belief_tasks.resize(hp.pn.size());
+    } else
     for (auto &b : pl->bufs) {
         if (share_psi && &b != &pl->bufs[0]) b.psi = pl->bufs[0].psi;
         else CREATE_TRY(hipMalloc(&b.psi, abytes));
@@ -357,6 +427,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     *pl->host_abort = 0;
 
     for (auto &b : pl->bufs) {
+        if (&b != &pl->bufs[0] && b.psi == pl->bufs[0].psi) continue;          // shared tables: filled once
         for (const VirtualFill &vf : hp.virtual_fills) {
             const int64_t n = (int64_t)1 << vf.nbits;
             const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
@@ -377,7 +448,10 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         CREATE_TRY(hipMalloc((void **)&pl->d_itab, hp.itab.size() * sizeof(int32_t)));
         CREATE_TRY(hipMemcpy(pl->d_itab, hp.itab.data(), hp.itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    if (hp.max_lds > 64 * 1024) {
+    if (pl->multiset) {
+        const void *f = hp.dtype == JTP_F32 ? (const void *)jt_multi_flow<float> : (const void *)jt_multi_flow<double>;
+        CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JT_RING_BYTES + JT_MSETS * JT_SETB_LARGE));
+    } else if (hp.max_lds > 64 * 1024) {
         for (int v = 0; v < JT_K_COUNT; ++v) {
             if (v == JT_K_COLLECT_FLOW || v == JT_K_DISTRIBUTE_FLOW) continue;
             const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v);
@@ -631,6 +705,11 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
     for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
     // only the sets that are run again lose their messages: a set whose propagate was already checked keeps
     // its arena (its separator beliefs are read from there), and no later launch of this plan waits on markers
+    if (pl->multiset) {                                     // (all sets run together, the padding sets of the last group too)
+        const size_t mbytes = (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 16;
+        HIP_TRY(hipMemsetD32((hipDeviceptr_t)pl->msg_all, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), mbytes * pl->n_groups * JT_MSETS / 4));
+        for (auto &b : pl->bufs) b.epoch = 0, b.flow_runs = 0;
+    } else
     for (size_t i = 0; i < pl->bufs.size(); ++i) {
         BatchBuffers &b = pl->bufs[i];
         if (!b.unchecked) continue;
@@ -639,6 +718,15 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
         b.epoch = 0;
         b.flow_runs = 0;
     }
+    if (pl->multiset) {
+        bool any = false;
+        for (auto &b : pl->bufs) any = any || b.unchecked, b.unchecked = false;
+        HIP_TRY(hipMemset(pl->sync_all, 0, (size_t)pl->hp.sync_words * 4 * pl->n_groups));
+        if (any) {
+            int rc = jtp_propagate(pl, 0, pl->hp.n_batch);
+            if (rc) return rc;
+        }
+    } else
     for (size_t i = 0; i < pl->bufs.size(); ++i) {
         if (!pl->bufs[i].unchecked) continue;
         pl->bufs[i].unchecked = false;
@@ -697,9 +785,16 @@ int jtp_set_evidence(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *var_
     HIP_TRY(hipSetDevice(hp.device));
     hipStream_t s = pl->streams[batch % pl->streams.size()];
     HIP_TRY(hipStreamSynchronize(s));                      // a propagate in flight may still read the old table
-    if (!b.ev) HIP_TRY(hipMalloc((void **)&b.ev, ev.size() * sizeof(uint32_t)));
+    if (!b.ev) HIP_TRY(hipMalloc((void **)&b.ev, ev.size() * sizeof(uint32_t)));      // (multi-set plans: a slice of ev_all)
     HIP_TRY(hipMemcpy(b.ev, ev.data(), ev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return JTP_OK;
+}
+
+// dynamic LDS of a multi-set launch: the ring plus one region per evidence set of the group (reduce tasks: none)
+static int multiset_lds(const HostPlan &hp, const Launch &L) {
+    int lds = 0;
+    for (int t : L.tasks) lds = std::max(lds, hp.tasks[t].kind == 0 ? hp.tasks[t].lds_bytes : 0);
+    return lds;
 }
 
 int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
@@ -711,6 +806,76 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
     if ((hp.flags & JTP_SHARE_POTENTIALS) && pl->psi_dirty) {
         HIP_TRY(hipStreamSynchronize(pl->streams[0]));        // the shared tables were written on stream 0
         pl->psi_dirty = false;
+    }
+    if (pl->multiset) {
+        if (batch_begin != 0 || batch_end != hp.n_batch)
+            return set_err(JTP_EINVAL, "a multi-set plan propagates all its evidence sets together: pass [0, %d)", hp.n_batch);
+        if (pl->prof_per_launch) return set_err(JTP_EINVAL, "per-launch profiling is not available for multi-set plans");
+        hipStream_t s = pl->streams[0];
+        const bool prof = pl->prof_steps > 0;
+        if (prof) while (pl->ev.size() < 3 * (size_t)pl->prof_steps) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            pl->ev.push_back(e);
+        }
+        const size_t ev_base = prof ? 3 * (size_t)(pl->prof_cursor % pl->prof_steps) : 0;
+        const int64_t half = std::max<int64_t>(hp.msg_doubles, 2);
+        for (auto &bb : pl->bufs) bb.epoch++;
+        BatchBuffers &b0 = pl->bufs[0];
+        JtFlow fl;
+        memset(&fl, 0, sizeof fl);
+        fl.sync = pl->sync_all;
+        fl.host_abort = pl->host_abort;
+        fl.cur_off = b0.cur_off(half);
+        fl.oth_off = half - fl.cur_off;                      // the kernel waits on markers in every launch mode
+        fl.dbg = pl->flow_debug;
+        fl.ev = pl->ev_all;
+        fl.set_stride = pl->set_stride;
+        fl.ev_stride = pl->ev_stride;
+        fl.sync_stride = (uint32_t)hp.sync_words;
+        const bool flow = pl->flow;
+        if (flow) {
+            b0.flow_runs++;
+            for (auto &bb : pl->bufs) bb.unchecked = true;
+        }
+        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->env_tickets || g_live_plans[hp.device & 63] > 1;
+        bool mid_done = false;
+        if (prof) HIP_TRY(hipEventRecord(pl->ev[ev_base + 0], s));
+        auto launch = [&](int phase, int64_t blk_off, int nblocks, int lds, int ticket_idx, uint32_t ticket_base) {
+            fl.ticket_idx = ticket_idx >= 0 ? (uint32_t)ticket_idx : 0xffffffffu;
+            fl.ticket_base = ticket_base;
+            fl.blk_base = (uint32_t)blk_off;
+            if (hp.dtype == JTP_F32)
+                hipLaunchKernelGGL(jt_multi_flow<float>, dim3(nblocks, pl->n_groups), dim3(JT_THREADS), lds, s, pl->d_tasks, pl->d_blocks + blk_off,
+                                   pl->d_itab, (const float *)b0.psi, (float *)b0.bel, pl->msg_all, fl);
+            else
+                hipLaunchKernelGGL(jt_multi_flow<double>, dim3(nblocks, pl->n_groups), dim3(JT_THREADS), lds, s, pl->d_tasks, pl->d_blocks + blk_off,
+                                   pl->d_itab, (const double *)b0.psi, (double *)b0.bel, pl->msg_all, fl);
+        };
+        for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {
+            if (st.kind != 0) continue;
+            const int phase = flow ? hp.segments[st.first].phase : hp.launches[st.first].phase;
+            if (prof && !mid_done && phase == 1) {
+                HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
+                mid_done = true;
+            }
+            if (flow) {
+                const Segment &sg = hp.segments[st.first];
+                int lds = 0;
+                for (int i = sg.first_launch; i < sg.first_launch + sg.n_launch; ++i) lds = std::max(lds, multiset_lds(hp, hp.launches[i]));
+                launch(sg.phase, sg.blk_off, sg.nblocks, lds, tickets ? sg.ticket_idx : -1, (b0.flow_runs - 1u) * (uint32_t)sg.nblocks);
+            } else {
+                const Launch &L = hp.launches[st.first];
+                launch(L.phase, L.blk_off, L.nblocks, multiset_lds(hp, L), -1, 0u);
+            }
+        }
+        if (prof) {
+            if (!mid_done) HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
+            HIP_TRY(hipEventRecord(pl->ev[ev_base + 2], s));
+            pl->prof_cursor++;
+        }
+        HIP_TRY(hipGetLastError());
+        return JTP_OK;
     }
     const bool prof = pl->prof_steps > 0;
     const size_t ev_per_step = pl->prof_per_launch ? 2 * hp.launches.size() : 3;
@@ -839,6 +1004,34 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
         const JtPackDesc &d = hp.pack[node];
         rc = ensure_stage(pl, (size_t)d.host_elems * hsz);
         if (rc) return rc;
+        if (pl->multiset) {
+            // no belief tables are kept: form this clique's belief for this evidence set now, from the shared
+            // table and the set's final messages (computation.py:216-224), into the scratch arena
+            jtp_plan::BeliefTask &bt = pl->belief_tasks[node];
+            if (!bt.d_task) {
+                JtTask tk;
+                std::vector<int32_t> itab;
+                std::vector<JtBlock> blocks;
+                std::string err;
+                rc = jtp_plan_belief_task(hp, node, tk, itab, blocks, err);
+                if (rc) return set_err(rc, "%s", err.c_str());
+                HIP_TRY(hipMalloc((void **)&bt.d_task, sizeof(JtTask)));
+                HIP_TRY(hipMalloc((void **)&bt.d_blk, blocks.size() * sizeof(JtBlock)));
+                HIP_TRY(hipMalloc((void **)&bt.d_tab, std::max<size_t>(itab.size(), 1) * sizeof(int32_t)));
+                HIP_TRY(hipMemcpy(bt.d_task, &tk, sizeof tk, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(bt.d_blk, blocks.data(), blocks.size() * sizeof(JtBlock), hipMemcpyHostToDevice));
+                if (!itab.empty()) HIP_TRY(hipMemcpy(bt.d_tab, itab.data(), itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                bt.nblocks = (int)blocks.size();
+                bt.lds = tk.lds_bytes;
+            }
+            JtFlow one;
+            memset(&one, 0, sizeof one);
+            one.cur_off = b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));
+            one.oth_off = -1;
+            one.ev = b.ev;
+            launch_variant(pl, JT_K_SINGLE, bt.nblocks, bt.lds, s, bt.d_task, bt.d_blk, bt.d_tab, b.psi, b.bel, b.msg, one);
+            HIP_TRY(hipGetLastError());
+        }
         const int grid = (int)std::min<int64_t>((d.host_elems + 255) / 256, 4096);
         if (hp.dtype == JTP_F32) {
             if (host_dtype == JTP_F32) hipLaunchKernelGGL((jt_unpack<float, float>), dim3(grid), dim3(256), 0, s, d, (const float *)b.bel, (float *)pl->stage);
@@ -963,7 +1156,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
             std::vector<JtBlock> blk;
             std::vector<int32_t> tab;
             std::string err;
-            rc = jtp_plan_marginal_task(hp, clique, ov, tk, tab, out_bits, npart, blk, err);
+            rc = jtp_plan_marginal_task(hp, clique, ov, tk, tab, out_bits, npart, blk, err, pl->multiset);
             if (rc) return set_err(rc, "request %d: %s", i, err.c_str());
             tk.itab_off = (int64_t)itab.size();
             tk.msg[JT_MAX_IN].off = scratch_doubles;
@@ -1042,7 +1235,15 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
     JtFlow plain;
     memset(&plain, 0, sizeof plain);
     plain.oth_off = -1;
-    launch_variant(pl, JT_K_COLLECT0, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.bel, b.bel, mb->scratch, plain);
+    if (pl->multiset) {
+        // psi * (the set's incoming messages) marginalised directly: inputs from the set's message arena,
+        // outputs into the request list's scratch buffer (JtFlow::out_shift)
+        plain.cur_off = b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));
+        plain.ev = b.ev;
+        plain.out_shift = (int64_t)(mb->scratch - (b.msg + plain.cur_off));
+        launch_variant(pl, JT_K_SINGLE, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.psi, b.bel, b.msg, plain);
+    } else
+        launch_variant(pl, JT_K_COLLECT0, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.bel, b.bel, mb->scratch, plain);
     hipLaunchKernelGGL(jt_marg_unpack, dim3(mb->max_grid_x, mb->n), dim3(256), 0, s, mb->d_descs, mb->scratch, mb->stage);
     HIP_TRY(hipGetLastError());
     bool packed = true;
@@ -1094,9 +1295,25 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     st->n_launches = (int32_t)(flow ? hp.segments.size() : hp.launches.size());
     st->n_messages = hp.n_messages;
     st->n_tasks = (int32_t)hp.tasks.size();
-    st->algorithmic_bytes = hp.alg_bytes;
+    // multi-set plans: a table is read once per GROUP of evidence sets, messages once per set
+    st->algorithmic_bytes = pl->multiset ? hp.alg_table_bytes * std::max(pl->n_groups, (hp.n_batch + JT_MSETS - 1) / JT_MSETS) + hp.alg_msg_bytes * hp.n_batch
+                                         : hp.alg_bytes;
     st->flow_fallbacks = pl->flow_fallbacks;
-    if (flow) {
+    if (pl->multiset) {
+        const int groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS;
+        for (const Launch &L : hp.launches) {
+            if (L.variant != JT_K_MULTI_COLLECT && L.variant != JT_K_MULTI_DISTRIBUTE) continue;
+            double tb = 0, mb = 0;
+            for (int t : L.tasks) {
+                const PNode &p = hp.pn[hp.tasks[t].pnode];
+                const double table = p.real >= 0 ? (double)hp.pack[p.real].host_elems * pl->esize : 0.0;
+                tb += table;
+            }
+            mb = L.alg_bytes - tb;
+            st->kernel_bytes[L.variant] += tb * groups + mb * hp.n_batch;
+        }
+        for (const Segment &sg : hp.segments) st->kernel_launches[sg.phase == 0 ? JT_K_MULTI_COLLECT : JT_K_MULTI_DISTRIBUTE] += flow ? 1 : sg.n_launch;
+    } else if (flow) {
         for (const Segment &sg : hp.segments) {
             const int v = sg.phase == 0 ? JT_K_COLLECT_FLOW : JT_K_DISTRIBUTE_FLOW;
             for (int i = sg.first_launch; i < sg.first_launch + sg.n_launch; ++i) st->kernel_bytes[v] += hp.launches[i].alg_bytes;
@@ -1137,7 +1354,10 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
             }
             // with one kernel per phase (the default), the phase time is that kernel's time over
             // its back-to-back launches (gaps included)
-            if (flow) {
+            if (pl->multiset) {
+                st->kernel_ms[JT_K_MULTI_COLLECT] = st->collect_ms;
+                st->kernel_ms[JT_K_MULTI_DISTRIBUTE] = st->distribute_ms;
+            } else if (flow) {
                 st->kernel_ms[JT_K_COLLECT_FLOW] = st->collect_ms;
                 st->kernel_ms[JT_K_DISTRIBUTE_FLOW] = st->distribute_ms;
             } else if (!(hp.flags & JTP_SPLIT_VARIANTS)) {

@@ -35,6 +35,13 @@
 // start of every propagate the half about to be used holds markers only.
 #define JT_UNWRITTEN 0x7FF8BEEF7FF8BEEFull
 #define JT_MAX_VARS 32         // variables per node
+// Multi-set plans (JTP_MULTISET): evidence sets that share ONE copy of the clique tables are processed
+// JT_MSETS at a time by every workgroup - a table row is loaded once and multiplied into the messages of
+// each set of the group (kernel jt_multi_*).  Per set a workgroup owns an LDS region of JtTask::setb bytes
+// (4 KiB or 16 KiB) holding the set's message sub-boxes.
+#define JT_MSETS 8
+#define JT_SETB_SMALL 4096
+#define JT_SETB_LARGE 16384
 
 struct JtMsg {
     int64_t off;               // msg arena offset (doubles) of partial copy 0
@@ -68,6 +75,9 @@ struct JtTask {
     int32_t debug;             // timing experiments only (JTP_DEBUG): 1 = skip epilogues and flush
     int32_t kind;              // 0: clique pass; 1: reduce task - sum the msg[0].npart partial copies of a
                                // message (2^nbits entries, 256 per workgroup from entry xF) into msg[JT_MAX_IN].off
+    int32_t mode;              // clique pass: 0 = marginalise (out = sum psi * ALL incoming: collect, and in multi-set
+                               // plans every downward message and marginal), 1 = distribute (belief + all-but-one)
+    int32_t setb;              // multi-set plans: bytes of LDS per evidence set (JT_SETB_SMALL / JT_SETB_LARGE), else 0
     int32_t pad0;
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
     uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base; 0 past the end)
@@ -91,6 +101,12 @@ struct JtFlow {
     uint32_t blk_base;         // index of the launch's first workgroup in the plan's block list (time stamps)
     const uint32_t *ev;        // hard evidence of this evidence set: per planner node (mask, value) over the
                                // clique's index bits, or null: entries with (x & mask) != value count as 0
+    // multi-set launches (grid.y = group of JT_MSETS evidence sets): distances between consecutive sets / groups
+    int64_t set_stride;        // doubles between the message arenas of consecutive sets
+    uint32_t ev_stride;        // uint32 between the evidence tables of consecutive sets
+    uint32_t sync_stride;      // uint32 between the sync areas of consecutive groups
+    int64_t out_shift;         // added to the address of every outgoing entry (doubles): read-out tasks of multi-set
+                               // plans read one set's message arena and write into a scratch buffer elsewhere
 };
 
 // one workgroup: which task, and the chunk's decoded bases (so the kernel does no bit decode)
@@ -151,5 +167,7 @@ enum {
     JT_K_COLLECT_LEVEL, JT_K_DISTRIBUTE_LEVEL,      // one launch per tree level
     JT_K_COLLECT_FLOW, JT_K_DISTRIBUTE_FLOW,        // one launch per phase, workgroups wait for their message entries (default)
     JT_K_REDUCE_LEVEL,                              // reduce tasks of one level (per-level launches only)
+    JT_K_MULTI_COLLECT, JT_K_MULTI_DISTRIBUTE,      // multi-set plans: JT_MSETS evidence sets per pass over a table
+    JT_K_SINGLE,                                    // one task list, any mix of modes and neighbour counts (read-out)
     JT_K_COUNT
 };

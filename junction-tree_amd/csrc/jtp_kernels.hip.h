@@ -558,7 +558,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         for (int j = 0; j < NOUT; ++j) {
             const JtMsg &m = tk.msg[JT_MAX_IN + j];
             const int64_t at = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
-            double *dst = msg_arena + fl.cur_off + at;
+            double *dst = msg_arena + fl.cur_off + at + fl.out_shift;
             double *oth = msg_arena + fl.oth_off + at;          // the half the next propagate will use
             const bool mark = fl.oth_off >= 0;
             const int nfree = m.nfree;
@@ -752,6 +752,479 @@ __global__ __launch_bounds__(JT_THREADS) void jt_distribute_flow(const JtTask *_
         case 5: jt_pass<T, 2, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
         case 6: jt_pass<T, 3, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
         default: jt_pass<T, 4, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-set pass (JTP_MULTISET plans): JT_MSETS evidence sets that share ONE copy of
+// the clique tables are served by ONE pass over a table.  Per set s of the group
+//     out_s[S] = sum_{C \ S} psi[C] * e_s[C] * prod_k in_{k,s}[S_k]
+// (collect, every downward message - planned as its own marginalisation with the parent's message and the
+// siblings' upward messages as inputs - and every marginal have this shape; e_s = the set's hard evidence).
+// A table row travels HBM -> LDS -> registers once and is multiplied into the G sets' message entries:
+// HBM bytes per evidence set fall by G, the arithmetic (two to four f64 operations per element and set)
+// becomes the bound.  Each set has its own LDS region of SETB bytes with the sub-boxes of its messages at
+// the offsets the single-set planner computed; SETB is a compile-time constant so that the G reads of one
+// message entry differ only in the instruction's immediate offset.  The sets' message arenas lie
+// fl.set_stride doubles apart, their evidence tables fl.ev_stride words apart.
+//
+// Evidence: the part of a set's (mask, value) that lies in the ROW bits (chunk + loop bits) is uniform per
+// row - a row that contradicts it is skipped for that set; the part in the thread bits (16-byte vector, lane,
+// wave) is constant over the loop, so it is applied to the register sums in the epilogue, not per element.
+template <typename T, int NIN, int SETB>
+__device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
+                                         const T *__restrict__ psi_arena, double *__restrict__ msg0,
+                                         const JtFlow &fl, uint32_t *flow_ctl, uint32_t bindex) {
+    constexpr int G = JT_MSETS;
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int EB = (VEC == 4) ? 2 : 1;
+    constexpr int TBITS = EB + 8;
+    constexpr int U = JT_U;
+    constexpr bool FLOW = true;
+    using VT = typename JtVec<T>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t xF = bk.xF + (uint32_t)tid * VEC;
+    const T *psi = psi_arena + tk.psi_off;
+    const int total = tk.total;
+    const int rmask = (1 << tk.nR) - 1;
+    const int64_t sstride = fl.set_stride;
+    const int dbg = tk.debug;
+    uint64_t stamp[6];
+    stamp[0] = __builtin_amdgcn_s_memrealtime();      // diagnostic time stamps (JTP_DEBUG=2), as in jt_pass
+    int n_attempts = 0;
+
+    const int *gtab = itab + tk.itab_off;
+    const T *psi0 = psi_arena + bk.psi_x0 + (uint32_t)tid * VEC;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + (uint32_t)wave * (U * 1024);
+    const char *ring = smem + wave * (U * 1024) + lane * 16;
+#pragma unroll
+    for (int u = 0; u < U; ++u) jt_dma16(psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
+    int trow[JT_NCOL];
+    {
+        const int r = lane < total ? lane : total - 1;
+        const int4 a = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL);
+        const int4 b = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL + 4);
+        trow[0] = a.x; trow[1] = a.y; trow[2] = a.z; trow[3] = a.w;
+        trow[4] = b.x; trow[5] = b.y; trow[6] = b.z; trow[7] = b.w;
+    }
+
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+    // evidence of the G sets on this clique, set s in lane s of a register pair (read after the first element
+    // loads have left: the table is two dependent loads away; kept in vector registers: sixteen more scalars
+    // live across the loop made hipcc spill scalars into it)
+    uint32_t ev_m = 0, ev_v = 0;
+    if (fl.ev != nullptr && lane < G) {
+        ev_m = fl.ev[(size_t)lane * fl.ev_stride + 2 * tk.pnode];
+        ev_v = fl.ev[(size_t)lane * fl.ev_stride + 2 * tk.pnode + 1];
+    }
+    // ---- stage the incoming sub-boxes of every set (one thread per entry, partial copies summed in copy
+    //      order), zero the outgoing ones; wait for entries still marked unwritten (dataflow launches)
+    const double *msg_cur = msg0 + fl.cur_off;
+    char *sets = smem + JT_RING_BYTES;                       // region of set s: sets + s * SETB
+    const JtMsg &mo = tk.msg[JT_MAX_IN];
+    uint64_t wait_t0 = 0;
+    for (int attempt = 0;; ++attempt) {
+        n_attempts = attempt + 1;
+        const double *unready = nullptr;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const JtMsg &m = tk.msg[k];
+            const int nfree = m.nfree;
+            const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+            const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
+            const bool thr_mem = m.same_launch != 0;
+            const int n = 1 << nfree;
+            for (int i = tid; i < n; i += JT_THREADS) {
+                int idx = 0;
+#pragma unroll
+                for (int b = 0; b < JT_MAX_FREE; ++b)
+                    if (b < nfree) idx += ((i >> b) & 1) << JT_FPOS(fp, b);
+                const double *src = msg_cur + m.off + bk.gbase[k] + idx;
+                double sum[G];
+#pragma unroll
+                for (int s = 0; s < G; ++s) sum[s] = 0.0;
+                for (int p = 0; p < m.npart; p += 4) {               // the G sets' copies p .. p+3 in flight together
+                    double c[G][4];
+#pragma unroll
+                    for (int s = 0; s < G; ++s)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            c[s][u] = (p + u < m.npart) ? jt_msg_load<FLOW>(src + (int64_t)s * sstride + (int64_t)(p + u) * m.pstride, thr_mem) : 0.0;
+#pragma unroll
+                    for (int s = 0; s < G; ++s)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            sum[s] += c[s][u];
+                            if (jt_unwritten(c[s][u])) unready = src + (int64_t)s * sstride + (int64_t)(p + u) * m.pstride;
+                        }
+                }
+#pragma unroll
+                for (int s = 0; s < G; ++s) reinterpret_cast<double *>(sets + s * SETB + (m.lds_off - JT_RING_BYTES))[i] = sum[s];
+            }
+        }
+        if (attempt == 0) {
+            const int n = 1 << mo.nfree;
+            for (int i = tid; i < n; i += JT_THREADS)
+#pragma unroll
+                for (int s = 0; s < G; ++s) reinterpret_cast<double *>(sets + s * SETB + (mo.lds_off - JT_RING_BYTES))[i] = 0.0;
+        }
+        if constexpr (NIN == 0) {
+            __syncthreads();
+            break;
+        } else {
+            if (fl.dbg & 8) unready = msg_cur;                           // fault injection: wait for ever
+            uint32_t *slot = flow_ctl + 4 + (attempt & 1) * 12;
+            {
+                const uint64_t have = __ballot(unready != nullptr);
+                if (have != 0 && lane == (int)__builtin_ctzll(have)) {
+                    slot[4 + 2 * wave] = (uint32_t)(uintptr_t)unready;
+                    slot[5 + 2 * wave] = (uint32_t)((uintptr_t)unready >> 32);
+                }
+                if (lane == 0) slot[wave] = have != 0 ? 1u : 0u;
+            }
+            __syncthreads();
+            const uint32_t w3 = slot[3], w2 = slot[2], w1 = slot[1], w0 = slot[0];
+            if ((w0 | w1 | w2 | w3) == 0) break;
+            if (tid == 0) {
+                const int cw = w3 ? 3 : (w2 ? 2 : (w1 ? 1 : 0));
+                const double *entry = reinterpret_cast<const double *>((uintptr_t)slot[4 + 2 * cw] | ((uintptr_t)slot[5 + 2 * cw] << 32));
+                if (wait_t0 == 0) wait_t0 = __builtin_amdgcn_s_memrealtime();
+                uint32_t give_up = 0;
+                unsigned spins = 0;
+                const uint64_t limit = (fl.dbg & 8) ? 2000000ull : 200000000ull;
+                while (jt_unwritten(jt_msg_load<true>(entry)) || (fl.dbg & 8)) {
+                    if (spins >= 64) __builtin_amdgcn_s_sleep(32);
+                    else if (spins >= 16) __builtin_amdgcn_s_sleep(16);
+                    if ((++spins & 15u) == 0) {
+                        if (__hip_atomic_load(fl.sync + JT_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = 1;
+                        else if (__builtin_amdgcn_s_memrealtime() - wait_t0 > limit) {
+                            __hip_atomic_store(fl.sync + JT_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(fl.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            give_up = 1;
+                        }
+                        if (give_up) break;
+                    }
+                }
+                flow_ctl[1] = give_up;
+            }
+            __syncthreads();
+            if (flow_ctl[1] != 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA loads must land before the wave ends
+                return;
+            }
+        }
+    }
+
+    stamp[2] = __builtin_amdgcn_s_memrealtime();
+    // ---- per-thread constants (read before the first store of the kernel, see jt_pass) ---------------
+    int thr_in[NIN > 0 ? NIN : 1], in_lds[NIN > 0 ? NIN : 1], in_edep[NIN > 0 ? NIN : 1];
+    int in_ew0[NIN > 0 ? NIN : 1], in_ew1[NIN > 0 ? NIN : 1];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const JtMsg &m = tk.msg[k];
+        int t = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) t += ((lane >> b) & 1) * m.t_w[b];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) t += ((wave >> b) & 1) * m.t_w[6 + b];
+        thr_in[k] = t;
+        in_lds[k] = m.lds_off - JT_RING_BYTES;
+        in_edep[k] = m.e_dep;
+        in_ew0[k] = m.e_w[0];
+        in_ew1[k] = m.e_w[1];
+    }
+    int thr_out = 0;
+    {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) thr_out += ((lane >> b) & 1) * mo.t_w[b];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) thr_out += ((wave >> b) & 1) * mo.t_w[6 + b];
+    }
+    const int o_lds = mo.lds_off - JT_RING_BYTES;
+    const int o_rede = mo.red_e, o_redl = mo.red_lane, o_redw = mo.red_wave;
+    const int o_ew0 = mo.e_w[0], o_ew1 = mo.e_w[1];
+    const int o_nfree = mo.nfree;
+    const int64_t o_at = mo.off + (int64_t)bk.pnum[0] * mo.pstride + bk.gbase[JT_MAX_IN];
+    const uint32_t *ofpw = reinterpret_cast<const uint32_t *>(mo.free_pos);
+    const uint32_t ofp[4] = {ofpw[0], ofpw[1], ofpw[2], ofpw[3]};
+    // thread part of the evidence: bit (4 s + e) set = element e of this thread agrees with set s
+    constexpr uint32_t TMASK = (1u << TBITS) - 1u;
+    uint32_t tmatch = 0;
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ev_m, s) & TMASK, v = (uint32_t)__builtin_amdgcn_readlane((int)ev_v, s);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (((((uint32_t)tid * VEC + e) ^ v) & m) == 0) tmatch |= 1u << (4 * s + e);
+    }
+    // row part (chunk and loop bits): lane s keeps set s's mask and value; one compare + ballot per row
+    const uint32_t row_m = ev_m & ~TMASK, row_v = ev_v & ~TMASK;
+    double acc[G][VEC];
+#pragma unroll
+    for (int s = 0; s < G; ++s)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[s][e] = 0.0;
+
+    auto epilogue = [&](const int oo) {
+        // thread part of the evidence, then the in-thread and cross-lane sums of every set
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (!((tmatch >> (4 * s + e)) & 1u)) acc[s][e] = 0.0;
+            if constexpr (VEC == 4) {
+                if (o_rede & 1) {
+                    acc[s][0] += acc[s][1];
+                    acc[s][2] += acc[s][3];
+                }
+                if (o_rede & 2) {
+                    acc[s][0] += acc[s][2];
+                    acc[s][1] += acc[s][3];
+                }
+            } else {
+                if (o_rede & 1) acc[s][0] += acc[s][1];
+            }
+        }
+#pragma nounroll
+        for (int b = 0; b < 6; ++b) {
+            if ((o_redl >> b) & 1) {
+#pragma unroll
+                for (int s = 0; s < G; ++s)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if ((e & o_rede) == 0) acc[s][e] += jt_shfl_xor(acc[s][e], 1 << b);
+            }
+        }
+        const bool rep = (lane & o_redl) == 0;
+        const int slot = oo + thr_out;
+        const int nph = 1 << __builtin_popcount((unsigned)o_redw);
+        int myph = 0;
+        if (o_redw == 1) myph = wave & 1;
+        else if (o_redw == 2) myph = wave >> 1;
+        else if (o_redw == 3) myph = wave;
+        for (int ph = 0; ph < nph; ++ph) {
+            if (rep && myph == ph) {
+#pragma unroll
+                for (int s = 0; s < G; ++s) {
+                    double *osub = reinterpret_cast<double *>(sets + s * SETB + o_lds);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if ((e & o_rede) == 0) {
+                            const int eo = ((e & 1) ? o_ew0 : 0) + ((e & 2) ? o_ew1 : 0);
+                            __hip_atomic_fetch_add(&osub[slot + eo], acc[s][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+            if (nph > 1) __syncthreads();
+        }
+#pragma unroll
+        for (int s = 0; s < G; ++s)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[s][e] = 0.0;
+    };
+
+#pragma unroll
+    for (int c = 0; c < JT_NCOL; ++c) asm volatile("" : "+v"(trow[c]));
+
+    // EDEP: some incoming message depends on the element bits of the 16-byte vector (then every message
+    // entry is read per element, four reads; otherwise one read per message serves the four elements).
+    // The choice is made once per workgroup, outside the loop: inside, a step has no branch at all, so the
+    // LDS reads of one evidence set are in flight while the previous set's products are formed.
+    auto step = [&](auto slot_tag, auto edep_tag, const int i) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr bool EDEP = decltype(edep_tag)::value;
+        constexpr int NV = EDEP ? VEC : 1;
+        jt_wait_vmcnt<U - 1>();
+        const VT v = *reinterpret_cast<const VT *>(ring + SLOT * 1024);
+        double p[VEC];
+        p[0] = (double)v.x;
+        p[1] = (double)v.y;
+        if constexpr (VEC == 4) {
+            p[2] = (double)v.z;
+            p[3] = (double)v.w;
+        }
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int inext = (i + U < total) ? i + U : total - 1;
+            jt_dma16(psi + (xF + (uint32_t)__builtin_amdgcn_readlane(trow[0], inext)),
+                     __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
+        }
+        const uint32_t xrow = bk.xF + (uint32_t)__builtin_amdgcn_readlane(trow[0], i);     // uniform: chunk + loop bits
+        const uint32_t rowok = (uint32_t)__ballot(((xrow ^ row_v) & row_m) == 0);         // bit s: the row agrees with set s
+        // byte offsets (inside a set's region) of this thread's entries of every incoming message
+        int ad[NIN > 0 ? NIN : 1][NV];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int base = (__builtin_amdgcn_readlane(trow[1 + k], i) + thr_in[k]) * 8 + in_lds[k];
+            ad[k][0] = base;
+            if constexpr (EDEP) {
+                ad[k][1] = base + in_ew0[k] * 8;
+                if constexpr (VEC == 4) {
+                    ad[k][2] = base + in_ew1[k] * 8;
+                    ad[k][3] = base + (in_ew0[k] + in_ew1[k]) * 8;
+                }
+            }
+        }
+        auto load_set = [&](const int s, double (&dst)[NIN > 0 ? NIN : 1][NV]) {
+            const char *reg = sets + s * SETB;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+#pragma unroll
+                for (int e = 0; e < NV; ++e) dst[k][e] = *reinterpret_cast<const double *>(reg + ad[k][e]);
+        };
+        // A row that contradicts a set's evidence contributes nothing to that set: its factor rs (1.0 or 0.0,
+        // uniform) is the multiplier of the accumulating fma.  Two-stage pipeline over the sets: the entries of
+        // set s + 1 are requested before the products of set s are formed.
+        // (the explicit look-ahead only where it is cheap in registers: one entry per message and set)
+        double cur[NIN > 0 ? NIN : 1][NV], nxt[NIN > 0 ? NIN : 1][NV];
+        if constexpr (!EDEP) load_set(0, cur);
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+            if constexpr (EDEP) load_set(s, cur);
+            else if (s + 1 < G) load_set(s + 1, nxt);
+            const double rs = ((rowok >> s) & 1u) ? 1.0 : 0.0;
+            if constexpr (!EDEP) {
+                // no message depends on the element bits: ONE product of the set's message entries serves the four
+                // elements (NIN multiplications + VEC fused multiply-adds per set and row)
+                double t = rs;
+#pragma unroll
+                for (int k = 0; k < NIN; ++k) t *= cur[k][0];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[s][e] = __builtin_fma(p[e], t, acc[s][e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    double w = p[e];
+#pragma unroll
+                    for (int k = 0; k < NIN; ++k) w *= cur[k][e];
+                    acc[s][e] = __builtin_fma(w, rs, acc[s][e]);
+                }
+            }
+            if constexpr (!EDEP) {
+#pragma unroll
+                for (int k = 0; k < NIN; ++k) cur[k][0] = nxt[k][0];
+            }
+        }
+        if ((i & rmask) == rmask) epilogue(__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], i));
+    };
+
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    using std::integral_constant;
+    bool any_edep = false;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) any_edep = any_edep || in_edep[k] != 0;
+    if (any_edep) {
+        for (int i0 = 0; i0 < total; i0 += U) {
+            step(integral_constant<int, 0>{}, integral_constant<bool, true>{}, i0);
+            step(integral_constant<int, 1>{}, integral_constant<bool, true>{}, i0 + 1);
+            step(integral_constant<int, 2>{}, integral_constant<bool, true>{}, i0 + 2);
+            step(integral_constant<int, 3>{}, integral_constant<bool, true>{}, i0 + 3);
+        }
+    } else {
+        for (int i0 = 0; i0 < total; i0 += U) {
+            step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, i0);
+            step(integral_constant<int, 1>{}, integral_constant<bool, false>{}, i0 + 1);
+            step(integral_constant<int, 2>{}, integral_constant<bool, false>{}, i0 + 2);
+            step(integral_constant<int, 3>{}, integral_constant<bool, false>{}, i0 + 3);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the ring's last (repeated) loads land before LDS is given back
+    stamp[4] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- flush every set's outgoing sub-box as this chunk's partial copy --------------------------------
+    __syncthreads();
+    {
+        const int n = 1 << o_nfree;
+        const bool mark = fl.oth_off >= 0;
+        for (int i = tid; i < n; i += JT_THREADS) {
+            int idx = 0;
+#pragma unroll
+            for (int b = 0; b < JT_MAX_FREE; ++b)
+                if (b < o_nfree) idx += ((i >> b) & 1) << JT_FPOS(ofp, b);
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                double *base = msg0 + (int64_t)s * sstride + o_at + idx;
+                jt_msg_store<FLOW>(base + fl.cur_off, reinterpret_cast<const double *>(sets + s * SETB + o_lds)[i]);
+                if (mark) base[fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
+            }
+        }
+    }
+    if (dbg & 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[5] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.y == 0) {
+            double *o = msg0 + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = (double)stamp[i];
+            o[6] = (double)n_attempts;
+        }
+    }
+}
+
+// Multi-set entry point: grid.y = group of JT_MSETS evidence sets; the block list is that of a whole phase
+// (dataflow launch) or of one tree level.  Workgroups of one group only ever wait for workgroups of the same
+// group earlier in the list.
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_multi_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                            const int *__restrict__ itab, const T *__restrict__ psi,
+                                                            T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28];
+    const uint32_t grp = blockIdx.y;
+    fl.sync += (size_t)grp * fl.sync_stride;
+    if (fl.ev != nullptr) fl.ev += (size_t)grp * JT_MSETS * fl.ev_stride;
+    double *msg0 = msg + (int64_t)grp * JT_MSETS * fl.set_stride;
+    const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
+    const JtBlock &bk = blk[ticket];
+    const JtTask &tk = tasks[bk.task];
+    if (tk.kind != 0) {
+        for (int s = 0; s < JT_MSETS; ++s) jt_reduce<true>(tk, bk, msg0 + (int64_t)s * fl.set_stride, fl);
+        return;
+    }
+    if (tk.setb <= JT_SETB_SMALL) {
+        switch (tk.n_in) {
+            case 0: jt_mpass<T, 0, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 1: jt_mpass<T, 1, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 2: jt_mpass<T, 2, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            default: jt_mpass<T, 3, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+        }
+    } else {
+        switch (tk.n_in) {
+            case 0: jt_mpass<T, 0, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 1: jt_mpass<T, 1, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 2: jt_mpass<T, 2, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            default: jt_mpass<T, 3, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+        }
+    }
+}
+
+// One task list of single-set passes of any shape (read-out of multi-set plans: beliefs and marginals formed on
+// demand from the shared table and one set's final messages; up to four incoming messages).
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS) void jt_single(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                        const int *__restrict__ itab, const T *__restrict__ psi,
+                                                        T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    const JtBlock &bk = blk[blockIdx.x];
+    const JtTask &tk = tasks[bk.task];
+    if (tk.mode == 0) {
+        switch (tk.n_in) {
+            case 0: jt_pass<T, 0, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+            case 1: jt_pass<T, 1, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+            case 2: jt_pass<T, 2, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+            case 3: jt_pass<T, 3, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+            default: jt_pass<T, 4, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        }
+    } else {                                   // belief only: psi * every incoming message
+        switch (tk.n_in) {
+            case 0: jt_pass<T, 0, 0, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+            case 1: jt_pass<T, 1, 0, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+            case 2: jt_pass<T, 2, 0, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+            case 3: jt_pass<T, 3, 0, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+            default: jt_pass<T, 4, 0, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        }
     }
 }
 

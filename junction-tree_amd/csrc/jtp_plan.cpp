@@ -67,9 +67,12 @@ MsgView make_view(const PNode &p, const PSep &s, int psep, bool up) {
 
 // Choose the F / A / R split of the high bits and fill every index table of the task.
 int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int nbits, int real_bits,
-               const std::vector<MsgView> &ins, const std::vector<MsgView> &outs, int block_log2, std::string &err) {
+               const std::vector<MsgView> &ins, const std::vector<MsgView> &outs, int block_log2, std::string &err,
+               int strict_budget = 0) {
     const int TB = hp.TB;
-    const int budget = hp.lds_budget > 0 ? hp.lds_budget : 32 * 1024;
+    // strict_budget (multi-set plans): the sub-boxes of ONE evidence set must fit in that many bytes, whatever
+    // it costs in loop iterations (down to 4) - the kernel reserves exactly that much LDS per set
+    const int budget = strict_budget > 0 ? strict_budget : (hp.lds_budget > 0 ? hp.lds_budget : 32 * 1024);
     // at most 8 partial copies per outgoing message; small levels (few cliques) may use up to 64
     // so that a lone clique still spreads over >= 128 workgroups
     const int PMAX_LOG2 = block_log2 <= 13 ? 6 : 3;
@@ -105,7 +108,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
         int best = -1;
         long best_lds = 0;
         int best_part = 0;
-        for (int b = TB; b < nbits && nbits - popc(F) > TB + 3; ++b) {      // (fitting LDS never goes below 8 iterations:
+        for (int b = TB; b < nbits && nbits - popc(F) > TB + (strict_budget > 0 ? 2 : 3); ++b) {      // (fitting LDS never goes below 8 iterations:
                                                                               //  staging a big sub-box for 4 would cost more than it saves)
             if (F >> b & 1) continue;
             long l = lds_of(F | 1u << b);
@@ -115,6 +118,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
             }
         }
         if (best < 0 || best_lds >= lds_of(F)) {
+            if (strict_budget > 0) FAIL(JTP_EUNSUPPORTED, "message sub-boxes of one evidence set need %ld bytes of LDS (limit %d)", lds_of(F), strict_budget);
             if (lds_of(F) <= 150 * 1024 && max_free(F) <= JT_MAX_FREE) break;   // cannot shrink further
             FAIL(JTP_EUNSUPPORTED, "message sub-boxes do not fit in LDS (%ld bytes)", lds_of(F));
         }
@@ -236,6 +240,11 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     }
     tk.itab_lds = ((lds + 15) & ~15) + JT_STAGE_SCRATCH * tk.n_in;        // sub-boxes, staging scratch per incoming message
     tk.lds_bytes = tk.itab_lds;                           // (the iteration table is register resident)
+    if (strict_budget > 0) {
+        if (lds - JT_RING_BYTES > strict_budget) FAIL(JTP_EUNSUPPORTED, "sub-boxes of one evidence set: %d bytes (limit %d)", lds - JT_RING_BYTES, strict_budget);
+        tk.setb = strict_budget;
+        tk.lds_bytes = JT_RING_BYTES + JT_MSETS * strict_budget;       // ring + one region per evidence set
+    }
     return JTP_OK;
 }
 
@@ -282,6 +291,14 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     hp.block_log2 = d->block_log2;
     hp.layout_policy = d->layout_policy;
     if (getenv("JTP_LAYOUT_POLICY")) hp.layout_policy = atoi(getenv("JTP_LAYOUT_POLICY"));     // experiments
+    hp.multiset = (d->flags & JTP_MULTISET) != 0;
+    if (hp.multiset) {
+        if (d->n_ranks != 1) FAIL(JTP_EUNSUPPORTED, "multi-set plans run on one rank (evidence sets are independent: give every rank its own sets)");
+        // Bit order: "epilogue first" (3) measured 2x faster than "traffic first" (2) on the width-20 tree (fewer
+        // epilogues per row; its sub-boxes still fit the 4 KiB regions).  jtp_plan_create falls back to 2 - the
+        // smallest sub-boxes - when a clique's sub-boxes do not fit one evidence set's LDS region under 3.
+        if (hp.layout_policy == 0) hp.layout_policy = 3;
+    }
     hp.VEC = d->dtype == JTP_F32 ? 4 : 2;
     hp.EB = d->dtype == JTP_F32 ? 2 : 1;
     hp.TB = hp.EB + 8;
@@ -681,9 +698,50 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         int nch = (int)p.children.size();
         for (int phase = 0; phase < 2; ++phase) {
             if (phase == 0 && c == hp.root) continue;
+            if (hp.multiset && phase == 1) {
+                // one marginalisation per child: down_k = sum psi * down_parent * prod_{j != k} up_j (no belief
+                // table is written; beliefs and marginals are formed on demand, jtp_plan_belief_task)
+                for (int j = 0; j < nch; ++j) {
+                    JtTask tk;
+                    memset(&tk, 0, sizeof tk);
+                    tk.pnode = c;
+                    tk.psi_off = p.arena_off;
+                    tk.bel_off = -1;
+                    tk.mode = 0;
+                    std::vector<MsgView> ins, outs;
+                    if (p.psep >= 0) ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
+                    for (int i = 0; i < nch; ++i)
+                        if (i != j) ins.push_back(make_view(p, hp.ps[hp.pn[p.children[i]].psep], hp.pn[p.children[i]].psep, true));
+                    const int ks = hp.pn[p.children[j]].psep;
+                    outs.push_back(make_view(p, hp.ps[ks], ks, false));
+                    int real_bits = 0;
+                    for (int nb : p.nb) real_bits += nb;
+                    std::vector<int32_t> itab;
+                    int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_SMALL);
+                    if (rc != JTP_OK) rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
+                    if (rc != JTP_OK) return rc;
+                    tk.itab_off = (int64_t)hp.itab.size();
+                    hp.itab.insert(hp.itab.end(), itab.begin(), itab.end());
+                    const int ti = (int)hp.tasks.size();
+                    p.down_tasks.push_back(ti);
+                    hp.ps[ks].dn_task = ti;
+                    hp.ps[ks].dn_npart = tk.msg[JT_MAX_IN].npart;
+                    hp.task_variant.push_back(JT_K_MULTI_DISTRIBUTE);
+                    double b = 0, mb = 0;
+                    if (p.real >= 0) b += host_elems(hp.node_vars[p.real]) * esize;
+                    for (auto &m : ins) if (hp.ps[m.psep].node >= 0) mb += host_elems(hp.ps[m.psep].vars) * 8;
+                    if (hp.ps[ks].node >= 0) mb += host_elems(hp.ps[ks].vars) * 8 * 2;      // down message + separator belief
+                    hp.alg_table_bytes += b;
+                    hp.alg_msg_bytes += mb;
+                    task_bytes.push_back(b + mb);
+                    hp.tasks.push_back(tk);
+                }
+                continue;
+            }
             JtTask tk;
             memset(&tk, 0, sizeof tk);
             tk.pnode = c;
+            tk.mode = phase;
             tk.psi_off = p.owner == hp.rank ? p.arena_off : 0;          // other ranks' tasks are not executed here
             tk.bel_off = phase == 1 ? (p.owner == hp.rank ? p.arena_off : 0) : -1;   // virtual cliques too (scratch)
             std::vector<MsgView> ins, outs;
@@ -694,7 +752,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             int real_bits = 0;
             for (int nb : p.nb) real_bits += nb;
             std::vector<int32_t> itab;
-            int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err);
+            int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err,
+                                hp.multiset ? JT_SETB_SMALL : 0);
+            if (rc != JTP_OK && hp.multiset)
+                rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
             if (rc != JTP_OK) return rc;
             tk.itab_off = (int64_t)hp.itab.size();
             hp.itab.insert(hp.itab.end(), itab.begin(), itab.end());
@@ -702,7 +763,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             if (phase == 0) {
                 p.collect_task = ti;
                 hp.ps[p.psep].up_npart = tk.msg[JT_MAX_IN].npart;
-                hp.task_variant.push_back(JT_K_COLLECT0 + nch);
+                hp.task_variant.push_back(hp.multiset ? JT_K_MULTI_COLLECT : JT_K_COLLECT0 + nch);
             } else {
                 p.distribute_task = ti;
                 for (int j = 0; j < nch; ++j) hp.ps[hp.pn[p.children[j]].psep].dn_npart = tk.msg[JT_MAX_IN + j].npart;
@@ -714,6 +775,11 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             for (auto &m : ins) if (hp.ps[m.psep].node >= 0) b += host_elems(hp.ps[m.psep].vars) * 8;
             for (auto &m : outs) if (hp.ps[m.psep].node >= 0) b += host_elems(hp.ps[m.psep].vars) * 8 * (phase == 1 ? 2 : 1);
             task_bytes.push_back(b);
+            if (hp.multiset) {
+                const double tb = p.real >= 0 ? host_elems(hp.node_vars[p.real]) * esize : 0.0;
+                hp.alg_table_bytes += tb;
+                hp.alg_msg_bytes += b - tb;
+            }
             hp.tasks.push_back(tk);
         }
     }
@@ -722,7 +788,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     // A message written as many partial copies costs every consuming workgroup (sub-box x copies)
     // loads before it can start, on the critical path of the small levels near the root.  From
     // `red_min` copies on, a reduce task behind the producer sums them once and consumers read the sum.
-    const int red_min = getenv("JTP_REDUCE_MIN") ? atoi(getenv("JTP_REDUCE_MIN")) : 8;
+    // (multi-set plans: every consumer stages the copies of EIGHT evidence sets - sum from two copies on)
+    const int red_min = getenv("JTP_REDUCE_MIN") ? atoi(getenv("JTP_REDUCE_MIN")) : (hp.multiset ? 2 : 8);
     hp.msg_doubles = 0;
     for (auto &s : hp.ps) {
         bool mine = hp.pn[s.child].owner == hp.rank || hp.pn[s.parent].owner == hp.rank;
@@ -769,6 +836,27 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         JtTask &tk = hp.tasks[t];
         if (tk.kind != 0) continue;
         const PNode &p = hp.pn[tk.pnode];
+        if (hp.multiset && (int)t != p.collect_task) {          // a downward-message task: which child?
+            size_t j = 0;
+            while (j < p.down_tasks.size() && p.down_tasks[j] != (int)t) ++j;
+            int k = 0;
+            if (p.psep >= 0) {
+                tk.msg[k].off = hp.ps[p.psep].dn_roff;
+                tk.msg[k].npart = hp.ps[p.psep].dn_rnpart;
+                tk.msg[k].same_launch = 1;                       // formed by the parent's task in this phase
+                ++k;
+            }
+            for (size_t i = 0; i < p.children.size(); ++i) {
+                if (i == j) continue;
+                const PSep &sp = hp.ps[hp.pn[p.children[i]].psep];
+                tk.msg[k].off = sp.up_roff;
+                tk.msg[k].npart = sp.up_rnpart;
+                tk.msg[k].same_launch = 0;                       // finished by the collect launch
+                ++k;
+            }
+            tk.msg[JT_MAX_IN].off = hp.ps[hp.pn[p.children[j]].psep].dn_off;
+            continue;
+        }
         bool collect = (int)t == p.collect_task;
         int k = 0;
         // same_launch: the producer runs in the same dataflow launch as this consumer (same phase, same
@@ -827,6 +915,11 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         for (int c : by_level(level)) {
             const PNode &p = hp.pn[c];
             if (p.owner != hp.rank) continue;
+            if (hp.multiset) {
+                if (phase == 0 && p.collect_task >= 0) groups[JT_K_MULTI_COLLECT].push_back(p.collect_task);
+                if (phase == 1) for (int t : p.down_tasks) groups[JT_K_MULTI_DISTRIBUTE].push_back(t);
+                continue;
+            }
             int t = phase == 0 ? p.collect_task : p.distribute_task;
             if (t < 0) continue;
             int key = hp.task_variant[t];
@@ -850,7 +943,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
                 L.lds_bytes = std::max(L.lds_bytes, tk.lds_bytes);
                 L.alg_bytes += task_bytes[t];
                 for (int k = 0; k < tk.n_in; ++k) hp.staging_bytes += (double)(1u << tk.nF) * (8.0 * (1 << tk.msg[k].nfree)) * tk.msg[k].npart;
-                hp.table_bytes += (double)((int64_t)1 << tk.nbits) * esize * (phase == 1 ? 2 : 1);
+                hp.table_bytes += (double)((int64_t)1 << tk.nbits) * esize * (phase == 1 && !hp.multiset ? 2 : 1);
             }
             L.nblocks = (int)(hp.blocks.size() - L.blk_off);
             hp.max_lds = std::max(hp.max_lds, L.lds_bytes);
@@ -971,9 +1064,23 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
 
 // ------------------------------------------------------------------------------------------
 
+// incoming messages of a clique for the read-out tasks: the parent's final downward message, every child's
+// final upward message (what consumers read: the reduced sum where a reduce task exists)
+static void neighbour_inputs(const HostPlan &hp, const PNode &p, std::vector<MsgView> &ins, std::vector<std::pair<int64_t, int>> &src) {
+    if (p.psep >= 0) {
+        ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
+        src.push_back({hp.ps[p.psep].dn_roff, hp.ps[p.psep].dn_rnpart});
+    }
+    for (int k : p.children) {
+        const PSep &sp = hp.ps[hp.pn[k].psep];
+        ins.push_back(make_view(p, sp, hp.pn[k].psep, true));
+        src.push_back({sp.up_roff, sp.up_rnpart});
+    }
+}
+
 int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
                            JtTask &tk, std::vector<int32_t> &itab, int &out_bits, int &npart,
-                           std::vector<JtBlock> &blocks, std::string &err) {
+                           std::vector<JtBlock> &blocks, std::string &err, bool with_neighbours) {
     const PNode &p = hp.pn[pnode];
     PSep s;
     s.vars.assign(out_vars.rbegin(), out_vars.rend());       // last requested variable = lowest bits
@@ -990,15 +1097,52 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int>
     tk.pnode = pnode;
     tk.psi_off = p.arena_off;
     tk.bel_off = -1;
+    tk.mode = 0;
     std::vector<MsgView> ins, outs;
+    std::vector<std::pair<int64_t, int>> src;
+    // multi-set plans keep no belief table: the marginal is taken of psi * (every incoming message) directly
+    if (with_neighbours) neighbour_inputs(hp, p, ins, src);
+    if ((int)ins.size() > JT_MAX_IN) FAIL(JTP_EUNSUPPORTED, "clique with %zu neighbours", ins.size());
     outs.push_back(make_view(p, s, -1, true));
     int real_bits = 0;
     for (int nb : p.nb) real_bits += nb;
     int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
     tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
+    for (size_t k = 0; k < src.size(); ++k) {
+        tk.msg[k].off = src[k].first;
+        tk.msg[k].npart = src[k].second;
+        tk.msg[k].same_launch = 0;
+    }
     out_bits = bit;
     npart = tk.msg[JT_MAX_IN].npart;
+    blocks.clear();
+    for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(tk, 0u, f));
+    return JTP_OK;
+}
+
+int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<int32_t> &itab,
+                         std::vector<JtBlock> &blocks, std::string &err) {
+    const PNode &p = hp.pn[pnode];
+    memset(&tk, 0, sizeof tk);
+    tk.pnode = pnode;
+    tk.psi_off = p.arena_off;
+    tk.bel_off = p.arena_off;
+    tk.mode = 1;
+    std::vector<MsgView> ins, outs;
+    std::vector<std::pair<int64_t, int>> src;
+    neighbour_inputs(hp, p, ins, src);
+    if ((int)ins.size() > JT_MAX_IN) FAIL(JTP_EUNSUPPORTED, "clique with %zu neighbours", ins.size());
+    int real_bits = 0;
+    for (int nb : p.nb) real_bits += nb;
+    int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
+    tk.itab_off = 0;
+    if (rc != JTP_OK) return rc;
+    for (size_t k = 0; k < src.size(); ++k) {
+        tk.msg[k].off = src[k].first;
+        tk.msg[k].npart = src[k].second;
+        tk.msg[k].same_launch = 0;
+    }
     blocks.clear();
     for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(tk, 0u, f));
     return JTP_OK;
@@ -1043,6 +1187,8 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
       << ",\"root\":" << hp.root << ",\"arena_elems\":" << hp.arena_elems << ",\"msg_doubles\":" << hp.msg_doubles
       << ",\"dbg_base\":" << hp.dbg_base << ",\"max_lds\":" << hp.max_lds << ",\"alg_bytes\":" << (long long)hp.alg_bytes
       << ",\"staging_bytes\":" << (long long)hp.staging_bytes << ",\"table_bytes\":" << (long long)hp.table_bytes
+      << ",\"multiset\":" << (hp.multiset ? 1 : 0) << ",\"alg_table_bytes\":" << (long long)hp.alg_table_bytes
+      << ",\"alg_msg_bytes\":" << (long long)hp.alg_msg_bytes
       << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
       << ",\"n_blocks\":" << hp.blocks.size();
     o << ",\"pnodes\":[";
@@ -1051,7 +1197,9 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         if (i) o << ",";
         o << "{\"real\":" << p.real << ",\"parent\":" << p.parent << ",\"psep\":" << p.psep << ",\"depth\":" << p.depth
           << ",\"owner\":" << p.owner << ",\"nbits\":" << p.nbits << ",\"arena_off\":" << p.arena_off
-          << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"vars\":";
+          << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"down_tasks\":";
+        json_vec(o, p.down_tasks);
+        o << ",\"vars\":";
         json_vec(o, p.vars);
         o << ",\"pos\":";
         json_vec(o, p.pos);
@@ -1069,7 +1217,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
           << ",\"up_npart\":" << s.up_npart << ",\"dn_npart\":" << s.dn_npart << ",\"up_off\":" << s.up_off
           << ",\"dn_off\":" << s.dn_off << ",\"up_roff\":" << s.up_roff << ",\"dn_roff\":" << s.dn_roff
           << ",\"up_rnpart\":" << s.up_rnpart << ",\"dn_rnpart\":" << s.dn_rnpart
-          << ",\"up_red_task\":" << s.up_red_task << ",\"dn_red_task\":" << s.dn_red_task << ",\"vars\":";
+          << ",\"up_red_task\":" << s.up_red_task << ",\"dn_red_task\":" << s.dn_red_task << ",\"dn_task\":" << s.dn_task << ",\"vars\":";
         json_vec(o, s.vars);
         o << ",\"pos\":";
         json_vec(o, s.pos);
@@ -1118,7 +1266,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         for (size_t t = 0; t < hp.tasks.size(); ++t) {
             const JtTask &tk = hp.tasks[t];
             if (t) o << ",";
-            o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
+            o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"setb\":" << tk.setb << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
               << ",\"nR\":" << tk.nR << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";

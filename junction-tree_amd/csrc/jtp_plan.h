@@ -20,6 +20,7 @@ struct PNode {                       // a clique of the (binarised) tree
     int owner = 0;                   // owning rank
     int64_t arena_off = -1;          // element offset in the potential/belief arenas (real, owned)
     int collect_task = -1, distribute_task = -1;
+    std::vector<int> down_tasks;     // multi-set plans: one task per child (its downward message), child order
 };
 
 struct PSep {                        // a separator = one message tensor per direction
@@ -34,6 +35,7 @@ struct PSep {                        // a separator = one message tensor per dir
     int64_t up_roff = -1, dn_roff = -1;
     int up_rnpart = 1, dn_rnpart = 1;
     int up_red_task = -1, dn_red_task = -1;
+    int dn_task = -1;                // multi-set plans: the task (at the parent clique) that forms the downward message
 };
 
 struct Launch {
@@ -110,6 +112,10 @@ struct HostPlan {
     int64_t dbg_base = -1;           // JTP_DEBUG & 2: time-stamp region inside the message arena
     int max_lds = 0;
     double alg_bytes = 0;
+    // multi-set plans: algorithmic bytes of one pass over the tables (once per GROUP of JT_MSETS evidence sets)
+    // and of one set's messages (once per set); alg_bytes = table + msg (one group of one set)
+    double alg_table_bytes = 0, alg_msg_bytes = 0;
+    bool multiset = false;
     double staging_bytes = 0;        // message bytes all workgroups load while staging (partial copies included)
     double table_bytes = 0;          // clique-table bytes all workgroups stream (reads + belief writes)
     int n_messages = 0;
@@ -124,6 +130,11 @@ int jtp_build_plan(const jtp_tree_desc *desc, HostPlan &hp, std::string &err);
 // 2^out_bits doubles at msg-arena offset `dst_off`.  Returns JTP_OK or error.
 int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
                            JtTask &task, std::vector<int32_t> &itab, int &out_bits, int &npart, std::vector<JtBlock> &blocks,
-                           std::string &err);
+                           std::string &err, bool with_neighbours = false);
+
+// Multi-set plans keep no belief tables: the belief of clique `pnode` for one evidence set is formed on
+// demand as psi * (every incoming message of that set) into the scratch belief arena (mode 1, no outputs).
+int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &task, std::vector<int32_t> &itab,
+                         std::vector<JtBlock> &blocks, std::string &err);
 
 void jtp_plan_to_json(HostPlan &hp, bool with_tasks);

@@ -19,7 +19,8 @@ JTP_KEEP_ROOT = 4
 JTP_LEVEL_LAUNCHES = 8
 JTP_SHARE_POTENTIALS = 32
 JTP_FLOW_TICKETS = 16
-N_VARIANTS = 17
+JTP_MULTISET = 64
+N_VARIANTS = 20
 
 
 class TreeDesc(C.Structure):

@@ -57,7 +57,7 @@ class Plan:
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
                  layout_policy=0, split_variants=False, keep_root=False, level_launches=False,
-                 flow_tickets=False, share_potentials=False):
+                 flow_tickets=False, share_potentials=False, multiset=False):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
@@ -116,7 +116,9 @@ class Plan:
                    | (_capi.JTP_KEEP_ROOT if keep_root else 0)
                    | (_capi.JTP_LEVEL_LAUNCHES if level_launches else 0)
                    | (_capi.JTP_FLOW_TICKETS if flow_tickets else 0)
-                   | (_capi.JTP_SHARE_POTENTIALS if share_potentials else 0))
+                   | (_capi.JTP_SHARE_POTENTIALS if share_potentials or multiset else 0)
+                   | (_capi.JTP_MULTISET if multiset else 0))
+        self.multiset = bool(multiset)
         d.lds_budget = lds_budget
         d.block_log2 = block_log2
         d.layout_policy = layout_policy
@@ -291,8 +293,10 @@ class Plan:
         for v in range(_capi.N_VARIANTS):
             if st.kernel_launches[v]:
                 name = self._lib.jtp_kernel_name(v).decode().replace("<T", "<" + tname)
-                kernels[name] = {"launches": st.kernel_launches[v], "ms": st.kernel_ms[v],
-                                 "bytes": st.kernel_bytes[v]}
+                k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0})      # (two variants may share a kernel)
+                k["launches"] += st.kernel_launches[v]
+                k["ms"] += st.kernel_ms[v]
+                k["bytes"] += st.kernel_bytes[v]
         return {"n_launches": st.n_launches, "n_messages": st.n_messages, "n_tasks": st.n_tasks,
                 "algorithmic_bytes": st.algorithmic_bytes, "collect_ms": st.collect_ms,
                 "distribute_ms": st.distribute_ms, "kernels": kernels, "flow_fallbacks": st.flow_fallbacks}

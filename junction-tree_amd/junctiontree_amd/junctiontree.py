@@ -162,7 +162,7 @@ class JunctionTree:
         `evidence_sets` is a list of {variable: observed state}; returns one list of factor marginals
         per set, each factor with its full shape (entries contradicting the evidence are zero) and
         every table of set e summing to P(evidence e) * Z.  The clique tables are formed once and
-        shared by all sets (JTP_SHARE_POTENTIALS); the sets run concurrently, one HIP stream each."""
+        shared by all sets; a pass over a table serves eight sets at a time (JTP_MULTISET)."""
         from . import engine
 
         ct = self.clique_tree
@@ -170,8 +170,10 @@ class JunctionTree:
             return []
         all_f32 = all(isinstance(x, np.ndarray) and x.dtype == np.float32 for x in xs)
         node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in self.separators]
+        # one copy of the tables; eight evidence sets per pass over a table (JTP_MULTISET), marginals formed
+        # on demand from the tables and each set's final messages
         plan = engine.plan_for(self.tree, node_vars, ct.factor_graph.sizes, "f32" if all_f32 else "f64",
-                               n_batch=len(evidence_sets), share_potentials=True, **self._opts)
+                               n_batch=len(evidence_sets), multiset=True, **self._opts)
         for c, members in enumerate(ct._members()):
             plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
         for b, observed in enumerate(evidence_sets):

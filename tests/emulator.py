@@ -238,7 +238,8 @@ class Emulator:
             covered += list(range(seg["first_launch"], seg["first_launch"] + seg["n_launch"]))
             self._launch_snapshot = self.msg.copy()
             for blk in d["blocks"][seg["blk_off"]:seg["blk_off"] + seg["nblocks"]]:
-                self._block(d["tasks"][blk[0]], blk[1], seg["phase"] == 0, blk[2:], strict=True)
+                tk = d["tasks"][blk[0]]
+                self._block(tk, blk[1], tk["mode"] == 0, blk[2:], strict=True)
         assert covered == list(range(len(d["launches"])))
 
     def propagate(self, comm=None):
@@ -259,8 +260,11 @@ class Emulator:
                 tk = d["tasks"][t]
                 assert t in launch["tasks"]
                 assert launch["variant"] in (tk["variant"], 12 + launch["phase"])      # per level or per shape
-                assert tk["kind"] == 1 or (tk["variant"] < 4) == (launch["phase"] == 0)
+                if d.get("multiset"):       # every task of a multi-set plan is a marginalisation (mode 0)
+                    assert tk["kind"] == 1 or (tk["mode"] == 0 and tk["variant"] == 17 + launch["phase"] and tk["setb"] in (4096, 16384))
+                else:
+                    assert tk["kind"] == 1 or ((tk["variant"] < 4) == (launch["phase"] == 0) and tk["mode"] == launch["phase"])
                 assert tk["lds_bytes"] <= launch["lds_bytes"]
                 seen.add((t, chunk))
-                self._block(tk, chunk, launch["phase"] == 0, blk[2:])
+                self._block(tk, chunk, tk["mode"] == 0, blk[2:])
             assert len(seen) == len(blocks) == sum(1 << d["tasks"][t]["nF"] for t in launch["tasks"])

@@ -598,7 +598,7 @@ def test_fallback_keeps_the_messages_of_sets_already_checked():
     plan.close()
 
 
-@pytest.mark.parametrize("share", [True, False])
+@pytest.mark.parametrize("share", [True, False, "multiset"])
 def test_hard_evidence_sets(share):
     """jtp_set_evidence: evidence sets that differ only by what is observed, with ONE copy of the clique
     tables (JTP_SHARE_POTENTIALS, BASELINE config 5 in miniature) or with a copy each.  Expected values:
@@ -610,7 +610,8 @@ def test_hard_evidence_sets(share):
         n, nb = spec["n_cliques"], 5
         np_dt = np.float32 if dtype == "f32" else np.float64
         base = synthetic.potentials_for(spec, seed=4, dtype=np_dt)
-        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, n_batch=nb, share_potentials=share)
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, n_batch=nb, share_potentials=bool(share),
+                           multiset=share == "multiset")
         for b in range(nb if not share else 1):
             for c in range(n):
                 plan.set_potential(c, base[c], batch=b)
@@ -647,6 +648,70 @@ def test_hard_evidence_sets(share):
             plan.set_evidence(observed[2], batch=2)
         with pytest.raises(ValueError):
             plan.set_evidence({labels[0]: spec["sizes"][labels[0]]})      # state out of range
+        plan.close()
+
+
+def _indicator_potentials(spec, base, observed):
+    pots = [np.asarray(p, dtype=np.float64).copy() for p in base]
+    for var, state in observed.items():
+        host = next(c for c in range(spec["n_cliques"]) if var in spec["node_vars"][c])
+        ind = np.zeros(spec["sizes"][var])
+        ind[state] = 1.0
+        shape = [1] * pots[host].ndim
+        shape[spec["node_vars"][host].index(var)] = spec["sizes"][var]
+        pots[host] = pots[host] * ind.reshape(shape)
+    return pots
+
+
+@pytest.mark.parametrize("nb", [16, 64, 11])
+def test_multiset_plans_many_evidence_sets(nb):
+    """JTP_MULTISET: evidence sets share the clique tables and are served eight at a
+    time by one pass over a table (jt_multi_flow); B = 16 / 64 sets (and 11: a padded last group) on trees of
+    cardinality 2, 3 and mixed, float64 and float32, dataflow and per-level launches, two propagates (both
+    halves of the message arenas).  Expected: the oracle on indicator-multiplied potentials - every separator
+    belief, Z, and the clique beliefs / marginals formed on demand."""
+    from test_planner_emulated import random_junction_tree
+    cases = [(synthetic.wide_binary_tree(n_cliques=15, width=13, sep=6, card=2, seed=2), "f64", {}),
+             (synthetic.random_tree(n_cliques=9, width=6, sep=3, card=3, seed=4), "f64", {"level_launches": True}),
+             (synthetic.wide_binary_tree(n_cliques=7, width=14, sep=7, card=2, seed=6), "f32", {"block_log2": 11}),
+             (random_junction_tree(np.random.default_rng(77), n_cliques=12, max_width=6)[0], "f64", {"flow_tickets": True})]
+    for ci, (spec, dtype, opts) in enumerate(cases):
+        n = spec["n_cliques"]
+        np_dt = np.float32 if dtype == "f32" else np.float64
+        rng0 = np.random.default_rng(ci)
+        base = [(rng0.uniform(0.5, 1.5, [spec["sizes"][v] for v in spec["node_vars"][c]]) * spec["scales"][c]).astype(np_dt)
+                for c in range(n)]
+        base += [np.ones([spec["sizes"][v] for v in labs]) for labs in spec["node_vars"][n:]]      # separators (unused values)
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, n_batch=nb, multiset=True, **opts)
+        assert plan.describe()["multiset"] == 1
+        for c in range(n):
+            plan.set_potential(c, base[c])
+        labels = sorted(spec["sizes"])
+        observed = []
+        for b in range(nb):
+            rng = np.random.default_rng(500 + b)
+            k = min(len(labels), b % 5)
+            observed.append({labels[i]: int(rng.integers(0, spec["sizes"][labels[i]])) for i in rng.choice(len(labels), size=k, replace=False)})
+            plan.set_evidence(observed[b], batch=b)
+        with pytest.raises(ValueError):
+            plan.propagate(0, 1)                              # all sets of a multi-set plan run together
+        rtol = RTOL32 if dtype == "f32" else RTOL64
+        for rep in range(2):
+            plan.propagate()
+            assert plan.stats()["flow_fallbacks"] == 0
+            check = range(nb) if rep == 0 and nb <= 16 else [0, 1, nb // 2, nb - 1]
+            for b in check:
+                want, z = oracle.beliefs_exact(spec["tree"], _indicator_potentials(spec, base, observed[b]), spec["node_vars"], return_z=True)
+                assert abs(plan.z(batch=b) - z) <= rtol * abs(z) + 1e-300, (ci, b)
+                for node in range(len(spec["node_vars"])):
+                    close(plan.belief(node, batch=b), want[node], rtol=rtol, what="case %d set %d node %d" % (ci, b, node))
+                c = int(np.random.default_rng(b).integers(0, n))
+                lab = list(spec["node_vars"][c])[:2]
+                axes = tuple(range(len(lab), len(spec["node_vars"][c])))
+                close(plan.marginal(c, lab, batch=b), want[c].sum(axis=axes), rtol=rtol, what="marginal")
+            observed[0], observed[nb - 1] = observed[nb - 1], observed[0]       # evidence can be replaced
+            plan.set_evidence(observed[0], batch=0)
+            plan.set_evidence(observed[nb - 1], batch=nb - 1)
         plan.close()
 
 

@@ -275,3 +275,42 @@ def test_renumbered_tree_gives_the_same_beliefs():
     spec = synthetic.renumber(base, np.random.default_rng(0).permutation(9))
     pots = synthetic.potentials_for(spec, seed=4)
     check(spec["tree"], pots, spec["node_vars"], spec["sizes"])
+
+
+@pytest.mark.parametrize("opts", [{}, {"block_log2": 10}, {"layout_policy": 3}, {"keep_root": True, "block_log2": 11}])
+def test_multiset_plans_on_the_emulator(opts):
+    """JTP_MULTISET plans (evidence sets share the tables, eight per pass): every downward message is its own
+    marginalisation task (parent's message and the siblings' upward messages in, one message out), no belief
+    table is written.  The emulator executes one set's tables; separator beliefs (up x down) against the oracle."""
+    specs = [
+        synthetic.chain_tree(n_cliques=5, card=4, width=3),
+        synthetic.wide_binary_tree(n_cliques=7, width=12, sep=6, card=2, seed=1),
+        synthetic.wide_binary_tree(n_cliques=7, width=5, sep=2, card=3, seed=4),
+        synthetic.random_tree(n_cliques=9, width=11, sep=5, card=2, seed=3),
+    ]
+    tree, pots, node_vars, sizes = star(7, card=2, seed=2)          # virtual cliques
+    specs.append({"tree": tree, "node_vars": node_vars, "sizes": sizes, "n_cliques": 8, "pots": pots})
+    for spec in specs:
+        pots = spec.get("pots") or synthetic.potentials_for(spec, seed=21)
+        want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
+        for dtype in ("f64", "f32"):
+            plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, plan_only=True, multiset=True, n_batch=3, **opts)
+            desc = plan.describe()
+            assert desc["multiset"] == 1
+            assert all(t["setb"] in (4096, 16384) and t["lds_bytes"] == 16384 + 8 * t["setb"] for t in desc["tasks"] if t["kind"] == 0)
+            for p in desc["pnodes"]:
+                assert len(p["down_tasks"]) == len(p["children"]) and p["distribute_task"] == -1
+            emu = Emulator(desc)
+            for c in plan.cliques:
+                ids = [plan.var_id[lab] for lab in spec["node_vars"][c]]
+                emu.set_potential(plan.abi_of[c], ids, [spec["sizes"][lab] for lab in spec["node_vars"][c]], pots[c])
+            emu.propagate()
+            level_msg = emu.msg.copy()
+            emu.propagate_flow()
+            np.testing.assert_array_equal(emu.msg, level_msg)
+            psep_of = {s["node"]: i for i, s in enumerate(desc["pseps"]) if s["node"] >= 0}
+            for sn in plan.seps:
+                ids = [plan.var_id[lab] for lab in spec["node_vars"][sn]]
+                got = emu.sep_belief(psep_of[plan.abi_of[sn]], ids, [spec["sizes"][lab] for lab in spec["node_vars"][sn]])
+                np.testing.assert_allclose(got, want[sn], rtol=1e-11, atol=1e-13, err_msg="separator %d" % sn)
+            plan.close()

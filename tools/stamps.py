@@ -20,6 +20,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "c3":
 elif len(sys.argv) > 1 and sys.argv[1] == "c2":
     spec = synthetic.chain_tree(n_cliques=int(sys.argv[2]) if len(sys.argv) > 2 else 64, card=64, width=3)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64")
+elif len(sys.argv) > 1 and sys.argv[1] == "multi":        # multi-set plan on the width-20 tree: [sets] [layout policy]
+    spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", multiset=True,
+                       n_batch=int(sys.argv[2]) if len(sys.argv) > 2 else 8, layout_policy=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 else:
     spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
