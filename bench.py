@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--multiset", action="store_true",
                     help="with --batch: JTP_MULTISET plan - the evidence sets share the tables and every pass over a table "
                          "serves eight sets (no belief tables; beliefs and marginals are formed on demand)")
+    ap.add_argument("--no-replicate-top", action="store_true",
+                    help="N > 1: give the top part of the partition to one rank instead of replicating it on all")
     ap.add_argument("--cliques", type=int, default=256)
     ap.add_argument("--width", type=int, default=20)
     ap.add_argument("--sep", type=int, default=10)
@@ -142,7 +144,8 @@ def main():
     itemsize = 4 if args.dtype == "f32" else 8
     alg = synthetic.algorithmic_bytes(spec, itemsize)
     n = spec["n_cliques"]
-    owner = partition.subtree_owners(spec["parent"], [1.0] * n, world)
+    # the small top part of the partition is replicated on every rank (one exchange per propagate instead of two)
+    owner = partition.subtree_owners(spec["parent"], [1.0] * n, world, replicate_top=not args.no_replicate_top)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=args.dtype,
                        device=device, n_ranks=world, rank=rank, owner=owner, n_batch=args.batch,
                        block_log2=args.block_log2, lds_budget=args.lds_budget,
@@ -219,7 +222,7 @@ def main():
                 "evidence_sets_per_step": args.batch, "shared_potentials": bool(args.share or args.multiset),
                 "multiset": bool(args.multiset),
                 "engine_table_bytes_per_step": stats["algorithmic_bytes"] if args.multiset else None,
-                "parallelism": "1 GPU" if world == 1 else "subtree-sharded x%d, RCCL send/recv at cuts" % world,
+                "parallelism": "1 GPU" if world == 1 else "subtree-sharded x%d, RCCL send/recv at cuts%s" % (world, "" if args.no_replicate_top else ", top part replicated"),
                 "launches_per_step": stats["n_launches"], "Z": z,
             },
         }

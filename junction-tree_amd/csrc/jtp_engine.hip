@@ -501,7 +501,7 @@ int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *hos
     pl->psi_dirty = true;
     HostPlan &hp = pl->hp;
     if (node < 0 || node >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", node);
-    if (hp.pn[node].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", node, hp.pn[node].owner);
+    if (!(hp.pn[node].owner == hp.rank || hp.pn[node].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", node, hp.pn[node].owner);
     if (host_dtype != JTP_F32 && host_dtype != JTP_F64) return set_err(JTP_EINVAL, "bad host dtype");
     JtPackDesc d = hp.pack[node];
     int64_t stride = 1;
@@ -539,7 +539,7 @@ int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32
     pl->psi_dirty = true;
     HostPlan &hp = pl->hp;
     if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
-    if (hp.pn[clique].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
+    if (!(hp.pn[clique].owner == hp.rank || hp.pn[clique].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
     if (n_factors < 0 || (n_factors > 0 && !factors)) return set_err(JTP_EINVAL, "bad factor list");
     const std::vector<int> &cvars = hp.node_vars[clique];
     // lay the tables out in the staging buffer (8-byte slots so that f32 and f64 tables can mix)
@@ -648,7 +648,7 @@ int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double 
     hipStream_t s = pl->streams[batch % pl->streams.size()];
     BatchBuffers &b = pl->bufs[batch];
     for (int c = 0; c < hp.n_cliques; ++c) {
-        if (hp.pn[c].owner != hp.rank) continue;
+        if (!(hp.pn[c].owner == hp.rank || hp.pn[c].owner == hp.n_ranks)) continue;
         const JtPackDesc &d = hp.pack[c];
         const uint64_t key = host_splitmix64(seed * 0x100000001B3ull + (uint64_t)c);
         const double sc = scale ? scale[c] : 1.0;
@@ -1000,7 +1000,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
     BatchBuffers &b = pl->bufs[batch];
     const size_t hsz = host_dtype == JTP_F32 ? 4 : 8;
     if (node < hp.n_cliques) {
-        if (hp.pn[node].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", node, hp.pn[node].owner);
+        if (!(hp.pn[node].owner == hp.rank || hp.pn[node].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", node, hp.pn[node].owner);
         const JtPackDesc &d = hp.pack[node];
         rc = ensure_stage(pl, (size_t)d.host_elems * hsz);
         if (rc) return rc;
@@ -1144,7 +1144,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         for (int i = 0; i < n; ++i) {
             const int clique = cliques[i];
             if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "request %d: node %d is not a clique", i, clique);
-            if (hp.pn[clique].owner != hp.rank) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
+            if (!(hp.pn[clique].owner == hp.rank || hp.pn[clique].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
             const int n_out = var_off[i + 1] - var_off[i];
             if (n_out < 0 || n_out > JT_MAX_VARS) return set_err(JTP_EINVAL, "request %d: bad variable count", i);
             std::vector<int> ov(var_ids + var_off[i], var_ids + var_off[i + 1]);
@@ -1266,7 +1266,8 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
 
 int jtp_get_z(jtp_plan *pl, int32_t batch, double *z) {
     if (!pl) return set_err(JTP_EINVAL, "null plan");
-    if (pl->hp.pn[pl->hp.root].owner != pl->hp.rank) return set_err(JTP_EINVAL, "the root clique belongs to rank %d", pl->hp.pn[pl->hp.root].owner);
+    if (pl->hp.pn[pl->hp.root].owner != pl->hp.rank && pl->hp.pn[pl->hp.root].owner != pl->hp.n_ranks)
+        return set_err(JTP_EINVAL, "the root clique belongs to rank %d", pl->hp.pn[pl->hp.root].owner);
     return jtp_get_marginal(pl, batch, pl->hp.root, nullptr, 0, z);
 }
 

@@ -447,7 +447,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         }
         const int li = i;
         const uint32_t xoff = (uint32_t)__builtin_amdgcn_readlane(trow[0], li);
-        {
+        if (ev_mask != 0) {                                // (uniform: no vector instruction is spent without evidence)
             const uint32_t x0 = xF + xoff;                 // index of this thread's first element in the clique table
 #pragma unroll
             for (int e = 0; e < VEC; ++e)

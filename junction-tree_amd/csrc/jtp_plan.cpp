@@ -328,7 +328,11 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     if (d->clique_owner)
         for (int c = 0; c < N; ++c) {
             hp.owner[c] = d->clique_owner[c];
-            if (hp.owner[c] < 0 || hp.owner[c] >= d->n_ranks) FAIL(JTP_EINVAL, "clique %d: bad owner %d", c, hp.owner[c]);
+            // owner == n_ranks: the clique is REPLICATED - every rank holds its table and runs its tasks (the small
+            // top of a partitioned tree: its children's upward messages go to every rank, its downward messages are
+            // formed where they are consumed, so a propagate needs one exchange instead of two)
+            if (hp.owner[c] < 0 || hp.owner[c] > d->n_ranks || (hp.owner[c] == d->n_ranks && d->n_ranks == 1))
+                FAIL(JTP_EINVAL, "clique %d: bad owner %d", c, hp.owner[c]);
         }
 
     // ---- nodes and separators -------------------------------------------------------------
@@ -374,6 +378,11 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
                 if (!seen[k]) seen[k] = 1, q.push_back(k);
         if ((int)q.size() != N) FAIL(JTP_EINVAL, "parent pointers do not form a tree");
     }
+    const int ALL = hp.n_ranks;                                    // owner value of replicated cliques
+    for (int c = 0; c < N; ++c)
+        if (hp.pn[c].owner == ALL && hp.pn[c].parent >= 0 && hp.pn[hp.pn[c].parent].owner != ALL)
+            FAIL(JTP_EINVAL, "clique %d is replicated but its parent %d is not (the replicated part must contain the root)", c, hp.pn[c].parent);
+    auto mine = [&](int pnode) { return hp.pn[pnode].owner == hp.rank || hp.pn[pnode].owner == ALL; };
 
     // ---- re-root at the tree's centre (single rank): results do not depend on the root (every
     //      belief is psi times ALL incoming messages), but the number of levels = dependent launches
@@ -625,7 +634,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     hp.arena_elems = 0;
     for (int c = 0; c < NP; ++c) {
         PNode &p = hp.pn[c];
-        if (p.owner != hp.rank) continue;
+        if (!mine(c)) continue;
         p.arena_off = hp.arena_elems;
         hp.arena_elems += (int64_t)1 << p.nbits;
         hp.arena_elems = (hp.arena_elems + 255) & ~(int64_t)255;
@@ -660,7 +669,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     // (per owning rank: a rank's launches hold only its own cliques, and every rank must size every
     // task the same way because the partial-copy counts of the cut messages follow from it)
     std::vector<std::vector<double>> lvl_elems[2];
-    for (int ph = 0; ph < 2; ++ph) lvl_elems[ph].assign(hp.n_ranks, std::vector<double>(maxdepth + 1, 0.0));
+    for (int ph = 0; ph < 2; ++ph) lvl_elems[ph].assign(hp.n_ranks + 1, std::vector<double>(maxdepth + 1, 0.0));
     for (int c = 0; c < NP; ++c) {
         double e = (double)((int64_t)1 << hp.pn[c].nbits);
         if (c != hp.root) lvl_elems[0][hp.pn[c].owner][hp.pn[c].depth] += e;
@@ -742,8 +751,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             memset(&tk, 0, sizeof tk);
             tk.pnode = c;
             tk.mode = phase;
-            tk.psi_off = p.owner == hp.rank ? p.arena_off : 0;          // other ranks' tasks are not executed here
-            tk.bel_off = phase == 1 ? (p.owner == hp.rank ? p.arena_off : 0) : -1;   // virtual cliques too (scratch)
+            tk.psi_off = mine(c) ? p.arena_off : 0;          // other ranks' tasks are not executed here
+            tk.bel_off = phase == 1 ? (mine(c) ? p.arena_off : 0) : -1;   // virtual cliques too (scratch)
             std::vector<MsgView> ins, outs;
             if (phase == 1 && p.psep >= 0) ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
             for (int k : p.children) ins.push_back(make_view(p, hp.ps[hp.pn[k].psep], hp.pn[k].psep, true));
@@ -792,8 +801,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     const int red_min = getenv("JTP_REDUCE_MIN") ? atoi(getenv("JTP_REDUCE_MIN")) : (hp.multiset ? 2 : 8);
     hp.msg_doubles = 0;
     for (auto &s : hp.ps) {
-        bool mine = hp.pn[s.child].owner == hp.rank || hp.pn[s.parent].owner == hp.rank;
-        if (!mine) continue;
+        if (!mine(s.child) && !mine(s.parent)) continue;
         int64_t n = (int64_t)1 << s.nbits;
         s.up_off = s.up_roff = hp.msg_doubles;
         hp.msg_doubles += n * s.up_npart;
@@ -865,7 +873,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         if (!collect && p.psep >= 0) {
             tk.msg[k].off = hp.ps[p.psep].dn_roff;
             tk.msg[k].npart = hp.ps[p.psep].dn_rnpart;
-            tk.msg[k].same_launch = hp.pn[p.parent].owner == p.owner;
+            // (a replicated parent forms the message on this rank, in this phase, with no exchange in between)
+            tk.msg[k].same_launch = hp.pn[p.parent].owner == p.owner || hp.pn[p.parent].owner == ALL;
             ++k;
         }
         for (int ch : p.children) {
@@ -914,7 +923,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         std::map<int, std::vector<int>> groups;
         for (int c : by_level(level)) {
             const PNode &p = hp.pn[c];
-            if (p.owner != hp.rank) continue;
+            if (!mine(c)) continue;
             if (hp.multiset) {
                 if (phase == 0 && p.collect_task >= 0) groups[JT_K_MULTI_COLLECT].push_back(p.collect_task);
                 if (phase == 1) for (int t : p.down_tasks) groups[JT_K_MULTI_DISTRIBUTE].push_back(t);
@@ -961,7 +970,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         std::vector<int> tasks;
         for (int c : by_level(level)) {
             const PNode &p = hp.pn[c];
-            if (p.owner != hp.rank) continue;
+            if (!mine(c)) continue;
             if (phase == 0) {
                 if (p.psep >= 0 && hp.ps[p.psep].up_red_task >= 0) tasks.push_back(hp.ps[p.psep].up_red_task);
             } else {
@@ -993,34 +1002,45 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     // between two ranks in ISSUE order, so both sides of a cut must enumerate the cut edges of one level
     // in the same order whatever the numbering of the cliques: always by the CHILD clique of the edge
     // (ascending), never by the parent's position.
-    auto cut_children = [&](int child_level, bool mine_is_child) {
+    // A cut edge joins cliques of different owners.  child (rank r) -> replicated parent: r sends the upward message
+    // to EVERY other rank, the downward message needs no exchange (each rank's replica forms it; only r uses it).
+    auto cut_children = [&](int child_level) {
         std::vector<int> v;                                    // children (ascending) of cut edges at this level
         for (int k : by_level(child_level)) {
             const PNode &ch = hp.pn[k];
-            if (ch.parent < 0) continue;
-            const int po = hp.pn[ch.parent].owner;
-            if (po == ch.owner) continue;
-            if (mine_is_child ? ch.owner == hp.rank : po == hp.rank) v.push_back(k);
+            if (ch.parent >= 0 && hp.pn[ch.parent].owner != ch.owner) v.push_back(k);
         }
         return v;
     };
     for (int level = maxdepth; level >= 0; --level) {          // collect
-        for (int k : cut_children(level + 1, false))           // receive what this level consumes
-            comm_op(0, hp.pn[k].psep, 1, hp.pn[k].owner);
+        for (int k : cut_children(level + 1)) {                // receive what this level consumes
+            const int po = hp.pn[hp.pn[k].parent].owner;
+            if (hp.pn[k].owner != hp.rank && (po == hp.rank || po == ALL)) comm_op(0, hp.pn[k].psep, 1, hp.pn[k].owner);
+        }
         if (level >= 1) {
             emit_launches(0, level);
             emit_reduce(0, level);
         }
-        for (int c : cut_children(level, true))                // send what this level produced
-            comm_op(1, hp.pn[c].psep, 1, hp.pn[hp.pn[c].parent].owner);
+        for (int c : cut_children(level)) {                    // send what this level produced
+            if (hp.pn[c].owner != hp.rank) continue;
+            const int po = hp.pn[hp.pn[c].parent].owner;
+            if (po == ALL) {
+                for (int peer = 0; peer < hp.n_ranks; ++peer)
+                    if (peer != hp.rank) comm_op(1, hp.pn[c].psep, 1, peer);
+            } else comm_op(1, hp.pn[c].psep, 1, po);
+        }
     }
     for (int level = 0; level <= maxdepth; ++level) {          // distribute
-        for (int c : cut_children(level, true))
-            comm_op(0, hp.pn[c].psep, 0, hp.pn[hp.pn[c].parent].owner);
+        for (int c : cut_children(level)) {
+            const int po = hp.pn[hp.pn[c].parent].owner;
+            if (hp.pn[c].owner == hp.rank && po != ALL) comm_op(0, hp.pn[c].psep, 0, po);
+        }
         emit_launches(1, level);
         emit_reduce(1, level);
-        for (int k : cut_children(level + 1, false))
-            comm_op(1, hp.pn[k].psep, 0, hp.pn[k].owner);
+        for (int k : cut_children(level + 1)) {
+            const int po = hp.pn[hp.pn[k].parent].owner;
+            if (po == hp.rank && hp.pn[k].owner != hp.rank) comm_op(1, hp.pn[k].psep, 0, hp.pn[k].owner);
+        }
     }
     flush_comm();
     // ---- dataflow schedule: runs of launches of one phase become one segment --------------------
@@ -1058,7 +1078,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     }
     hp.n_messages = 0;
     for (int c = 0; c < N; ++c)
-        if (c != hp.root && hp.owner[c] == hp.rank) hp.n_messages += 2;
+        if (c != hp.root && (hp.owner[c] == hp.rank || (hp.owner[c] == ALL && hp.rank == 0))) hp.n_messages += 2;
     return JTP_OK;
 }
 

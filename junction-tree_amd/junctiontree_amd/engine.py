@@ -140,7 +140,8 @@ class Plan:
         return json.loads(self._lib.jtp_plan_describe(self._handle).decode())
 
     def owns(self, clique):
-        return self.owner[self.abi_of[clique]] == self.rank
+        """This rank holds the clique: it is the owner, or the clique is replicated (owner == n_ranks)."""
+        return self.owner[self.abi_of[clique]] in (self.rank, self.n_ranks) or self.n_ranks == 1
 
     # ------------------------------------------------------------------ data in
     def set_potential(self, node, array, batch=0):

@@ -12,9 +12,15 @@ gives the top part to the least loaded rank.
 __all__ = ["subtree_owners", "part_weights"]
 
 
-def subtree_owners(parent, weights, n_parts, slack=1.05):
+def subtree_owners(parent, weights, n_parts, slack=1.05, replicate_top=False):
     """parent[c] = parent clique (-1 for the root), weights[c] = cost of clique c (table
-    bytes).  Returns owner[c] in [0, n_parts)."""
+    bytes).  Returns owner[c] in [0, n_parts).
+
+    `replicate_top`: the cliques of the top part get owner `n_parts` = "every rank" instead of
+    being given to the least loaded rank: each rank then holds the top's tables, receives the
+    upward message of every cut edge (the only exchange of a propagate) and forms the top's
+    messages itself, so the downward messages need no exchange and no rank carries the top on
+    top of its own subtree."""
     n = len(parent)
     if n_parts <= 1:
         return [0] * n
@@ -62,15 +68,20 @@ def subtree_owners(parent, weights, n_parts, slack=1.05):
             x = stack.pop()
             owner[x] = r
             stack.extend(children[x])
-    r = min(range(n_parts), key=lambda i: load[i])
+    r = n_parts if replicate_top and top else min(range(n_parts), key=lambda i: load[i])
     for c in top:
         owner[c] = r
-        load[r] += weights[c]
+        if r < n_parts:
+            load[r] += weights[c]
     return owner
 
 
 def part_weights(owner, weights, n_parts):
+    """Load of every rank; a replicated clique (owner == n_parts) counts for every rank."""
     out = [0.0] * n_parts
     for o, w in zip(owner, weights):
-        out[o] += w
+        if o == n_parts:
+            out = [x + w for x in out]
+        else:
+            out[o] += w
     return out

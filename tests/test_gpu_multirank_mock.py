@@ -26,6 +26,7 @@ def _build_mock():
 def _spec(synthetic, recipe, kwargs):
     kwargs = dict(kwargs)
     perm_seed = kwargs.pop("renumber", None)
+    kwargs.pop("replicate_top", None)
     spec = getattr(synthetic, recipe)(**kwargs)
     if perm_seed is not None:           # arbitrary clique numbering (the recipes number breadth first)
         spec = synthetic.renumber(spec, np.random.default_rng(perm_seed).permutation(spec["n_cliques"]))
@@ -53,18 +54,18 @@ def _worker(rank, world, port_file, recipe, kwargs, opts, env, queue):
         spec = _spec(synthetic, recipe, kwargs)
         n = spec["n_cliques"]
         weights = [float(np.prod([spec["sizes"][v] for v in spec["node_vars"][c]])) for c in range(n)]
-        owner = partition.subtree_owners(spec["parent"], weights, world)
+        owner = partition.subtree_owners(spec["parent"], weights, world, replicate_top=kwargs.get("replicate_top", False))
         plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", n_ranks=world, rank=rank,
                            owner=owner, **opts)
         results = []
         for rep in range(3):
             pots = synthetic.potentials_for(spec, seed=40 + rep)
             for c in range(n):
-                if owner[c] == rank:
+                if owner[c] in (rank, world):
                     plan.set_potential(c, pots[c])
             rdzv.barrier()
             plan.propagate()
-            mine = {c: plan.belief(c) for c in range(n) if owner[c] == rank}
+            mine = {c: plan.belief(c) for c in range(n) if owner[c] in (rank, world)}
             z = plan.z() if plan.owns(plan.root) else None
             results.append((mine, z))
         n_comm = len(plan.describe()["comm"])
@@ -86,6 +87,8 @@ def _worker(rank, world, port_file, recipe, kwargs, opts, env, queue):
     (3, "random_tree", {"n_cliques": 14, "width": 11, "sep": 5, "card": 2, "seed": 3}, {"level_launches": True}, {}),
     (2, "chain_tree", {"n_cliques": 9, "card": 8, "width": 3}, {}, {}),
     (3, "random_tree", {"n_cliques": 26, "width": 11, "sep": 5, "card": 2, "seed": 8, "renumber": 2}, {}, {}),
+    (4, "wide_binary_tree", {"n_cliques": 31, "width": 13, "sep": 6, "card": 2, "seed": 5, "replicate_top": True}, {}, {}),
+    (3, "random_tree", {"n_cliques": 28, "width": 11, "sep": 5, "card": 2, "seed": 6, "renumber": 4, "replicate_top": True}, {"level_launches": True}, {}),
 ])
 def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opts, env, tmp_path):
     import multiprocessing as mp
@@ -116,7 +119,7 @@ def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opt
     spec = _spec(synthetic, recipe, kwargs)
     n = spec["n_cliques"]
     owner = got[0][1]
-    assert len(set(owner)) == world
+    assert len(set(owner) - {world}) == world
     for rep in range(3):
         pots = synthetic.potentials_for(spec, seed=40 + rep)
         want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
@@ -129,6 +132,7 @@ def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opt
         assert sorted(seen) == list(range(n))
         for c in range(n):
             np.testing.assert_allclose(seen[c], want[c], rtol=1e-11, atol=1e-13 * np.max(np.abs(want[c])))
-    cuts = sum(1 for c in range(n) if spec["parent"][c] >= 0 and owner[c] != owner[spec["parent"][c]])
-    assert sum(got[r][2] for r in range(world)) == 4 * cuts and cuts >= world - 1
+    cut = [c for c in range(n) if spec["parent"][c] >= 0 and owner[c] != owner[spec["parent"][c]]]
+    assert len(cut) >= world - 1
+    assert sum(got[r][2] for r in range(world)) == sum(2 * (world - 1) if owner[spec["parent"][c]] == world else 4 for c in cut)
     assert all(got[r][3] == 0 for r in range(world))

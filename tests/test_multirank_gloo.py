@@ -38,20 +38,21 @@ def _worker(rank, world, port, recipe, kwargs, queue):
     try:
         kwargs = dict(kwargs)
         perm_seed = kwargs.pop("renumber", None)
+        replicate = kwargs.pop("replicate_top", False)
         spec = getattr(synthetic, recipe)(**kwargs)
         if perm_seed is not None:       # arbitrary clique numbering, as construct_junction_tree produces
             spec = synthetic.renumber(spec, np.random.default_rng(perm_seed).permutation(spec["n_cliques"]))
         n = spec["n_cliques"]
         weights = [float(np.prod([spec["sizes"][v] for v in spec["node_vars"][c]])) for c in range(n)]
-        owner = partition.subtree_owners(spec["parent"], weights, world)
-        assert len(set(owner)) == world
+        owner = partition.subtree_owners(spec["parent"], weights, world, replicate_top=replicate)
+        assert len(set(owner) - {world}) == world and (world in owner) == bool(replicate)
         plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", plan_only=True,
                            n_ranks=world, rank=rank, owner=owner, block_log2=12)
         desc = plan.describe()
         emu = Emulator(desc)
         pots = synthetic.potentials_for(spec, seed=9)
         for c in range(n):
-            if owner[c] == rank:
+            if owner[c] in (rank, world):
                 ids = [plan.var_id[v] for v in spec["node_vars"][c]]
                 emu.set_potential(c, ids, [spec["sizes"][v] for v in spec["node_vars"][c]], pots[c])
 
@@ -77,7 +78,7 @@ def _worker(rank, world, port, recipe, kwargs, queue):
         np.testing.assert_array_equal(emu.bel, level_bel)
         mine = {}
         for c in range(n):
-            if owner[c] == rank:
+            if owner[c] in (rank, world):
                 ids = [plan.var_id[v] for v in spec["node_vars"][c]]
                 mine[c] = emu.belief(c, ids, [spec["sizes"][v] for v in spec["node_vars"][c]])
         n_comm = len(desc["comm"])
@@ -92,9 +93,11 @@ def _worker(rank, world, port, recipe, kwargs, queue):
             assert sorted(seen) == list(range(n))
             for c in range(n):
                 np.testing.assert_allclose(seen[c], want[c], rtol=1e-11, atol=1e-14)
-            cuts = sum(1 for c in range(n) if spec["parent"][c] >= 0 and owner[c] != owner[spec["parent"][c]])
-            # every cut edge carries one message up and one down, seen once by each side
-            assert sum(g[1] for g in gathered) == 4 * cuts
+            cut = [c for c in range(n) if spec["parent"][c] >= 0 and owner[c] != owner[spec["parent"][c]]]
+            cuts = len(cut)
+            # every cut edge carries one message up and one down, seen once by each side; below a replicated
+            # parent the upward message goes to every other rank and the downward one is formed locally
+            assert sum(g[1] for g in gathered) == sum(2 * (world - 1) if owner[spec["parent"][c]] == world else 4 for c in cut)
             queue.put(("ok", cuts))
     except Exception as exc:                        # noqa: BLE001
         queue.put(("error rank %d" % rank, repr(exc)))
@@ -108,6 +111,8 @@ def _worker(rank, world, port, recipe, kwargs, queue):
     ("random_tree", {"n_cliques": 14, "width": 11, "sep": 5, "card": 2, "seed": 3}),
     ("wide_binary_tree", {"n_cliques": 15, "width": 13, "sep": 6, "card": 2, "seed": 4, "reduce_min": "2"}),
     ("random_tree", {"n_cliques": 24, "width": 10, "sep": 4, "card": 2, "seed": 7, "renumber": 5}),
+    ("wide_binary_tree", {"n_cliques": 31, "width": 11, "sep": 5, "card": 2, "seed": 2, "replicate_top": True}),
+    ("random_tree", {"n_cliques": 30, "width": 10, "sep": 4, "card": 2, "seed": 9, "renumber": 3, "replicate_top": True}),
 ])
 def test_two_rank_exchange_schedule(recipe, kwargs, monkeypatch):
     import multiprocessing as mp

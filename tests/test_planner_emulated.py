@@ -268,6 +268,10 @@ def test_exchange_order_matches_on_both_sides_of_every_cut():
         for opts in ({}, {"keep_root": True}):
             sends, recvs = _comm_sequences(spec["tree"], spec["node_vars"], spec["sizes"], owner, world, **opts)
             assert sends == recvs, "trial %d" % trial
+        if trial % 3:            # the top of the partition replicated on every rank: upward messages go to all ranks
+            owner = partition.subtree_owners(spec["parent"], [1.0] * spec["n_cliques"], world, replicate_top=True)
+            sends, recvs = _comm_sequences(spec["tree"], spec["node_vars"], spec["sizes"], owner, world)
+            assert sends == recvs and all(up for seq in sends.values() for _, up, _ in seq), "trial %d (replicated top)" % trial
 
 
 def test_renumbered_tree_gives_the_same_beliefs():

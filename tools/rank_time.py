@@ -15,7 +15,9 @@ world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
 n = spec["n_cliques"]
-owner = partition.subtree_owners(spec["parent"], [1.0] * n, world)
+replicate = not (len(sys.argv) > 3 and sys.argv[3] == "noreplicate")
+owner = partition.subtree_owners(spec["parent"], [1.0] * n, world, replicate_top=replicate)
+print("world %d, top part %s" % (world, "replicated on every rank" if replicate else "on one rank"))
 alg = synthetic.algorithmic_bytes(spec, 4)
 for rank in range(world):
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", n_ranks=world, rank=rank, owner=owner)
@@ -32,6 +34,6 @@ for rank in range(world):
     st = plan.stats()
     d = plan.describe()
     print("rank %d: %3d cliques  %2d launches  %d exchange groups  %.1f us/propagate (collect %.1f, distribute %.1f)  share %.0f MB" % (
-        rank, sum(1 for o in owner if o == rank), st["n_launches"], sum(1 for k, _, _ in d["flow_steps"] if k == 1),
+        rank, sum(1 for o in owner if o in (rank, world)), st["n_launches"], sum(1 for k, _, _ in d["flow_steps"] if k == 1),
         dt * 1e6, st["collect_ms"] * 1e3, st["distribute_ms"] * 1e3, st["algorithmic_bytes"] / 1e6))
     plan.close()
