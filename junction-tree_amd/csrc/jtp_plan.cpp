@@ -165,7 +165,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     }
     tk.nbits = nbits;
     tk.real_bits = real_bits;
-    tk.debug = getenv("JTP_DEBUG") ? atoi(getenv("JTP_DEBUG")) : 0;
+    tk.debug = hp.knobs.debug;
     tk.nF = (int)Fb.size();
     tk.nA = (int)Ab.size();
     tk.nR = (int)Rb.size();
@@ -267,8 +267,29 @@ JtBlock jtp_make_block(const JtTask &tk, uint32_t task_index, uint32_t chunk) {
     return b;
 }
 
+PlanKnobs jtp_read_knobs() {
+    PlanKnobs k;
+    auto geti = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+    auto getd = [](const char *name, double dflt) { const char *v = getenv(name); return v ? atof(v) : dflt; };
+    k.debug = geti("JTP_DEBUG", 0);
+    k.layout_policy = geti("JTP_LAYOUT_POLICY", -1);
+    k.reduce_min = geti("JTP_REDUCE_MIN", -1);
+    k.target_blocks_c = getd("JTP_TARGET_BLOCKS", 1024.0);
+    k.target_blocks_d = getd("JTP_TARGET_BLOCKS_D", k.target_blocks_c);
+    k.min_block_log2 = geti("JTP_MIN_BLOCK_LOG2", 13);
+    k.max_block_log2 = geti("JTP_MAX_BLOCK_LOG2", 16);
+    k.tiny_level_elems = getd("JTP_TINY_LEVEL_ELEMS", 2097152.0);
+    k.force_level_launches = geti("JTP_FORCE_LEVEL_LAUNCHES", 0);
+    k.force_flow = geti("JTP_FORCE_FLOW", 0);
+    k.fake_comm = geti("JTP_FAKE_COMM", 0);
+    k.flow_debug = (unsigned)geti("JTP_FLOW_DEBUG", 0);
+    k.flow_tickets = geti("JTP_FLOW_TICKETS", 0);
+    return k;
+}
+
 int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     if (!d) FAIL(JTP_EINVAL, "null description");
+    hp.knobs = jtp_read_knobs();
     if (d->struct_size != (int32_t)sizeof(jtp_tree_desc))
         FAIL(JTP_EINVAL, "jtp_tree_desc size mismatch (%d vs %zu)", d->struct_size, sizeof(jtp_tree_desc));
     if (d->n_cliques < 1 || d->n_vars < 0) FAIL(JTP_EINVAL, "empty tree");
@@ -290,7 +311,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     hp.lds_budget = d->lds_budget;
     hp.block_log2 = d->block_log2;
     hp.layout_policy = d->layout_policy;
-    if (getenv("JTP_LAYOUT_POLICY")) hp.layout_policy = atoi(getenv("JTP_LAYOUT_POLICY"));     // experiments
+    if (hp.knobs.layout_policy >= 0) hp.layout_policy = hp.knobs.layout_policy;               // experiments
     hp.multiset = (d->flags & JTP_MULTISET) != 0;
     if (hp.multiset) {
         if (d->n_ranks != 1) FAIL(JTP_EUNSUPPORTED, "multi-set plans run on one rank (evidence sets are independent: give every rank its own sets)");
@@ -305,16 +326,23 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     const int N = d->n_cliques;
     const int esize = d->dtype == JTP_F32 ? 4 : 8;
 
+    if ((d->n_vars > 0 && !d->var_card) || !d->node_var_off || !d->parent_clique || !d->parent_sep)
+        FAIL(JTP_EINVAL, "null array in the description");
     hp.card.assign(d->var_card, d->var_card + d->n_vars);
     hp.vbits.resize(d->n_vars);
     for (int v = 0; v < d->n_vars; ++v) {
         if (hp.card[v] < 1) FAIL(JTP_EINVAL, "variable %d has cardinality %d", v, hp.card[v]);
+        if (hp.card[v] > (1 << 28)) FAIL(JTP_EUNSUPPORTED, "variable %d has cardinality %d (max 2^28)", v, hp.card[v]);
         hp.vbits[v] = ceil_log2(hp.card[v]);
     }
     hp.node_vars.resize(d->n_nodes);
+    // (the CSR offsets are the only bound on node_var_ids this ABI has: they must start at 0 and never decrease)
+    if (d->node_var_off[0] != 0) FAIL(JTP_EINVAL, "node_var_off[0] must be 0 (got %d)", d->node_var_off[0]);
+    if (d->node_var_off[d->n_nodes] > 0 && !d->node_var_ids) FAIL(JTP_EINVAL, "null array in the description");
     for (int n = 0; n < d->n_nodes; ++n) {
         int a = d->node_var_off[n], b = d->node_var_off[n + 1];
-        if (b < a || b - a > JT_MAX_VARS) FAIL(JTP_EUNSUPPORTED, "node %d has %d variables (max %d)", n, b - a, JT_MAX_VARS);
+        if (a < 0 || b < a) FAIL(JTP_EINVAL, "node_var_off decreases at node %d (%d, %d)", n, a, b);
+        if (b - a > JT_MAX_VARS) FAIL(JTP_EUNSUPPORTED, "node %d has %d variables (max %d)", n, b - a, JT_MAX_VARS);
         for (int i = a; i < b; ++i) {
             int v = d->node_var_ids[i];
             if (v < 0 || v >= d->n_vars) FAIL(JTP_EINVAL, "node %d: unknown variable %d", n, v);
@@ -680,14 +708,11 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         // aim at ~1024 workgroups per tree level (one round of resident workgroups; in a dataflow launch
         // the next level fills the tail), each streaming 16 KiB .. 256 KiB.  Measured on C4: 1024 is
         // 2-3 % faster than 2048 (which was best with one launch per level), 512 and 4096 slower.
-        static const double target_c = getenv("JTP_TARGET_BLOCKS") ? atof(getenv("JTP_TARGET_BLOCKS")) : 1024.0;
-        static const double target_d = getenv("JTP_TARGET_BLOCKS_D") ? atof(getenv("JTP_TARGET_BLOCKS_D")) : target_c;
-        const double target = phase == 0 ? target_c : target_d;
-        static const int lgmin = getenv("JTP_MIN_BLOCK_LOG2") ? atoi(getenv("JTP_MIN_BLOCK_LOG2")) : 13;
-        static const int lgmax = getenv("JTP_MAX_BLOCK_LOG2") ? atoi(getenv("JTP_MAX_BLOCK_LOG2")) : 16;
+        const double target = phase == 0 ? hp.knobs.target_blocks_c : hp.knobs.target_blocks_d;
+        const int lgmin = hp.knobs.min_block_log2, lgmax = hp.knobs.max_block_log2;
         // levels of a clique or two are latency bound: 4 iterations per workgroup, so that every element
         // load is already in flight while the workgroup waits for its messages
-        static const double tiny = getenv("JTP_TINY_LEVEL_ELEMS") ? atof(getenv("JTP_TINY_LEVEL_ELEMS")) : 2097152.0;
+        const double tiny = hp.knobs.tiny_level_elems;
         if (lvl_elems[phase][owner][level] <= tiny) return hp.TB + JT_MIN_ITER_LOG2;
         double want = lvl_elems[phase][owner][level] / target;
         int lg = lgmin;
@@ -798,7 +823,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     // loads before it can start, on the critical path of the small levels near the root.  From
     // `red_min` copies on, a reduce task behind the producer sums them once and consumers read the sum.
     // (multi-set plans: every consumer stages the copies of EIGHT evidence sets - sum from two copies on)
-    const int red_min = getenv("JTP_REDUCE_MIN") ? atoi(getenv("JTP_REDUCE_MIN")) : (hp.multiset ? 2 : 8);
+    const int red_min = hp.knobs.reduce_min >= 0 ? hp.knobs.reduce_min : (hp.multiset ? 2 : 8);
     hp.msg_doubles = 0;
     for (auto &s : hp.ps) {
         if (!mine(s.child) && !mine(s.parent)) continue;
@@ -1070,7 +1095,7 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         sg.lds_bytes = std::max(sg.lds_bytes, L.lds_bytes);
     }
     hp.sync_words = JT_SYNC_HDR + (int)hp.segments.size();
-    if (getenv("JTP_DEBUG") && (atoi(getenv("JTP_DEBUG")) & 2)) {     // time-stamp region, 8 doubles per workgroup
+    if (hp.knobs.debug & 2) {     // time-stamp region, 8 doubles per workgroup
         hp.dbg_base = hp.msg_doubles;
         hp.msg_doubles += (int64_t)hp.blocks.size() * 8;
         for (const Launch &L : hp.launches)

@@ -79,7 +79,23 @@ struct VirtualFill { int64_t off; int nbits, real_bits; };   // all-ones table o
 // decode chunk number -> workgroup record (element base, message bases, partial numbers)
 JtBlock jtp_make_block(const JtTask &tk, uint32_t task_index, uint32_t chunk);
 
+// Development knobs, read from the environment ONCE per plan (jtp_read_knobs, at the top of jtp_build_plan):
+// nothing else in the product path calls getenv while planning or propagating.
+struct PlanKnobs {
+    int debug = 0;                   // JTP_DEBUG: 1 skip epilogues (timing), 2 in-kernel time stamps, ...
+    int layout_policy = -1;          // JTP_LAYOUT_POLICY overrides jtp_tree_desc.layout_policy
+    int reduce_min = -1;             // JTP_REDUCE_MIN: partial copies from which a reduce task sums them (-1: default)
+    double target_blocks_c = 1024.0, target_blocks_d = 1024.0;     // JTP_TARGET_BLOCKS(_D): workgroups per tree level
+    int min_block_log2 = 13, max_block_log2 = 16;                   // JTP_MIN/MAX_BLOCK_LOG2
+    double tiny_level_elems = 2097152.0;                            // JTP_TINY_LEVEL_ELEMS
+    int force_level_launches = 0, force_flow = 0, fake_comm = 0;   // JTP_FORCE_LEVEL_LAUNCHES / JTP_FORCE_FLOW / JTP_FAKE_COMM
+    unsigned flow_debug = 0;                                        // JTP_FLOW_DEBUG
+    int flow_tickets = 0;                                           // JTP_FLOW_TICKETS
+};
+PlanKnobs jtp_read_knobs();
+
 struct HostPlan {
+    PlanKnobs knobs;
     // copy of the description
     int n_vars = 0, n_cliques = 0, n_nodes = 0, dtype = 0, n_ranks = 1, rank = 0, n_batch = 1;
     int device = 0;

@@ -151,6 +151,7 @@ class Plan:
         if arr.dtype not in (np.float32, np.float64):
             arr = arr.astype(np.float64)
         arr = np.ascontiguousarray(arr).reshape(arr.shape)      # ascontiguousarray makes 0-d 1-d
+        self.__dict__.get("_factor_digests", {}).pop(node, None)    # (JunctionTree.propagate's record of what is staged)
         full = self.node_shape[node]
         if arr.ndim != len(full):
             raise ValueError("potential of node %r has %d axes, its variable list has %d"
@@ -159,12 +160,18 @@ class Plan:
         host_dtype = _capi.JTP_F32 if arr.dtype == np.float32 else _capi.JTP_F64
         _capi.check(self._lib.jtp_set_potential(self._handle, batch, self.abi_of[node],
                                                 arr.ctypes.data_as(C.c_void_p), shape, host_dtype))
+        # uploads are asynchronous (two staging buffers, no stream synchronisation per call): a page-locked
+        # source array must stay alive until the copy has run - hold the last few
+        keep = self.__dict__.setdefault("_uploads", [])
+        keep.append(arr)
+        del keep[:-4]
 
     def set_potential_product(self, node, arrays, var_lists, batch=0):
         """Potential of clique `node` = product of factor tables, formed on the device in the clique's
         layout (`CliqueGraph.evaluate` for one clique, `junctiontree.py:203-226`): only the factor
         tables are uploaded.  `var_lists[i]` labels the axes of `arrays[i]`; an axis may have length
         1 to broadcast.  No factors gives an all-ones potential."""
+        self.__dict__.get("_factor_digests", {}).pop(node, None)
         keep, recs = [], (_capi.Factor * max(len(arrays), 1))()
         for i, (arr, labels) in enumerate(zip(arrays, var_lists)):
             a = np.asarray(arr)
@@ -195,6 +202,7 @@ class Plan:
     def fill_synthetic(self, seed, scales=None, batch=0):
         """Device-side counter-based potentials (see synthetic.synth_values).  `scales` is
         indexed by the caller's clique index."""
+        self.__dict__.pop("_factor_digests", None)
         sc = None
         if scales is not None:
             sc = (C.c_double * self.n_cliques)(*[float(scales[c]) for c in self.cliques])
@@ -211,6 +219,7 @@ class Plan:
 
     def sync(self):
         _capi.check(self._lib.jtp_sync(self._handle))
+        self.__dict__.pop("_uploads", None)
 
     # ------------------------------------------------------------------ data out
     def belief(self, node, batch=0, dtype=np.float64, out=None):

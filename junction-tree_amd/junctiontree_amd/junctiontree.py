@@ -69,6 +69,40 @@ def einsum(xs, xs_keys, y_keys):
     return np.einsum(*call)
 
 
+_DIGEST_LIMIT = 1 << 20          # bytes: larger tables are uploaded again rather than hashed (PCIe beats the hash)
+
+
+def _digest(x):
+    """Content fingerprint of one factor table (shape, dtype, 128-bit hash of the bytes), or None for tables too
+    large to be worth hashing.  Identity is not enough: callers update arrays in place."""
+    a = np.asarray(x)
+    if a.nbytes > _DIGEST_LIMIT:
+        return None
+    try:
+        import xxhash
+        h = xxhash.xxh3_128_digest(np.ascontiguousarray(a).view(np.uint8).reshape(-1).data)
+    except ImportError:               # pragma: no cover - xxhash ships with the image
+        import hashlib
+        h = hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
+    return (a.shape, a.dtype.str, h)
+
+
+def _stage_changed_cliques(plan, ct, xs):
+    """`evaluate` on the device for the cliques whose member factors differ from what `plan` holds.  Returns the
+    number of cliques staged (`plan.staged_cliques` keeps the count of the last call for tests and tools)."""
+    seen = plan.__dict__.setdefault("_factor_digests", {})
+    staged = 0
+    for c, members in enumerate(ct._members()):
+        digests = tuple(_digest(xs[i]) for i in members)
+        if None not in digests and seen.get(c) == digests:
+            continue
+        plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
+        seen[c] = digests
+        staged += 1
+    plan.staged_cliques = staged
+    return staged
+
+
 @dataclass(frozen=True)
 class FactorGraph:
     """Factors (lists of variables) and the size of every variable (`junctiontree.py:83-117`)."""
@@ -149,9 +183,10 @@ class JunctionTree:
         ct = self.clique_tree
         all_f32 = all(isinstance(x, np.ndarray) and x.dtype == np.float32 for x in xs)
         plan = self.plan("f32" if all_f32 else "f64")
-        # evaluate (junctiontree.py:203-226) on the device: only factor tables cross PCIe
-        for c, members in enumerate(ct._members()):
-            plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
+        # evaluate (junctiontree.py:203-226) on the device: only factor tables cross PCIe, and only those of
+        # cliques whose factors changed since this plan last saw them (the reference recomputes every clique on
+        # every call and says so in a FIXME, junctiontree.py:206-214)
+        _stage_changed_cliques(plan, ct, xs)
         plan.propagate()
         # marginalize (junctiontree.py:229-274) on the device, all factors in one launch
         return plan.marginals([(mc, list(fvars)) for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)])
@@ -174,8 +209,7 @@ class JunctionTree:
         # on demand from the tables and each set's final messages
         plan = engine.plan_for(self.tree, node_vars, ct.factor_graph.sizes, "f32" if all_f32 else "f64",
                                n_batch=len(evidence_sets), multiset=True, **self._opts)
-        for c, members in enumerate(ct._members()):
-            plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
+        _stage_changed_cliques(plan, ct, xs)
         for b, observed in enumerate(evidence_sets):
             plan.set_evidence(observed, batch=b)
         plan.propagate(0, len(evidence_sets))

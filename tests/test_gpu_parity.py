@@ -715,6 +715,42 @@ def test_multiset_plans_many_evidence_sets(nb):
         plan.close()
 
 
+def test_propagate_restages_only_cliques_whose_factors_changed(golden):
+    """JunctionTree.propagate keeps a content digest of the factor tables behind every clique of its plan and
+    forms a clique potential again only when one of them changed - also when it was changed IN PLACE (the
+    reference recomputes every clique on every call, FIXME at junctiontree.py:206-214)."""
+    g = golden("networks.npz")
+    net = g.meta["networks"]["abcdefgh"]
+    tree = jt.create_junction_tree(net["factors"], dict(net["sizes"]))
+    values = [np.array(v, dtype=np.float64) for v in g.arrs(net["values"])]
+    ct = tree.clique_tree
+
+    def want(vals):
+        return oracle.propagate(tree.tree, tree.separators, ct.maxcliques, ct.factor_to_maxclique, net["factors"],
+                                net["sizes"], vals)
+
+    engine.clear_plan_cache()
+    out = tree.propagate(values)
+    plan = tree.plan("f64")
+    assert plan.staged_cliques == len(ct.maxcliques)
+    for o, w in zip(out, want(values)):
+        close(o, w)
+    out = tree.propagate([v.copy() for v in values])          # equal content in new arrays: nothing to stage
+    assert plan.staged_cliques == 0
+    for o, w in zip(out, want(values)):
+        close(o, w)
+    values[3] *= 1.5                                          # one factor, modified in place
+    out = tree.propagate(values)
+    assert plan.staged_cliques == 1
+    for o, w in zip(out, want(values)):
+        close(o, w)
+    comp.compute_beliefs(tree.tree, [np.ones([net["sizes"][v] for v in labs]) for labs in list(ct.maxcliques) + list(tree.separators)],
+                         [list(c) for c in ct.maxcliques] + [list(x) for x in tree.separators])
+    out = tree.propagate(values)                              # the plan's tables were overwritten behind propagate's back
+    for o, w in zip(out, want(values)):
+        close(o, w)
+
+
 def test_grid_mrf_through_public_api_vs_bruteforce():
     """Loopy pairwise models (BASELINE config 3 family at brute-forceable size): 3x3, 4x4 and
     3x3x2 binary lattices through create_junction_tree / propagate (the reference is wrong or
