@@ -78,7 +78,8 @@ struct JtTask {
     int32_t mode;              // clique pass: 0 = marginalise (out = sum psi * ALL incoming: collect, and in multi-set
                                // plans every downward message and marginal), 1 = distribute (belief + all-but-one)
     int32_t setb;              // multi-set plans: bytes of LDS per evidence set (JT_SETB_SMALL / JT_SETB_LARGE), else 0
-    int32_t pad0;
+    int32_t settle;            // dataflow launches: 1 = from the second staging attempt on, a thread re-loads an entry it
+                               // finds unwritten itself (plans made of latency-bound levels: chains), see jt_msg_settle
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
     uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base; 0 past the end)
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer

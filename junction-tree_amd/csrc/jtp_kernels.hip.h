@@ -99,6 +99,25 @@ __device__ __forceinline__ void jt_msg_store(double *p, double v) {
         *p = v;
 }
 
+// (FLOW) From the second staging attempt on - the producer is known to be flushing: the polled entry has just
+// arrived - a thread that finds one of ITS entries still unwritten loads that entry again for up to ~1.5 us
+// instead of sending the whole workgroup round the poll-and-reload loop once more (measured: the loop then
+// ends at the second attempt nearly always).
+template <bool FLOW>
+__device__ __forceinline__ double jt_msg_settle(const double *p, double v, bool through, int attempt) {
+#ifndef JT_NO_SETTLE                 // (A/B builds: python junction-tree_amd/build.py --out x.so -DJT_NO_SETTLE)
+    if constexpr (FLOW) {
+        if (attempt > 0 && through) {
+            for (int spins = 0; spins < 24 && jt_unwritten(v); ++spins) {
+                __builtin_amdgcn_s_sleep(2);
+                v = jt_msg_load<true>(p);
+            }
+        }
+    }
+#endif
+    return v;
+}
+
 template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
@@ -173,6 +192,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     int n_attempts = 0;
     for (int attempt = 0;; ++attempt) {
         n_attempts = attempt + 1;
+        // (only in plans made of latency-bound levels, JtTask::settle: chains gain 6 %; next to streaming
+        //  levels the extra loads of waiting workgroups cost 1-2 % - both measured)
+        const int settle_attempt = tk.settle ? attempt : 0;
         const double *unready = nullptr;          // (FLOW) an entry this thread found not written yet
         {
             const double *src[NIN > 0 ? NIN : 1];
@@ -219,6 +241,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                             for (int u = 0; u < 8; ++u) c[u] = (p + u < m.npart) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(p + u) * ps[k] + idx), thr_mem[k]) : 0.0;
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
+                                if (FLOW && p + u < m.npart) c[u] = jt_msg_settle<FLOW>(src[k] + ((int64_t)(p + u) * ps[k] + idx), c[u], thr_mem[k], settle_attempt);
                                 sum += c[u];
                                 if (FLOW && jt_unwritten(c[u])) unready = src[k] + ((int64_t)(p + u) * ps[k] + idx);
                             }
@@ -240,6 +263,8 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 for (int k = 0; k < NIN; ++k)
 #pragma unroll
                     for (int u = 0; u < GC; ++u) {
+                        if (FLOW && grouped[k] && gp0[k] + p + u < gp1[k])
+                            c[k][u] = jt_msg_settle<FLOW>(src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]), c[k][u], thr_mem[k], settle_attempt);
                         psum[k] += c[k][u];
                         if (FLOW && jt_unwritten(c[k][u])) unready = src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]);
                     }

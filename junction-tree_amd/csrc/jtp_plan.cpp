@@ -818,6 +818,12 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         }
     }
 
+    {   // plans whose tasks are mostly the 4-iteration workgroups of latency-bound levels (chains): settle in place
+        size_t tiny = 0;
+        for (const JtTask &tk : hp.tasks) tiny += tk.kind == 0 && tk.total == (1 << JT_MIN_ITER_LOG2);
+        if (2 * tiny > hp.tasks.size())
+            for (JtTask &tk : hp.tasks) tk.settle = 1;
+    }
     // ---- message arena ----------------------------------------------------------------------
     // A message written as many partial copies costs every consuming workgroup (sub-box x copies)
     // loads before it can start, on the critical path of the small levels near the root.  From
