@@ -186,6 +186,7 @@ struct jtp_plan {
     int64_t set_stride = 0;         // doubles between consecutive sets' arenas (both halves)
     uint32_t ev_stride = 0;         // uint32 per set's evidence table
     // read-out of multi-set plans: belief task of each clique, built on first use
+    std::vector<uint32_t> ev_host;  // host copy of ev_all (which tasks may sum their elements first depends on it)
     struct BeliefTask { JtTask *d_task = nullptr; JtBlock *d_blk = nullptr; int *d_tab = nullptr; int nblocks = 0, lds = 0; };
     std::vector<BeliefTask> belief_tasks;
     std::vector<hipStream_t> streams;
@@ -445,6 +446,11 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             else hipLaunchKernelGGL((jt_fill_ones<double>), dim3(grid), dim3(256), 0, pl->streams[0], (double *)b.psi, vf.off, vf.nbits, vf.real_bits);
         }
         CREATE_TRY(hipGetLastError());
+    }
+    if (pl->multiset) {
+        pl->ev_host.assign((size_t)pl->ev_stride * pl->n_groups * JT_MSETS, 0u);
+        for (JtTask &tk : hp.tasks)
+            if (tk.esum & 1) tk.esum |= 2;                     // no evidence yet
     }
     if (!hp.tasks.empty()) {
         CREATE_TRY(hipMalloc((void **)&pl->d_tasks, hp.tasks.size() * sizeof(JtTask)));
@@ -812,6 +818,25 @@ int jtp_set_evidence(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *var_
     HIP_TRY(hipStreamSynchronize(s));                      // a propagate in flight may still read the old table
     if (!b.ev) HIP_TRY(hipMalloc((void **)&b.ev, ev.size() * sizeof(uint32_t)));      // (multi-set plans: a slice of ev_all)
     HIP_TRY(hipMemcpy(b.ev, ev.data(), ev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (pl->multiset) {
+        // a task may sum the elements of a vector before the message product only while NO evidence set observes a
+        // variable on its clique's element bits (JtTask::esum bit 1)
+        std::copy(ev.begin(), ev.end(), pl->ev_host.begin() + (size_t)batch * pl->ev_stride);
+        const uint32_t emask = (1u << hp.EB) - 1u;
+        std::vector<char> on_e(hp.pn.size(), 0);
+        for (size_t sidx = 0; sidx < pl->ev_host.size() / pl->ev_stride; ++sidx)
+            for (size_t p = 0; p < hp.pn.size(); ++p)
+                if (pl->ev_host[sidx * pl->ev_stride + 2 * p] & emask) on_e[p] = 1;
+        for (size_t t = 0; t < hp.tasks.size(); ++t) {
+            JtTask &tk = hp.tasks[t];
+            if (tk.kind != 0 || !(tk.esum & 1)) continue;
+            const int32_t want = 1 | (on_e[tk.pnode] ? 0 : 2);
+            if (want != tk.esum) {
+                tk.esum = want;
+                HIP_TRY(hipMemcpy(&pl->d_tasks[t].esum, &want, sizeof want, hipMemcpyHostToDevice));
+            }
+        }
+    }
     return JTP_OK;
 }
 

@@ -22,6 +22,9 @@
 #define JT_MAX_BITS 31         // max index bits of one clique table
 #define JT_MAX_FREE 13         // max log2(entries) of a staged message sub-box
 #define JT_THREADS 256
+#define JT_REDUCE_ENTRIES 64   // entries of a message summed by one reduce workgroup: its four waves each take a quarter of the
+                               // partial copies of those entries (all loads of a wave in flight together), then the four
+                               // partial sums are added in wave order
 #define JT_RING_BYTES 16384      // LDS bytes at offset 0: per wave a ring of 4 x 1 KiB element slots (LDS-DMA)
 #define JT_STAGE_SCRATCH 2048    // bytes of LDS for staging sums
 #define JT_MIN_ITER_LOG2 2       // a workgroup runs at least 4 loop iterations (one per ring slot)
@@ -74,12 +77,18 @@ struct JtTask {
     int32_t real_bits;         // index bits actually used by variables (<= nbits; rest is padding)
     int32_t debug;             // timing experiments only (JTP_DEBUG): 1 = skip epilogues and flush
     int32_t kind;              // 0: clique pass; 1: reduce task - sum the msg[0].npart partial copies of a
-                               // message (2^nbits entries, 256 per workgroup from entry xF) into msg[JT_MAX_IN].off
+                               // message (2^nbits entries, JT_REDUCE_ENTRIES per workgroup from entry xF) into
+                               // msg[JT_MAX_IN].off (multi-set plans: for all JT_MSETS sets of the group)
     int32_t mode;              // clique pass: 0 = marginalise (out = sum psi * ALL incoming: collect, and in multi-set
                                // plans every downward message and marginal), 1 = distribute (belief + all-but-one)
     int32_t setb;              // multi-set plans: bytes of LDS per evidence set (JT_SETB_SMALL / JT_SETB_LARGE), else 0
     int32_t settle;            // dataflow launches: 1 = from the second staging attempt on, a thread re-loads an entry it
                                // finds unwritten itself (plans made of latency-bound levels: chains), see jt_msg_settle
+    int32_t esum;              // multi-set plans: bit 0 = the element bits of the 16-byte vector are in NO message of this
+                               // task (planner), bit 1 = no evidence set observes a variable on them (engine, updated by
+                               // jtp_set_evidence).  Both set: the four elements are summed BEFORE they meet the message
+                               // product - one fused multiply-add per evidence set and row instead of four.
+    int32_t pad1;
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
     uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base; 0 past the end)
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer

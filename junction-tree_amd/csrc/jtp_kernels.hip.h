@@ -615,36 +615,96 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     }
 }
 
-// Reduce task: entry i of the sum = copy_0[i] + copy_1[i] + ... (in copy order: bit-reproducible), 256
-// entries per workgroup.  In a dataflow launch the copies may still be in the making: every entry is
-// loaded until it is no longer the "unwritten" marker (one poller per wave here; the wait is short,
-// the producers are the workgroups just ahead in the list).
-template <bool FLOW>
+// Reduce task: entry i of the sum = the sum of the partial copies of entry i, JT_REDUCE_ENTRIES entries per
+// workgroup.  Wave w sums copies [w * per, (w + 1) * per) of its lane's entry with ALL its loads in flight at once
+// (up to 16 per lane; a message of 64 copies used to cost eight dependent round trips - 40 us on a loaded chip, the
+// whole critical path of the top of a tree), the four partial sums are then added in wave order: a fixed order,
+// bit-reproducible.  In a dataflow launch the copies may still be in the making: a wave loads until none of its
+// entries is the "unwritten" marker (one poller per wave; the producers are the workgroups just ahead in the list).
+// MULTI (multi-set plans; their messages have few copies): the four waves take two evidence sets each instead of a
+// quarter of the copies - set w, then set w + 4 - and every wave stores its own sums.
+template <bool FLOW, bool MULTI = false>
 __device__ __forceinline__ void jt_reduce(const JtTask &tk, const JtBlock &bk, double *__restrict__ msg_arena,
                                           const JtFlow &fl) {
+    __shared__ double red_part[4][JT_REDUCE_ENTRIES];
+    __shared__ uint32_t red_abort;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = (int64_t)1 << tk.nbits;
-    const int64_t i = (int64_t)bk.xF + threadIdx.x;
+    const int64_t i = (int64_t)bk.xF + lane;
     const JtMsg &src = tk.msg[0];
     const bool active = i < n;
-    const double *copies = msg_arena + fl.cur_off + src.off + (active ? i : 0);
     const int npart = src.npart;
+    if constexpr (MULTI) {
+        for (int set = wave; set < JT_MSETS; set += 4) {
+            double *arena = msg_arena + (int64_t)set * fl.set_stride;
+            const double *copies = arena + fl.cur_off + src.off + (active ? i : 0);
+            double sum = 0.0;
+            uint64_t t0 = 0;
+            for (int p0 = 0; p0 < npart; p0 += 16) {
+                double c[16];
+                for (;;) {
+                    const double *unready = nullptr;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) c[u] = (active && p0 + u < npart) ? jt_msg_load<FLOW>(copies + (int64_t)(p0 + u) * src.pstride) : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (FLOW && jt_unwritten(c[u])) unready = copies + (int64_t)(p0 + u) * src.pstride;
+                    if (!FLOW || (fl.dbg & 4)) break;
+                    const uint64_t have = __ballot(unready != nullptr);
+                    if (have == 0) break;
+                    bool give_up = false;
+                    if (lane == (int)__builtin_ctzll(have)) {
+                        if (t0 == 0) t0 = __builtin_amdgcn_s_memrealtime();
+                        unsigned spins = 0;
+                        while (jt_unwritten(jt_msg_load<true>(unready))) {
+                            if (spins < 4) __builtin_amdgcn_s_sleep(8);
+                            else __builtin_amdgcn_s_sleep(32);
+                            if ((++spins & 15u) == 0) {
+                                if (__hip_atomic_load(fl.sync + JT_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+                                else if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+                                    __hip_atomic_store(fl.sync + JT_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(fl.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    give_up = true;
+                                }
+                                if (give_up) break;
+                            }
+                        }
+                    }
+                    if (__any(give_up)) return;              // (no barrier below on this path: every wave finds the flag itself)
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sum += c[u];
+            }
+            if (active) {
+                const int64_t at = tk.msg[JT_MAX_IN].off + i;
+                jt_msg_store<FLOW>(arena + fl.cur_off + at, sum);
+                if (fl.oth_off >= 0) arena[fl.oth_off + at] = __longlong_as_double((long long)JT_UNWRITTEN);
+            }
+        }
+        return;
+    }
+    const int per = (npart + 3) >> 2;
+    const int p_lo = wave * per, p_hi = (p_lo + per < npart) ? p_lo + per : npart;
+    const double *copies = msg_arena + fl.cur_off + src.off + (active ? i : 0);
     const int64_t ps = src.pstride;
     double sum = 0.0;
     uint64_t t0 = 0;
-    for (int p0 = 0; p0 < npart; p0 += 8) {
-        double c[8];
+    bool gave_up = false;
+    if (threadIdx.x == 0) red_abort = 0;
+    for (int p0 = p_lo; p0 < p_hi && !gave_up; p0 += 16) {
+        double c[16];
         for (;;) {
             const double *unready = nullptr;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = (active && p0 + u < npart) ? jt_msg_load<FLOW>(copies + (int64_t)(p0 + u) * ps) : 0.0;
+            for (int u = 0; u < 16; ++u) c[u] = (active && p0 + u < p_hi) ? jt_msg_load<FLOW>(copies + (int64_t)(p0 + u) * ps) : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (FLOW && jt_unwritten(c[u])) unready = copies + (int64_t)(p0 + u) * ps;
             if (!FLOW || (fl.dbg & 4)) break;
             const uint64_t have = __ballot(unready != nullptr);
             if (have == 0) break;
             bool give_up = false;
-            if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(have)) {
+            if (lane == (int)__builtin_ctzll(have)) {
                 if (t0 == 0) t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
                 while (jt_unwritten(jt_msg_load<true>(unready))) {
@@ -661,14 +721,23 @@ __device__ __forceinline__ void jt_reduce(const JtTask &tk, const JtBlock &bk, d
                     }
                 }
             }
-            if (__any(give_up)) return;          // (no LDS-DMA in flight here; other waves find the abort flag themselves)
+            if (__any(give_up)) {
+                gave_up = true;
+                break;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sum += c[u];
+        for (int u = 0; u < 16; ++u) sum += c[u];
     }
-    if (active) {
+    __syncthreads();                               // (red_abort = 0 is visible)
+    if (gave_up && lane == 0) red_abort = 1;
+    red_part[wave][lane] = sum;
+    __syncthreads();
+    if (red_abort != 0) return;                    // the grid drains; the host runs the propagate again per level
+    if (wave == 0 && active) {
+        const double total = ((red_part[0][lane] + red_part[1][lane]) + red_part[2][lane]) + red_part[3][lane];
         const int64_t at = tk.msg[JT_MAX_IN].off + i;
-        jt_msg_store<FLOW>(msg_arena + fl.cur_off + at, sum);
+        jt_msg_store<FLOW>(msg_arena + fl.cur_off + at, total);
         if (fl.oth_off >= 0) msg_arena[fl.oth_off + at] = __longlong_as_double((long long)JT_UNWRITTEN);
     }
 }
@@ -796,7 +865,7 @@ __global__ __launch_bounds__(JT_THREADS) void jt_distribute_flow(const JtTask *_
 // Evidence: the part of a set's (mask, value) that lies in the ROW bits (chunk + loop bits) is uniform per
 // row - a row that contradicts it is skipped for that set; the part in the thread bits (16-byte vector, lane,
 // wave) is constant over the loop, so it is applied to the register sums in the epilogue, not per element.
-template <typename T, int NIN, int SETB>
+template <typename T, int NIN, int SETB, bool ESUM = false>
 __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                          const T *__restrict__ psi_arena, double *__restrict__ msg0,
                                          const JtFlow &fl, uint32_t *flow_ctl, uint32_t bindex) {
@@ -988,30 +1057,35 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     }
     // row part (chunk and loop bits): lane s keeps set s's mask and value; one compare + ballot per row
     const uint32_t row_m = ev_m & ~TMASK, row_v = ev_v & ~TMASK;
-    double acc[G][VEC];
+    // ESUM (JtTask::esum): no message and no evidence involves the element bits - the elements of a vector are
+    // summed first and ONE accumulator per evidence set is kept
+    constexpr int NACC = ESUM ? 1 : VEC;
+    double acc[G][NACC];
 #pragma unroll
     for (int s = 0; s < G; ++s)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[s][e] = 0.0;
+        for (int e = 0; e < NACC; ++e) acc[s][e] = 0.0;
 
     auto epilogue = [&](const int oo) {
         // thread part of the evidence, then the in-thread and cross-lane sums of every set
 #pragma unroll
         for (int s = 0; s < G; ++s) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
+            for (int e = 0; e < NACC; ++e)
                 if (!((tmatch >> (4 * s + e)) & 1u)) acc[s][e] = 0.0;
-            if constexpr (VEC == 4) {
-                if (o_rede & 1) {
-                    acc[s][0] += acc[s][1];
-                    acc[s][2] += acc[s][3];
+            if constexpr (!ESUM) {
+                if constexpr (VEC == 4) {
+                    if (o_rede & 1) {
+                        acc[s][0] += acc[s][1];
+                        acc[s][2] += acc[s][3];
+                    }
+                    if (o_rede & 2) {
+                        acc[s][0] += acc[s][2];
+                        acc[s][1] += acc[s][3];
+                    }
+                } else {
+                    if (o_rede & 1) acc[s][0] += acc[s][1];
                 }
-                if (o_rede & 2) {
-                    acc[s][0] += acc[s][2];
-                    acc[s][1] += acc[s][3];
-                }
-            } else {
-                if (o_rede & 1) acc[s][0] += acc[s][1];
             }
         }
 #pragma nounroll
@@ -1020,7 +1094,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
 #pragma unroll
                 for (int s = 0; s < G; ++s)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e)
+                    for (int e = 0; e < NACC; ++e)
                         if ((e & o_rede) == 0) acc[s][e] += jt_shfl_xor(acc[s][e], 1 << b);
             }
         }
@@ -1037,7 +1111,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
                 for (int s = 0; s < G; ++s) {
                     double *osub = reinterpret_cast<double *>(sets + s * SETB + o_lds);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
+                    for (int e = 0; e < NACC; ++e) {
                         if ((e & o_rede) == 0) {
                             const int eo = ((e & 1) ? o_ew0 : 0) + ((e & 2) ? o_ew1 : 0);
                             __hip_atomic_fetch_add(&osub[slot + eo], acc[s][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1050,7 +1124,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
 #pragma unroll
         for (int s = 0; s < G; ++s)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[s][e] = 0.0;
+            for (int e = 0; e < NACC; ++e) acc[s][e] = 0.0;
     };
 
 #pragma unroll
@@ -1105,6 +1179,11 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
         // A row that contradicts a set's evidence contributes nothing to that set: its factor rs (1.0 or 0.0,
         // uniform) is the multiplier of the accumulating fma.  Two-stage pipeline over the sets: the entries of
         // set s + 1 are requested before the products of set s are formed.
+        double psum = 0.0;
+        if constexpr (ESUM) {
+            psum = p[0] + p[1];
+            if constexpr (VEC == 4) psum += p[2] + p[3];
+        }
         // (the explicit look-ahead only where it is cheap in registers: one entry per message and set)
         double cur[NIN > 0 ? NIN : 1][NV], nxt[NIN > 0 ? NIN : 1][NV];
         if constexpr (!EDEP) load_set(0, cur);
@@ -1115,12 +1194,15 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
             const double rs = ((rowok >> s) & 1u) ? 1.0 : 0.0;
             if constexpr (!EDEP) {
                 // no message depends on the element bits: ONE product of the set's message entries serves the four
-                // elements (NIN multiplications + VEC fused multiply-adds per set and row)
+                // elements (NIN multiplications + VEC fused multiply-adds per set and row; with ESUM one)
                 double t = rs;
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) t *= cur[k][0];
+                if constexpr (ESUM) acc[s][0] = __builtin_fma(psum, t, acc[s][0]);
+                else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[s][e] = __builtin_fma(p[e], t, acc[s][e]);
+                    for (int e = 0; e < VEC; ++e) acc[s][e] = __builtin_fma(p[e], t, acc[s][e]);
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
@@ -1143,7 +1225,14 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     bool any_edep = false;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) any_edep = any_edep || in_edep[k] != 0;
-    if (any_edep) {
+    if constexpr (ESUM) {                               // (the planner sets JtTask::esum only where no message has element bits)
+        for (int i0 = 0; i0 < total; i0 += U) {
+            step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, i0);
+            step(integral_constant<int, 1>{}, integral_constant<bool, false>{}, i0 + 1);
+            step(integral_constant<int, 2>{}, integral_constant<bool, false>{}, i0 + 2);
+            step(integral_constant<int, 3>{}, integral_constant<bool, false>{}, i0 + 3);
+        }
+    } else if (any_edep) {
         for (int i0 = 0; i0 < total; i0 += U) {
             step(integral_constant<int, 0>{}, integral_constant<bool, true>{}, i0);
             step(integral_constant<int, 1>{}, integral_constant<bool, true>{}, i0 + 1);
@@ -1206,10 +1295,17 @@ __global__ __launch_bounds__(JT_THREADS, 3) void jt_multi_flow(const JtTask *__r
     const JtBlock &bk = blk[ticket];
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
-        for (int s = 0; s < JT_MSETS; ++s) jt_reduce<true>(tk, bk, msg0 + (int64_t)s * fl.set_stride, fl);
+        jt_reduce<true, true>(tk, bk, msg0, fl);
         return;
     }
-    if (tk.setb <= JT_SETB_SMALL) {
+    if (tk.setb <= JT_SETB_SMALL && tk.esum == 3) {
+        switch (tk.n_in) {
+            case 0: jt_mpass<T, 0, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 1: jt_mpass<T, 1, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 2: jt_mpass<T, 2, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            default: jt_mpass<T, 3, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+        }
+    } else if (tk.setb <= JT_SETB_SMALL) {
         switch (tk.n_in) {
             case 0: jt_mpass<T, 0, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
             case 1: jt_mpass<T, 1, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;

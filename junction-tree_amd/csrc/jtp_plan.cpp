@@ -241,6 +241,12 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     tk.itab_lds = ((lds + 15) & ~15) + JT_STAGE_SCRATCH * tk.n_in;        // sub-boxes, staging scratch per incoming message
     tk.lds_bytes = tk.itab_lds;                           // (the iteration table is register resident)
     if (strict_budget > 0) {
+        // element bits in no message of the task: the elements of a 16-byte vector can be summed before they meet
+        // the message product (JtTask::esum bit 0; bit 1 - no evidence on those bits - is the engine's)
+        bool e_free = !outs.empty();
+        for (int k = 0; k < tk.n_in; ++k) e_free = e_free && !tk.msg[k].e_dep;
+        for (int k = 0; k < tk.n_out; ++k) e_free = e_free && tk.msg[JT_MAX_IN + k].red_e == (1 << hp.EB) - 1;
+        tk.esum = e_free ? 1 : 0;
         if (lds - JT_RING_BYTES > strict_budget) FAIL(JTP_EUNSUPPORTED, "sub-boxes of one evidence set: %d bytes (limit %d)", lds - JT_RING_BYTES, strict_budget);
         tk.setb = strict_budget;
         tk.lds_bytes = JT_RING_BYTES + JT_MSETS * strict_budget;       // ring + one region per evidence set
@@ -828,8 +834,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     // A message written as many partial copies costs every consuming workgroup (sub-box x copies)
     // loads before it can start, on the critical path of the small levels near the root.  From
     // `red_min` copies on, a reduce task behind the producer sums them once and consumers read the sum.
-    // (multi-set plans: every consumer stages the copies of EIGHT evidence sets - sum from two copies on)
-    const int red_min = hp.knobs.reduce_min >= 0 ? hp.knobs.reduce_min : (hp.multiset ? 2 : 8);
+    // (multi-set plans: 2 and 8 measured within 4 % of each other on the width-20 tree, 8 ahead)
+    const int red_min = hp.knobs.reduce_min >= 0 ? hp.knobs.reduce_min : 8;
     hp.msg_doubles = 0;
     for (auto &s : hp.ps) {
         if (!mine(s.child) && !mine(s.parent)) continue;
@@ -860,8 +866,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             rt.msg[JT_MAX_IN].off = up ? s.up_roff : s.dn_roff;
             rt.msg[JT_MAX_IN].npart = 1;
             rt.msg[JT_MAX_IN].pstride = (int32_t)n;
-            while ((256 << rt.nF) < n) {
-                rt.f_x[rt.nF] = 256u << rt.nF;
+            while (((int64_t)JT_REDUCE_ENTRIES << rt.nF) < n) {
+                rt.f_x[rt.nF] = (uint32_t)JT_REDUCE_ENTRIES << rt.nF;
                 rt.nF++;
             }
             (up ? s.up_red_task : s.dn_red_task) = (int)hp.tasks.size();
@@ -1317,7 +1323,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         for (size_t t = 0; t < hp.tasks.size(); ++t) {
             const JtTask &tk = hp.tasks[t];
             if (t) o << ",";
-            o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"setb\":" << tk.setb << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
+            o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
               << ",\"nR\":" << tk.nR << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";

@@ -82,8 +82,8 @@ class Emulator:
         src, dst = tk["in"][0], tk["out"][0]
         n = 1 << tk["nbits"]
         x0 = sum(tk["f_x"][j] for j in range(tk["nF"]) if (chunk >> j) & 1)
-        assert x0 == chunk * 256 and record[0] == x0
-        i = x0 + np.arange(256)
+        assert x0 == chunk * 64 and record[0] == x0          # JT_REDUCE_ENTRIES per workgroup
+        i = x0 + np.arange(64)
         i = i[i < n]
         assert src["pstride"] == n
         tot = np.zeros(len(i))
