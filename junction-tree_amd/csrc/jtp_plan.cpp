@@ -293,7 +293,66 @@ PlanKnobs jtp_read_knobs() {
     return k;
 }
 
-int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
+// The planner proper: one method per stage of jtp_build_plan, run in order; what the stages share lives here.
+struct PlanBuilder {
+    const jtp_tree_desc *d;
+    HostPlan &hp;
+    std::string &err;
+    int N = 0, NP = 0, esize = 4, ALL = 1, maxdepth = 0;
+    std::vector<std::vector<double>> lvl_elems[2];       // [phase][owner][level]: elements, to size workgroups
+    std::vector<double> task_bytes;                      // algorithmic bytes of every task
+
+    PlanBuilder(const jtp_tree_desc *desc, HostPlan &plan, std::string &e) : d(desc), hp(plan), err(e) {}
+    bool mine(int pnode) const { return hp.pn[pnode].owner == hp.rank || hp.pn[pnode].owner == ALL; }
+    double host_elems(const std::vector<int> &vars) const {
+        double e = 1;
+        for (int v : vars) e *= hp.card[v];
+        return e;
+    }
+    int block_log2_for(int phase, int level, int owner) const;
+    int read_description();      // validate and copy the caller's description
+    int link_nodes();            // cliques, separators, reachability, replicated part
+    int reroot();                // single rank: root at the tree's centre
+    int binarise();              // at most three children per node (virtual all-ones cliques)
+    int depths();
+    int layouts();               // bit order of every clique and separator table
+    int arenas();                // table offsets, host<->device conversion records
+    int level_work();
+    int make_tasks();            // one task per (clique, phase) - multi-set plans: per (clique, child) in distribute
+    int messages();              // message arena, reduce tasks, message offsets of every task
+    int schedule();              // launches, workgroup records, exchange schedule
+    int finish();                // dataflow segments, sync words, time-stamp region
+    int run() {
+        int (PlanBuilder::*stages[])() = {&PlanBuilder::read_description, &PlanBuilder::link_nodes, &PlanBuilder::reroot,
+                                          &PlanBuilder::binarise, &PlanBuilder::depths, &PlanBuilder::layouts,
+                                          &PlanBuilder::arenas, &PlanBuilder::level_work, &PlanBuilder::make_tasks,
+                                          &PlanBuilder::messages, &PlanBuilder::schedule, &PlanBuilder::finish};
+        for (auto stage : stages) {
+            const int rc = (this->*stage)();
+            if (rc != JTP_OK) return rc;
+        }
+        return JTP_OK;
+    }
+};
+
+int PlanBuilder::block_log2_for(int phase, int level, int owner) const {
+        if (hp.block_log2 > 0) return std::max(hp.block_log2, hp.TB);
+        // aim at ~1024 workgroups per tree level (one round of resident workgroups; in a dataflow launch
+        // the next level fills the tail), each streaming 16 KiB .. 256 KiB.  Measured on C4: 1024 is
+        // 2-3 % faster than 2048 (which was best with one launch per level), 512 and 4096 slower.
+        const double target = phase == 0 ? hp.knobs.target_blocks_c : hp.knobs.target_blocks_d;
+        const int lgmin = hp.knobs.min_block_log2, lgmax = hp.knobs.max_block_log2;
+        // levels of a clique or two are latency bound: 4 iterations per workgroup, so that every element
+        // load is already in flight while the workgroup waits for its messages
+        const double tiny = hp.knobs.tiny_level_elems;
+        if (lvl_elems[phase][owner][level] <= tiny) return hp.TB + JT_MIN_ITER_LOG2;
+        double want = lvl_elems[phase][owner][level] / target;
+        int lg = lgmin;
+        while (lg < lgmax && (double)(1 << (lg + 1)) <= want) ++lg;
+        return std::max(lg, hp.TB);
+    }
+
+int PlanBuilder::read_description() {
     if (!d) FAIL(JTP_EINVAL, "null description");
     hp.knobs = jtp_read_knobs();
     if (d->struct_size != (int32_t)sizeof(jtp_tree_desc))
@@ -329,8 +388,8 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     hp.VEC = d->dtype == JTP_F32 ? 4 : 2;
     hp.EB = d->dtype == JTP_F32 ? 2 : 1;
     hp.TB = hp.EB + 8;
-    const int N = d->n_cliques;
-    const int esize = d->dtype == JTP_F32 ? 4 : 8;
+    N = d->n_cliques;
+    esize = d->dtype == JTP_F32 ? 4 : 8;
 
     if ((d->n_vars > 0 && !d->var_card) || !d->node_var_off || !d->parent_clique || !d->parent_sep)
         FAIL(JTP_EINVAL, "null array in the description");
@@ -369,6 +428,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
                 FAIL(JTP_EINVAL, "clique %d: bad owner %d", c, hp.owner[c]);
         }
 
+    return JTP_OK;
+}
+
+int PlanBuilder::link_nodes() {
     // ---- nodes and separators -------------------------------------------------------------
     hp.pn.assign(N, PNode());
     hp.sep_of_node.assign(d->n_nodes, -1);
@@ -412,12 +475,15 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
                 if (!seen[k]) seen[k] = 1, q.push_back(k);
         if ((int)q.size() != N) FAIL(JTP_EINVAL, "parent pointers do not form a tree");
     }
-    const int ALL = hp.n_ranks;                                    // owner value of replicated cliques
+    ALL = hp.n_ranks;                                              // owner value of replicated cliques
     for (int c = 0; c < N; ++c)
         if (hp.pn[c].owner == ALL && hp.pn[c].parent >= 0 && hp.pn[hp.pn[c].parent].owner != ALL)
             FAIL(JTP_EINVAL, "clique %d is replicated but its parent %d is not (the replicated part must contain the root)", c, hp.pn[c].parent);
-    auto mine = [&](int pnode) { return hp.pn[pnode].owner == hp.rank || hp.pn[pnode].owner == ALL; };
 
+    return JTP_OK;
+}
+
+int PlanBuilder::reroot() {
     // ---- re-root at the tree's centre (single rank): results do not depend on the root (every
     //      belief is psi times ALL incoming messages), but the number of levels = dependent launches
     //      does: a chain of N cliques needs N/2 levels per phase instead of N.
@@ -464,6 +530,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             hp.root = centre;
         }
     }
+    return JTP_OK;
+}
+
+int PlanBuilder::binarise() {
     // ---- binarise: at most 3 children per node, via virtual all-ones cliques ---------------
     for (int c = 0; c < (int)hp.pn.size(); ++c) {
         while (hp.pn[c].children.size() > 3) {
@@ -502,10 +572,14 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             hp.pn[c].children = fresh;
         }
     }
-    const int NP = (int)hp.pn.size();
+    NP = (int)hp.pn.size();
 
+    return JTP_OK;
+}
+
+int PlanBuilder::depths() {
     // ---- depth ------------------------------------------------------------------------------
-    int maxdepth = 0;
+    maxdepth = 0;
     {
         std::vector<int> q{hp.root};
         hp.pn[hp.root].depth = 0;
@@ -517,6 +591,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             }
     }
 
+    return JTP_OK;
+}
+
+int PlanBuilder::layouts() {
     // ---- bit layouts ----------------------------------------------------------------------
     for (int c = 0; c < NP; ++c) {
         PNode &p = hp.pn[c];
@@ -664,6 +742,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         if (bit > 28) FAIL(JTP_EUNSUPPORTED, "separator with %d index bits", bit);
     }
 
+    return JTP_OK;
+}
+
+int PlanBuilder::arenas() {
     // ---- arena offsets (this rank's real cliques) --------------------------------------------
     hp.arena_elems = 0;
     for (int c = 0; c < NP; ++c) {
@@ -699,40 +781,26 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         pd.host_elems = stride;
     }
 
+    return JTP_OK;
+}
+
+int PlanBuilder::level_work() {
     // ---- per (phase, level, rank) work, to size workgroups ----------------------------------------
     // (per owning rank: a rank's launches hold only its own cliques, and every rank must size every
     // task the same way because the partial-copy counts of the cut messages follow from it)
-    std::vector<std::vector<double>> lvl_elems[2];
     for (int ph = 0; ph < 2; ++ph) lvl_elems[ph].assign(hp.n_ranks + 1, std::vector<double>(maxdepth + 1, 0.0));
     for (int c = 0; c < NP; ++c) {
         double e = (double)((int64_t)1 << hp.pn[c].nbits);
         if (c != hp.root) lvl_elems[0][hp.pn[c].owner][hp.pn[c].depth] += e;
         lvl_elems[1][hp.pn[c].owner][hp.pn[c].depth] += e;
     }
-    auto block_log2_for = [&](int phase, int level, int owner) {
-        if (hp.block_log2 > 0) return std::max(hp.block_log2, hp.TB);
-        // aim at ~1024 workgroups per tree level (one round of resident workgroups; in a dataflow launch
-        // the next level fills the tail), each streaming 16 KiB .. 256 KiB.  Measured on C4: 1024 is
-        // 2-3 % faster than 2048 (which was best with one launch per level), 512 and 4096 slower.
-        const double target = phase == 0 ? hp.knobs.target_blocks_c : hp.knobs.target_blocks_d;
-        const int lgmin = hp.knobs.min_block_log2, lgmax = hp.knobs.max_block_log2;
-        // levels of a clique or two are latency bound: 4 iterations per workgroup, so that every element
-        // load is already in flight while the workgroup waits for its messages
-        const double tiny = hp.knobs.tiny_level_elems;
-        if (lvl_elems[phase][owner][level] <= tiny) return hp.TB + JT_MIN_ITER_LOG2;
-        double want = lvl_elems[phase][owner][level] / target;
-        int lg = lgmin;
-        while (lg < lgmax && (double)(1 << (lg + 1)) <= want) ++lg;
-        return std::max(lg, hp.TB);
-    };
 
+    return JTP_OK;
+}
+
+int PlanBuilder::make_tasks() {
     // ---- tasks ------------------------------------------------------------------------------
-    auto host_elems = [&](const std::vector<int> &vars) {
-        double e = 1;
-        for (int v : vars) e *= hp.card[v];
-        return e;
-    };
-    std::vector<double> task_bytes;
+    task_bytes.clear();
     for (int c = 0; c < NP; ++c) {
         PNode &p = hp.pn[c];
         int nch = (int)p.children.size();
@@ -824,6 +892,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         }
     }
 
+    return JTP_OK;
+}
+
+int PlanBuilder::messages() {
     {   // plans whose tasks are mostly the 4-iteration workgroups of latency-bound levels (chains): settle in place
         size_t tiny = 0;
         for (const JtTask &tk : hp.tasks) tiny += tk.kind == 0 && tk.total == (1 << JT_MIN_ITER_LOG2);
@@ -926,6 +998,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
             for (size_t j = 0; j < p.children.size(); ++j) tk.msg[JT_MAX_IN + j].off = hp.ps[hp.pn[p.children[j]].psep].dn_off;
     }
 
+    return JTP_OK;
+}
+
+int PlanBuilder::schedule() {
     // ---- launches, blocks, exchange schedule -----------------------------------------------------
     hp.alg_bytes = 0;
     hp.max_lds = 0;
@@ -1080,6 +1156,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
         }
     }
     flush_comm();
+    return JTP_OK;
+}
+
+int PlanBuilder::finish() {
     // ---- dataflow schedule: runs of launches of one phase become one segment --------------------
     for (const Step &st : hp.steps) {
         if (st.kind == 1) {
@@ -1117,6 +1197,10 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
     for (int c = 0; c < N; ++c)
         if (c != hp.root && (hp.owner[c] == hp.rank || (hp.owner[c] == ALL && hp.rank == 0))) hp.n_messages += 2;
     return JTP_OK;
+}
+
+int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
+    return PlanBuilder(d, hp, err).run();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -207,8 +207,14 @@ class JunctionTree:
         node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in self.separators]
         # one copy of the tables; eight evidence sets per pass over a table (JTP_MULTISET), marginals formed
         # on demand from the tables and each set's final messages
-        plan = engine.plan_for(self.tree, node_vars, ct.factor_graph.sizes, "f32" if all_f32 else "f64",
-                               n_batch=len(evidence_sets), multiset=True, **self._opts)
+        try:
+            plan = engine.plan_for(self.tree, node_vars, ct.factor_graph.sizes, "f32" if all_f32 else "f64",
+                                   n_batch=len(evidence_sets), multiset=True, **self._opts)
+        except ValueError:
+            # separators too large for the per-set LDS regions of a multi-set pass (e.g. 64 x 64 doubles): the sets
+            # still share one copy of the tables but run one pass each, one HIP stream each
+            plan = engine.plan_for(self.tree, node_vars, ct.factor_graph.sizes, "f32" if all_f32 else "f64",
+                                   n_batch=len(evidence_sets), share_potentials=True, **self._opts)
         _stage_changed_cliques(plan, ct, xs)
         for b, observed in enumerate(evidence_sets):
             plan.set_evidence(observed, batch=b)
