@@ -58,6 +58,9 @@ extern "C" {
                                marginals are formed on demand from the shared tables and the set's final messages;
                                jtp_propagate always runs all evidence sets of the plan                        */
 
+#define JTP_NO_COMPACT 128u /* store every clique table padded to powers of two in every variable (round-1 layout).  By
+                               default the rows above the thread part are stored at the true cardinalities         */
+
 typedef struct jtp_plan jtp_plan;
 
 /* Structure of one junction tree.  Mirrors the reference's data model

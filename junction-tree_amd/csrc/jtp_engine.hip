@@ -233,9 +233,19 @@ static int ensure_stage(jtp_plan *pl, size_t bytes) {
     return JTP_OK;
 }
 
+// messages and marginals are plain bit fields: complete the physical part of their layout record
+static void bitfield_desc(JtPackDesc &d) {
+    for (int i = 0; i < d.nvars; ++i) {
+        d.dstride[i] = 1u << d.pos[i];
+        d.dmod[i] = 1 << d.nb[i];
+    }
+    d.phys_elems = (int64_t)1 << d.nbits;
+    d.low_bits = d.nbits;
+}
+
 template <typename T, typename S>
 static void launch_pack(const JtPackDesc &d, const S *stage, T *arena, hipStream_t s) {
-    const int64_t n = (int64_t)1 << d.nbits;
+    const int64_t n = d.phys_elems;
     const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL((jt_pack<T, S, 0>), dim3(grid), dim3(256), 0, s, d, stage, arena, 0ull, 0.0);
 }
@@ -331,13 +341,26 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     jtp_plan *pl = new jtp_plan();
     std::string err;
     int rc = jtp_build_plan(desc, pl->hp, err);
-    if (rc == JTP_EUNSUPPORTED && desc && (desc->flags & JTP_MULTISET) && desc->layout_policy == 0) {
-        // sub-boxes too large for one evidence set's LDS region under the default bit order: smallest sub-boxes
+    // Fall-backs of the planner's defaults, tried in turn while the structure is "unsupported":
+    //  - multi-set plans: sub-boxes too large for one evidence set's LDS region under the default bit order -> the
+    //    order with the smallest sub-boxes;
+    //  - a table that cannot be cut into workgroups without splitting a variable stored at its true cardinality ->
+    //    every table padded to powers of two (the round-1 layout).
+    for (int attempt = 1; attempt < 4 && rc == JTP_EUNSUPPORTED && desc; ++attempt) {
         jtp_tree_desc again = *desc;
-        again.layout_policy = 2;
+        const bool relayout = (attempt & 1) && (desc->flags & JTP_MULTISET) && desc->layout_policy == 0;
+        const bool pad = (attempt & 2) && !(desc->flags & JTP_NO_COMPACT);
+        if (!relayout && !pad) continue;
+        if ((attempt & 1) && !relayout) continue;
+        if ((attempt & 2) && !pad) continue;
+        if (relayout) again.layout_policy = 2;
+        if (pad) again.flags |= JTP_NO_COMPACT;
+        std::string err2;
         delete pl;
         pl = new jtp_plan();
-        rc = jtp_build_plan(&again, pl->hp, err);
+        const int rc2 = jtp_build_plan(&again, pl->hp, err2);
+        if (rc2 == JTP_OK) rc = rc2;
+        else if (rc2 != JTP_EUNSUPPORTED) rc = rc2, err = err2;
     }
     if (rc != JTP_OK) {
         delete pl;
@@ -440,10 +463,10 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     for (auto &b : pl->bufs) {
         if (&b != &pl->bufs[0] && b.psi == pl->bufs[0].psi) continue;          // shared tables: filled once
         for (const VirtualFill &vf : hp.virtual_fills) {
-            const int64_t n = (int64_t)1 << vf.nbits;
+            const int64_t n = vf.d.phys_elems;
             const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
-            if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_fill_ones<float>), dim3(grid), dim3(256), 0, pl->streams[0], (float *)b.psi, vf.off, vf.nbits, vf.real_bits);
-            else hipLaunchKernelGGL((jt_fill_ones<double>), dim3(grid), dim3(256), 0, pl->streams[0], (double *)b.psi, vf.off, vf.nbits, vf.real_bits);
+            if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_pack<float, float, 2>), dim3(grid), dim3(256), 0, pl->streams[0], vf.d, (const float *)nullptr, (float *)b.psi, 0ull, 1.0);
+            else hipLaunchKernelGGL((jt_pack<double, double, 2>), dim3(grid), dim3(256), 0, pl->streams[0], vf.d, (const double *)nullptr, (double *)b.psi, 0ull, 1.0);
         }
         CREATE_TRY(hipGetLastError());
     }
@@ -598,7 +621,11 @@ int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32
     HIP_TRY(hipSetDevice(hp.device));
     hipStream_t s = pl->streams[batch % pl->streams.size()];
     BatchBuffers &b = pl->bufs[batch];
-    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
+    // the kernel's records (one per pass of JT_EVAL_MAX_F factors) travel in front of the tables
+    const size_t descb = (sizeof(JtEvalDesc) + 255) & ~(size_t)255;
+    const size_t npass = (size_t)std::max(1, (n_factors + JT_EVAL_MAX_F - 1) / JT_EVAL_MAX_F);
+    const size_t tables_at = npass * descb;
+    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256) + tables_at;
     if (pl->eval_pending && pl->eval_stream != s) {        // another evidence set's kernels may still read the buffer
         HIP_TRY(hipStreamSynchronize(pl->eval_stream));
         pl->eval_pending = false;
@@ -625,13 +652,13 @@ int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32
     pl->eval_stream = s;
     pl->eval_pending = true;
     for (int f = 0; f < n_factors; ++f)
-        memcpy(hstage + offs[f] * 8, factors[f].host, (size_t)elems[f] * (factors[f].dtype == JTP_F32 ? 4 : 8));
-    if (n_factors > 0) HIP_TRY(hipMemcpyAsync(stage, hstage, bytes, hipMemcpyHostToDevice, s));
-    const int64_t n = (int64_t)1 << hp.pack[clique].nbits;
+        memcpy(hstage + tables_at + offs[f] * 8, factors[f].host, (size_t)elems[f] * (factors[f].dtype == JTP_F32 ? 4 : 8));
+    const int64_t n = hp.pack[clique].phys_elems;
     const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
     int done = 0;
+    size_t pass = 0;
     do {
-        JtEvalDesc d;
+        JtEvalDesc &d = *reinterpret_cast<JtEvalDesc *>(hstage + pass * descb);
         memset(&d, 0, sizeof d);
         d.clique = hp.pack[clique];
         d.accumulate = done > 0;
@@ -648,15 +675,22 @@ int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32
                 int pos = 0;
                 while (cvars[pos] != v) ++pos;
                 e.cvar[j] = (uint8_t)pos;
+                e.vds[j] = d.clique.dstride[pos];
+                e.vmod[j] = d.clique.dmod[pos];
                 const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
                 e.stride[j] = (len == 1) ? 0 : (int32_t)stride;
                 stride *= len;
             }
         }
-        if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_product<float>), dim3(grid), dim3(256), 0, s, d, (const char *)stage, (float *)b.psi);
-        else hipLaunchKernelGGL((jt_eval_product<double>), dim3(grid), dim3(256), 0, s, d, (const char *)stage, (double *)b.psi);
         done += d.nf;
+        ++pass;
     } while (done < n_factors);
+    HIP_TRY(hipMemcpyAsync(stage, hstage, bytes, hipMemcpyHostToDevice, s));
+    for (size_t k = 0; k < pass; ++k) {
+        const JtEvalDesc *dd = reinterpret_cast<const JtEvalDesc *>(stage + k * descb);
+        if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_product<float>), dim3(grid), dim3(256), 0, s, dd, (const char *)(stage + tables_at), (float *)b.psi);
+        else hipLaunchKernelGGL((jt_eval_product<double>), dim3(grid), dim3(256), 0, s, dd, (const char *)(stage + tables_at), (double *)b.psi);
+    }
     HIP_TRY(hipGetLastError());
     return JTP_OK;                        // (the caller's tables were copied to pinned memory above)
 }
@@ -683,7 +717,7 @@ int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double 
         const JtPackDesc &d = hp.pack[c];
         const uint64_t key = host_splitmix64(seed * 0x100000001B3ull + (uint64_t)c);
         const double sc = scale ? scale[c] : 1.0;
-        const int64_t n = (int64_t)1 << d.nbits;
+        const int64_t n = d.phys_elems;
         const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
         if (hp.dtype == JTP_F32)
             hipLaunchKernelGGL((jt_pack<float, float, 1>), dim3(grid), dim3(256), 0, s, d, (const float *)nullptr, (float *)b.psi, key, sc);
@@ -1115,6 +1149,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
         stride *= hp.card[v];
     }
     d.host_elems = stride;
+    bitfield_desc(d);
     rc = ensure_stage(pl, (size_t)stride * hsz);
     if (rc) return rc;
     const int grid = (int)std::min<int64_t>((stride + 255) / 256, 4096);
@@ -1235,6 +1270,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
                 stride *= hp.card[ov[a]];
             }
             md.d.host_elems = stride;
+            bitfield_desc(md.d);
             md.src_off = scratch_doubles;
             md.pstride = (int64_t)1 << out_bits;
             md.dst_off = total_out;

@@ -38,6 +38,15 @@
 // start of every propagate the half about to be used holds markers only.
 #define JT_UNWRITTEN 0x7FF8BEEF7FF8BEEFull
 #define JT_MAX_VARS 32         // variables per node
+// Physical layout of a clique table (round 2): the thread part (low TB index bits = one 4 KiB row) stays a bit
+// field; ABOVE it only the rows that exist are stored - a variable that lies wholly above the thread part counts
+// its true cardinality (mixed radix), padding bits store nothing.  Element offsets stay LINEAR in the logical index
+// bits (bit k of a variable weighs 2^k x the variable's stride), so every host-built offset table keeps its form;
+// rows whose digits do not exist (digit >= cardinality, padding bit set) read the arena's ZERO ROW (offset 0) and
+// are marked in the tables with JT_NO_ROW.
+#define JT_NO_ROW 0xFFFFFFFFu
+#define JT_BLOCK_INVALID 1u    // JtBlock::flags: the chunk's own digits do not exist - every row is the zero row (the
+                               // workgroup still writes its - all zero - partial copy and padded message entries)
 // Multi-set plans (JTP_MULTISET): evidence sets that share ONE copy of the clique tables are processed
 // JT_MSETS at a time by every workgroup - a table row is loaded once and multiplied into the messages of
 // each set of the group (kernel jt_multi_*).  Per set a workgroup owns an LDS region of JtTask::setb bytes
@@ -89,8 +98,11 @@ struct JtTask {
                                // jtp_set_evidence).  Both set: the four elements are summed BEFORE they meet the message
                                // product - one fused multiply-add per evidence set and row instead of four.
     int32_t pad1;
-    uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j
-    uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base; 0 past the end)
+    uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j (physical)
+    uint32_t f_lx[JT_MAX_HI];  // logical index weight of F bit j (1 << bit): evidence masks are over the logical index
+    uint8_t loop_pos[8];       // logical index bit of loop-counter bit t (t < nR: R bits, then A bits)
+    uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base; 0 past the end;
+                               // JT_NO_ROW: the row does not exist)
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer
     int32_t total;             // loop iterations per workgroup = 2^(nA + nR), 4 .. 64
     int32_t itab_lds;          // byte offset of the iteration table in dynamic LDS
@@ -127,8 +139,9 @@ struct JtBlock {               // 96 bytes; everything the first element loads n
     int32_t gbase[JT_MAX_MSG]; // per message: global-index base of the chunk's sub-box
     int32_t pnum[JT_MAX_OUT];  // per outgoing message: partial-copy number written by this chunk
     int64_t psi_x0;            // arena element offset of the chunk: task psi_off + xF
-    uint32_t first_x[8];       // copy of the task's first_x
-    uint32_t pad[2];
+    uint32_t first_x[8];       // the task's first_x resolved for this chunk (JT_NO_ROW where the row does not exist)
+    uint32_t lxF;              // logical index of the chunk (F bits deposited): evidence masks
+    uint32_t flags;            // JT_BLOCK_INVALID
 };
 
 // host <-> device layout conversion of one table (pack / unpack / synthetic fill)
@@ -137,10 +150,17 @@ struct JtPackDesc {
     int32_t nbits;             // device index bits (padded)
     int32_t nvars;
     int64_t host_elems;        // product of host cardinalities
-    uint8_t pos[JT_MAX_VARS];  // first device bit of variable i (host axis order)
+    uint8_t pos[JT_MAX_VARS];  // first device bit of variable i (host axis order) in the LOGICAL index
     uint8_t nb[JT_MAX_VARS];   // bits of variable i
     int32_t card[JT_MAX_VARS]; // cardinality
     int64_t hstride[JT_MAX_VARS]; // host C-order stride in elements (0: broadcast axis)
+    // physical layout (tables of cliques; messages and marginals are plain bit fields: dstride = 1 << pos, dmod = 1 << nb)
+    uint32_t dstride[JT_MAX_VARS]; // device element stride of variable i's digit (< 2^31; 32 bits: read with a run-time
+                                  // index out of the kernel-argument segment, where 64-bit elements were mis-read)
+    int32_t dmod[JT_MAX_VARS];    // digits stored along that stride (2^nb where padded, the cardinality where compact)
+    int64_t phys_elems;        // elements of the table as stored (zero row not included)
+    int32_t low_bits;          // index bits of the thread part (one row = 2^low_bits elements)
+    int32_t pad2;
 };
 
 // one request of a batched marginal read-out (jt_marg_unpack): partial copies -> host order
@@ -161,6 +181,10 @@ struct JtEvalFactor {
     int32_t is_f64;
     uint8_t cvar[JT_MAX_VARS]; // position of factor variable j in the clique's host variable list
     int32_t stride[JT_MAX_VARS]; // C-order stride of factor variable j (0: broadcast axis)
+    // where factor variable j's digit sits in the clique's device index (copied from the clique's record by the
+    // host: the kernel indexes these with its loop counter only)
+    uint32_t vds[JT_MAX_VARS];   // device element stride of the digit
+    int32_t vmod[JT_MAX_VARS];   // digits stored along it
 };
 struct JtEvalDesc {
     JtPackDesc clique;

@@ -152,6 +152,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         ev_mask = fl.ev[2 * tk.pnode];
         ev_val = fl.ev[2 * tk.pnode + 1];
     }
+    uint32_t loop_pos[JT_MAX_ITER_LOG2];                // logical index bit of loop-counter bit t (beyond the loop: bit 31, never set)
+#pragma unroll
+    for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) loop_pos[t] = t < tk.nA + tk.nR ? tk.loop_pos[t] : 31u;
+    T *junk_row = bel_arena + ((size_t)1 << (EB + 8)) + (uint32_t)tid * VEC;
 
     // ---- element loads run U iterations ahead of their use.  Iteration i's offsets are row i of
     //      the task's iteration table (host built, held in registers below): the loops do no index
@@ -164,10 +168,15 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // in flight across loop iterations whatever the register allocator does; waits are counted by
     // hand (vmcnt counts loads and stores in issue order on CDNA4).
     const T *psi0 = psi_arena + bk.psi_x0 + (uint32_t)tid * VEC;
+    // rows that do not exist (JT_NO_ROW: a digit beyond a variable's cardinality, a padding bit) read the arena's
+    // zero row; their belief stores go to the row behind it (jtp_internal.h).  The whole chunk may be such.
+    const T *zero_row = psi_arena + (uint32_t)tid * VEC;
+    const bool chunk_ok = !(bk.flags & JT_BLOCK_INVALID);
     const uint32_t ring_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + (uint32_t)wave * (U * 1024);
     const char *ring = smem + wave * (U * 1024) + lane * 16;
 #pragma unroll
-    for (int u = 0; u < U; ++u) jt_dma16(psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
+    for (int u = 0; u < U; ++u)
+        jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
     // The workgroup's iteration table (<= 64 rows of JT_NCOL ints, host built) lives in registers,
     // row r in lane r; a step reads "row i, column c" with v_readlane: no memory latency on the
     // critical path of a step except the message entries themselves.
@@ -467,13 +476,19 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             // operations in flight stays the same in every step.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int inext = (i + U < total) ? i + U : total - 1;
-            jt_dma16(psi + (xF + (uint32_t)__builtin_amdgcn_readlane(trow[0], inext)),
+            const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
+            jt_dma16((xnext == JT_NO_ROW || !chunk_ok) ? zero_row : psi + (xF + xnext),
                      __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
         }
         const int li = i;
         const uint32_t xoff = (uint32_t)__builtin_amdgcn_readlane(trow[0], li);
+        const bool row_ok = xoff != JT_NO_ROW && chunk_ok;   // (uniform)
         if (ev_mask != 0) {                                // (uniform: no vector instruction is spent without evidence)
-            const uint32_t x0 = xF + xoff;                 // index of this thread's first element in the clique table
+            // LOGICAL index of this thread's first element (evidence masks are over index bits, element offsets are
+            // physical): chunk bits + the row's loop bits + thread part
+            uint32_t x0 = bk.lxF + (uint32_t)tid * VEC;
+#pragma unroll
+            for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) x0 += (((uint32_t)i >> t) & 1u) << loop_pos[t];
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 if (((x0 + e) & ev_mask) != ev_val) p[e] = 0.0;
@@ -538,7 +553,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                     ov[2] = (T)b[2];
                     ov[3] = (T)b[3];
                 }
-                __builtin_nontemporal_store(ov, reinterpret_cast<ext_t *>(bel + (xF + xoff)));
+                __builtin_nontemporal_store(ov, reinterpret_cast<ext_t *>(row_ok ? bel + (xF + xoff) : junk_row));
             }
         }
         if constexpr (NOUT > 0) {
@@ -895,8 +910,11 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     const T *psi0 = psi_arena + bk.psi_x0 + (uint32_t)tid * VEC;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + (uint32_t)wave * (U * 1024);
     const char *ring = smem + wave * (U * 1024) + lane * 16;
+    const T *zero_row = psi_arena + (uint32_t)tid * VEC;         // what rows that do not exist read (JT_NO_ROW)
+    const bool chunk_ok = !(bk.flags & JT_BLOCK_INVALID);
 #pragma unroll
-    for (int u = 0; u < U; ++u) jt_dma16(psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
+    for (int u = 0; u < U; ++u)
+        jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
     int trow[JT_NCOL];
     {
         const int r = lane < total ? lane : total - 1;
@@ -1057,6 +1075,10 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     }
     // row part (chunk and loop bits): lane s keeps set s's mask and value; one compare + ballot per row
     const uint32_t row_m = ev_m & ~TMASK, row_v = ev_v & ~TMASK;
+    const bool has_row_ev = __ballot(row_m != 0) != 0;
+    uint32_t loop_pos[JT_MAX_ITER_LOG2];                // logical index bit of loop-counter bit t
+#pragma unroll
+    for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) loop_pos[t] = t < tk.nA + tk.nR ? tk.loop_pos[t] : 31u;
     // ESUM (JtTask::esum): no message and no evidence involves the element bits - the elements of a vector are
     // summed first and ONE accumulator per evidence set is kept
     constexpr int NACC = ESUM ? 1 : VEC;
@@ -1150,10 +1172,15 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
         {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int inext = (i + U < total) ? i + U : total - 1;
-            jt_dma16(psi + (xF + (uint32_t)__builtin_amdgcn_readlane(trow[0], inext)),
+            const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
+            jt_dma16((xnext == JT_NO_ROW || !chunk_ok) ? zero_row : psi + (xF + xnext),
                      __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
         }
-        const uint32_t xrow = bk.xF + (uint32_t)__builtin_amdgcn_readlane(trow[0], i);     // uniform: chunk + loop bits
+        uint32_t xrow = bk.lxF;                             // LOGICAL index of the row (uniform): chunk + loop bits
+        if (has_row_ev) {
+#pragma unroll
+            for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) xrow += (((uint32_t)i >> t) & 1u) << loop_pos[t];
+        }
         const uint32_t rowok = (uint32_t)__ballot(((xrow ^ row_v) & row_m) == 0);         // bit s: the row agrees with set s
         // byte offsets (inside a set's region) of this thread's entries of every incoming message
         int ad[NIN > 0 ? NIN : 1][NV];
@@ -1377,34 +1404,41 @@ __device__ __forceinline__ uint64_t jt_splitmix64(uint64_t x) {
     return z ^ (z >> 31);
 }
 
-// device index -> host index; returns false for padding entries
+// digit of variable i at device (physical) element index x: a shift where the variable is a bit field
+__device__ __forceinline__ int jt_digit(const JtPackDesc &d, int i, uint32_t x) {
+    const uint32_t ds = d.dstride[i];
+    if (ds == (1u << d.pos[i]) && d.dmod[i] == (1 << d.nb[i])) return (int)((x >> d.pos[i]) & ((1u << d.nb[i]) - 1u));
+    return ds > 0 ? (int)((x / ds) % (uint32_t)d.dmod[i]) : 0;
+}
+
+// device index -> host index; returns false for entries that name no table entry (padding inside the thread part)
 __device__ __forceinline__ bool jt_dev_to_host(const JtPackDesc &d, uint32_t x, int64_t &hidx) {
     bool valid = true;
-    int64_t h = 0;
-    int used = 0;
+    int64_t h = 0, back = 0;
     for (int i = 0; i < d.nvars; ++i) {
-        const int nb = d.nb[i];
-        const int digit = (int)((x >> d.pos[i]) & ((1u << nb) - 1u));
+        const int digit = jt_digit(d, i, x);
         valid = valid && (digit < d.card[i]);
         h += (int64_t)digit * d.hstride[i];
-        used += nb;
+        back += (int64_t)digit * d.dstride[i];
     }
-    if (used < 32 && (x >> used) != 0) valid = false;
+    if (back != (int64_t)x) valid = false;              // index bits no variable owns must be clear
     hidx = h;
     return valid;
 }
 
 // MODE 0: arena[x] = stage[host index] (pack);  MODE 1: synthetic fill
+// MODE 2: 1 where the index names an entry, else 0 (tables of virtual cliques)
 template <typename T, typename S, int MODE>
 __global__ __launch_bounds__(256) void jt_pack(JtPackDesc d, const S *__restrict__ stage, T *__restrict__ arena,
                                                uint64_t key, double scale) {
-    const int64_t n = (int64_t)1 << d.nbits;
+    const int64_t n = d.phys_elems;
     for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
         int64_t h;
         const bool valid = jt_dev_to_host(d, (uint32_t)x, h);
         double v = 0.0;
         if (valid) {
             if constexpr (MODE == 0) v = (double)stage[h];
+            else if constexpr (MODE == 2) v = 1.0;
             else {
                 const uint64_t bits = jt_splitmix64(key + (uint64_t)h);
                 v = (0.5 + (double)(bits >> 11) * (1.0 / 9007199254740992.0)) * scale;
@@ -1412,15 +1446,6 @@ __global__ __launch_bounds__(256) void jt_pack(JtPackDesc d, const S *__restrict
         }
         arena[d.dev_off + x] = (T)v;
     }
-}
-
-// potential of a virtual (all-ones) clique: 1 on its real index range, 0 on the padding
-template <typename T>
-__global__ __launch_bounds__(256) void jt_fill_ones(T *__restrict__ arena, int64_t off, int nbits, int real_bits) {
-    const int64_t n = (int64_t)1 << nbits;
-    const int64_t lim = (int64_t)1 << real_bits;
-    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x)
-        arena[off + x] = (T)(x < lim ? 1.0 : 0.0);
 }
 
 // JTP_FAKE_COMM: stand-in for a received message
@@ -1431,26 +1456,23 @@ __global__ __launch_bounds__(256) void jt_fill_value(double *__restrict__ dst, i
 // clique potential = product of factor tables, written in the clique's device layout
 // (CliqueGraph.evaluate for one clique, junctiontree/junctiontree.py:203-226)
 template <typename T>
-__global__ __launch_bounds__(256) void jt_eval_product(JtEvalDesc d, const char *__restrict__ stage, T *__restrict__ arena) {
+__global__ __launch_bounds__(256) void jt_eval_product(const JtEvalDesc *__restrict__ dp, const char *__restrict__ stage, T *__restrict__ arena) {
+    // (the record is read from memory, not passed as a kernel argument: hipcc (ROCm 7.2) mis-read the 32-bit arrays of a
+    //  kernel-argument struct when indexed with a run-time index - dstride[cvar] came back as dstride[0])
+    const JtEvalDesc &d = *dp;
     const JtPackDesc &c = d.clique;
-    const int64_t n = (int64_t)1 << c.nbits;
+    const int64_t n = c.phys_elems;
     for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
-        bool valid = true;
-        int used = 0;
-        for (int i = 0; i < c.nvars; ++i) {
-            const int digit = (int)(((uint32_t)x >> c.pos[i]) & ((1u << c.nb[i]) - 1u));
-            valid = valid && (digit < c.card[i]);
-            used += c.nb[i];
-        }
-        if (used < 32 && ((uint32_t)x >> used) != 0) valid = false;
+        int64_t unused;
+        const bool valid = jt_dev_to_host(c, (uint32_t)x, unused);
         double v = d.accumulate ? (double)arena[c.dev_off + x] : 1.0;
         if (valid) {
             for (int f = 0; f < d.nf; ++f) {
                 const JtEvalFactor &ff = d.f[f];
                 int64_t idx = 0;
                 for (int j = 0; j < ff.nv; ++j) {
-                    const int cv = ff.cvar[j];
-                    const int digit = (int)(((uint32_t)x >> c.pos[cv]) & ((1u << c.nb[cv]) - 1u));
+                    const uint32_t ds = ff.vds[j];
+                    const int digit = ds > 0 ? (int)(((uint32_t)x / ds) % (uint32_t)ff.vmod[j]) : 0;
                     idx += (int64_t)digit * ff.stride[j];
                 }
                 v *= ff.is_f64 ? reinterpret_cast<const double *>(stage)[ff.off + idx]
@@ -1470,7 +1492,7 @@ __device__ __forceinline__ uint32_t jt_host_to_dev(const JtPackDesc &d, int64_t 
         const int c = d.card[i];
         const int digit = (int)(h % c);
         h /= c;
-        x |= (uint32_t)digit << d.pos[i];
+        x += (uint32_t)digit * d.dstride[i];
     }
     return x;
 }

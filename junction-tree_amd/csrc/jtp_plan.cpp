@@ -66,10 +66,28 @@ MsgView make_view(const PNode &p, const PSep &s, int psep, bool up) {
 }
 
 // Choose the F / A / R split of the high bits and fill every index table of the task.
-int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int nbits, int real_bits,
+// Does the high part (bits >= TB) of logical index `x`, restricted to the bits in `within`, name rows that exist?
+// A compact variable whose bits all lie in `within` must have a digit below its cardinality; a padding bit in
+// `within` must be clear.  (Variables only partly in `within` cannot occur: their bits stay together.)
+bool high_digits_exist(const PNode &p, uint32_t x, uint32_t within) {
+    if (x & within & p.pad_mask) return false;
+    for (size_t g = 0; g < p.group_mask.size(); ++g) {
+        if ((p.group_mask[g] & within) != p.group_mask[g]) continue;
+        if ((int)((x & p.group_mask[g]) >> p.group_pos[g]) >= p.group_card[g]) return false;
+    }
+    return true;
+}
+
+int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32_t> &itab, int nbits, int real_bits,
                const std::vector<MsgView> &ins, const std::vector<MsgView> &outs, int block_log2, std::string &err,
                int strict_budget = 0) {
     const int TB = hp.TB;
+    // the bits of a compact variable (stored at its true cardinality) go to the chunk bits or stay loop bits TOGETHER
+    auto unit = [&](int b) {
+        for (uint32_t g : p.group_mask)
+            if (g >> b & 1) return g;
+        return 1u << b;
+    };
     // strict_budget (multi-set plans): the sub-boxes of ONE evidence set must fit in that many bytes, whatever
     // it costs in loop iterations (down to 4) - the kernel reserves exactly that much LDS per set
     const int budget = strict_budget > 0 ? strict_budget : (hp.lds_budget > 0 ? hp.lds_budget : 32 * 1024);
@@ -108,11 +126,12 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
         int best = -1;
         long best_lds = 0;
         int best_part = 0;
-        for (int b = TB; b < nbits && nbits - popc(F) > TB + (strict_budget > 0 ? 2 : 3); ++b) {      // (fitting LDS never goes below 8 iterations:
-                                                                              //  staging a big sub-box for 4 would cost more than it saves)
+        for (int b = TB; b < nbits; ++b) {      // (fitting LDS never goes below 8 iterations: staging a big
+                                                //  sub-box for 4 would cost more than it saves; multi-set plans: 4)
             if (F >> b & 1) continue;
-            long l = lds_of(F | 1u << b);
-            int pl = part_log2(F | 1u << b);
+            if (nbits - popc(F | unit(b)) < TB + (strict_budget > 0 ? 2 : 3)) continue;
+            long l = lds_of(F | unit(b));
+            int pl = part_log2(F | unit(b));
             if (best < 0 || l < best_lds || (l == best_lds && pl < best_part)) {
                 best = b, best_lds = l, best_part = pl;
             }
@@ -122,7 +141,7 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
             if (lds_of(F) <= 150 * 1024 && max_free(F) <= JT_MAX_FREE) break;   // cannot shrink further
             FAIL(JTP_EUNSUPPORTED, "message sub-boxes do not fit in LDS (%ld bytes)", lds_of(F));
         }
-        F |= 1u << best;
+        F |= unit(best);
     }
     // 2. Parallelism: split until a workgroup handles at most 2^block_log2 elements, preferring
     //    bits that every outgoing message contains (no partial copies), highest bit first.
@@ -130,8 +149,9 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     block_log2 = std::min(block_log2, TB + JT_MAX_ITER_LOG2);   // and at most 2^JT_MAX_ITER_LOG2
     while (nbits - popc(F) > block_log2) {
         int best = -1;
+        auto fits = [&](int b) { return nbits - popc(F | unit(b)) >= TB + JT_MIN_ITER_LOG2; };      // >= 4 iterations stay
         for (int b = nbits - 1; b >= TB; --b)
-            if (!(F >> b & 1) && (everyout >> b & 1)) {
+            if (!(F >> b & 1) && (everyout & unit(b)) == unit(b) && fits(b)) {
                 best = b;
                 break;
             }
@@ -142,8 +162,8 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
             // messages contain (smaller staged sub-boxes), then the highest
             int best_pl = 1 << 30, best_in = -1, best_cls = 9;
             for (int b = nbits - 1; b >= TB; --b) {
-                if (F >> b & 1) continue;
-                int pl = part_log2(F | 1u << b);
+                if ((F >> b & 1) || !fits(b)) continue;
+                int pl = part_log2(F | unit(b));
                 int cls = (allout >> b & 1) ? 0 : 1;
                 int nin = 0;
                 for (auto &m : ins) nin += (m.mask >> b) & 1;
@@ -153,9 +173,12 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
             if (best < 0) break;
             if (best_pl > PMAX_LOG2 && nbits - popc(F) <= TB + JT_MAX_ITER_LOG2) break;
         }
-        F |= 1u << best;
+        F |= unit(best);
     }
     if (popc(F) > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "too many chunk bits (%d)", popc(F));
+    if (nbits - popc(F) > TB + JT_MAX_ITER_LOG2)
+        FAIL(JTP_EUNSUPPORTED, "cannot split a table of %d index bits into workgroups of at most 64 rows without splitting a "
+                               "variable stored at its true cardinality", nbits);
 
     std::vector<int> Fb, Ab, Rb;
     for (int b = TB; b < nbits; ++b) {
@@ -172,7 +195,15 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     tk.n_in = (int)ins.size();
     tk.n_out = (int)outs.size();
     if (tk.nA > JT_MAX_HI || tk.nR > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "too many loop bits");
-    for (int j = 0; j < tk.nF; ++j) tk.f_x[j] = 1u << Fb[j];
+    for (int j = 0; j < tk.nF; ++j) {
+        tk.f_x[j] = (uint32_t)p.bitw[Fb[j]];
+        tk.f_lx[j] = 1u << Fb[j];
+    }
+    for (int t = 0; t < tk.nR; ++t) tk.loop_pos[t] = (uint8_t)Rb[t];
+    for (int t = 0; t < tk.nA; ++t) tk.loop_pos[tk.nR + t] = (uint8_t)Ab[t];
+    uint32_t loopmask = 0;
+    for (int b : Rb) loopmask |= 1u << b;
+    for (int b : Ab) loopmask |= 1u << b;
 
     int lds = JT_RING_BYTES;                    // the element ring sits at LDS offset 0
     // per-message tables
@@ -225,16 +256,20 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
     for (int i = 0; i < tk.total; ++i) {
         const int r = i & ((1 << tk.nR) - 1), a = i >> tk.nR;
         int64_t row[JT_NCOL] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t lx = 0;                                    // logical index of the row's loop bits
         for (int t = 0; t < tk.nR; ++t)
             if (r >> t & 1) {
-                row[0] += (int64_t)1 << Rb[t];
+                row[0] += p.bitw[Rb[t]];
+                lx |= 1u << Rb[t];
                 for (int c = 1; c < JT_NCOL; ++c) row[c] += slotw[c - 1][Rb[t]];
             }
         for (int t = 0; t < tk.nA; ++t)
             if (a >> t & 1) {
-                row[0] += (int64_t)1 << Ab[t];
+                row[0] += p.bitw[Ab[t]];
+                lx |= 1u << Ab[t];
                 for (int c = 1; c < JT_NCOL; ++c) row[c] += slotw[c - 1][Ab[t]];
             }
+        if (!high_digits_exist(p, lx, loopmask)) row[0] = (int64_t)JT_NO_ROW;      // read the zero row instead
         for (int c = 0; c < JT_NCOL; ++c) itab[(size_t)i * JT_NCOL + c] = (int32_t)(uint32_t)row[c];
         if (i < 8) tk.first_x[i] = (uint32_t)row[0];
     }
@@ -258,18 +293,29 @@ int plan_loops(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, int n
 
 // ------------------------------------------------------------------------------------------
 
-JtBlock jtp_make_block(const JtTask &tk, uint32_t task_index, uint32_t chunk) {
+JtBlock jtp_make_block(const HostPlan &hp, const JtTask &tk, uint32_t task_index, uint32_t chunk) {
     JtBlock b;
     memset(&b, 0, sizeof b);
     b.task = task_index;
+    uint32_t fmask = 0;
     for (int j = 0; j < tk.nF; ++j) {
+        fmask |= tk.f_lx[j];
         if (!((chunk >> j) & 1u)) continue;
         b.xF += tk.f_x[j];
+        b.lxF += tk.f_lx[j];
         for (int k = 0; k < JT_MAX_MSG; ++k) b.gbase[k] += tk.msg[k].f_w[j];
         for (int k = 0; k < JT_MAX_OUT; ++k) b.pnum[k] += tk.msg[JT_MAX_IN + k].f_p[j];
     }
     b.psi_x0 = tk.psi_off + (int64_t)b.xF;
     for (int i = 0; i < 8; ++i) b.first_x[i] = tk.first_x[i];
+    // a chunk whose own digits do not exist (a compact variable's digit beyond its cardinality, a padding bit set)
+    // has no rows: the workgroup runs on the zero row and writes its all-zero partial copy (jtp_internal.h)
+    if (tk.kind == 0 && !high_digits_exist(hp.pn[tk.pnode], b.lxF, fmask)) {
+        b.flags |= JT_BLOCK_INVALID;
+        b.xF = 0;
+        b.psi_x0 = 0;
+        for (int i = 0; i < 8; ++i) b.first_x[i] = JT_NO_ROW;
+    }
     return b;
 }
 
@@ -290,6 +336,7 @@ PlanKnobs jtp_read_knobs() {
     k.fake_comm = geti("JTP_FAKE_COMM", 0);
     k.flow_debug = (unsigned)geti("JTP_FLOW_DEBUG", 0);
     k.flow_tickets = geti("JTP_FLOW_TICKETS", 0);
+    k.no_compact = geti("JTP_NO_COMPACT", 0);
     return k;
 }
 
@@ -377,6 +424,7 @@ int PlanBuilder::read_description() {
     hp.block_log2 = d->block_log2;
     hp.layout_policy = d->layout_policy;
     if (hp.knobs.layout_policy >= 0) hp.layout_policy = hp.knobs.layout_policy;               // experiments
+    hp.compact = !hp.knobs.no_compact && !(d->flags & JTP_NO_COMPACT);
     hp.multiset = (d->flags & JTP_MULTISET) != 0;
     if (hp.multiset) {
         if (d->n_ranks != 1) FAIL(JTP_EUNSUPPORTED, "multi-set plans run on one rank (evidence sets are independent: give every rank its own sets)");
@@ -639,7 +687,12 @@ int PlanBuilder::layouts() {
                 for (int sp : seps) cnt += find_var(hp.ps[sp].vars, host[i]) >= 0;
                 keyed.push_back({cnt, (int)i});
             }
-            std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+            // (among variables of equally many messages, powers of two lowest: the thread part is the one place
+            //  where a cardinality is still padded to a power of two)
+            auto waste = [&](int i) { return (double)(1 << hp.vbits[host[i]]) / hp.card[host[i]]; };
+            std::stable_sort(keyed.begin(), keyed.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+                return a.first != b.first ? a.first < b.first : waste(a.second) < waste(b.second);
+            });
             // (moving variables of every message onto the wave bits, to spare the epilogues their barriers,
             //  was tried: the larger sub-boxes cost more than the barriers - config 3 27 -> 37 ms)
             for (auto &kv : keyed) order.push_back(host[kv.second]);
@@ -668,6 +721,12 @@ int PlanBuilder::layouts() {
                 } else if (in_child == 0) ponly.push_back(v);
                 else part.push_back(v);
             }
+            // (inside every class, powers of two first: they are the ones taken into the thread part, the one place
+            //  where a cardinality is still padded to a power of two)
+            for (std::vector<int> *cls : {&priv, &ponly, &part})
+                std::stable_sort(cls->begin(), cls->end(), [&](int a, int b) {
+                    return (double)(1 << hp.vbits[a]) / hp.card[a] < (double)(1 << hp.vbits[b]) / hp.card[b];
+                });
             auto take = [&](std::vector<int> &from, int want_bits) {
                 int got = 0;
                 while (!from.empty() && got < want_bits) {
@@ -722,6 +781,38 @@ int PlanBuilder::layouts() {
         if (bit > JT_MAX_BITS) FAIL(JTP_EUNSUPPORTED, "clique %d needs %d index bits (max %d)", p.real, bit, JT_MAX_BITS);
         p.nbits = std::max(bit, hp.TB + JT_MIN_ITER_LOG2);   // >= 4 loop iterations per workgroup
         if (p.nbits - hp.TB > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
+        // Physical layout (jtp_internal.h, JT_NO_ROW): rows above the thread part.  A variable that starts inside
+        // the thread part keeps its bit field (its upper bits double the row stride); a variable wholly above it
+        // whose cardinality is not a power of two is stored at its true cardinality - its bits form a group that
+        // every task keeps together; index bits above the last variable are padding and store nothing.
+        p.bitw.assign(p.nbits, 0);
+        p.group_mask.clear();
+        p.group_pos.clear();
+        p.group_card.clear();
+        p.pad_mask = 0;
+        for (int b = 0; b < hp.TB && b < p.nbits; ++b) p.bitw[b] = (int64_t)1 << b;
+        int64_t mult = (int64_t)1 << hp.TB;
+        for (size_t i = 0; i < p.vars.size(); ++i) {
+            const int pos = p.pos[i], nb = p.nb[i], card = hp.card[p.vars[i]];
+            if (pos + nb <= hp.TB) continue;
+            const bool whole = pos >= hp.TB && hp.compact && (card & (card - 1)) != 0;
+            for (int k = std::max(0, hp.TB - pos); k < nb; ++k) {
+                p.bitw[pos + k] = whole ? mult << k : mult;
+                if (!whole) mult <<= 1;
+            }
+            if (whole) {
+                p.group_mask.push_back(((1u << nb) - 1u) << pos);
+                p.group_pos.push_back(pos);
+                p.group_card.push_back(card);
+                mult *= card;
+            }
+        }
+        for (int b = std::max(bit, hp.TB); b < p.nbits; ++b) {
+            if (hp.compact) p.pad_mask |= 1u << b;           // weight 0, exists only when clear
+            else p.bitw[b] = mult, mult <<= 1;
+        }
+        p.phys_elems = mult;
+        if (mult > ((int64_t)1 << 31)) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
     }
     for (size_t s = 0; s < hp.ps.size(); ++s) {
         PSep &sp = hp.ps[s];
@@ -747,40 +838,48 @@ int PlanBuilder::layouts() {
 
 int PlanBuilder::arenas() {
     // ---- arena offsets (this rank's real cliques) --------------------------------------------
-    hp.arena_elems = 0;
-    for (int c = 0; c < NP; ++c) {
-        PNode &p = hp.pn[c];
-        if (!mine(c)) continue;
-        p.arena_off = hp.arena_elems;
-        hp.arena_elems += (int64_t)1 << p.nbits;
-        hp.arena_elems = (hp.arena_elems + 255) & ~(int64_t)255;
-        if (p.real < 0) {                               // virtual clique: a resident 0/1 table
-            int rb = 0;
-            for (int nb : p.nb) rb += nb;
-            hp.virtual_fills.push_back({p.arena_off, p.nbits, rb});
-        }
-    }
-    hp.pack.assign(N, JtPackDesc());
-    for (int c = 0; c < N; ++c) {
-        const PNode &p = hp.pn[c];
-        JtPackDesc &pd = hp.pack[c];
+    // rows 0 and 1 of the arenas are shared: row 0 stays all zero (what rows that do not exist read), row 1 takes
+    // the belief stores of such rows (a belief arena is read again by the marginal tasks: its row 0 must stay zero)
+    hp.arena_elems = (int64_t)2 << hp.TB;
+    hp.host_table_elems = 0;
+    auto pack_of = [&](const PNode &p, const std::vector<int> &host_vars) {
+        JtPackDesc pd;
         memset(&pd, 0, sizeof pd);
         pd.dev_off = p.arena_off;
         pd.nbits = p.nbits;
-        pd.nvars = (int)hp.node_vars[c].size();
+        pd.nvars = (int)host_vars.size();
+        pd.phys_elems = p.phys_elems;
+        pd.low_bits = hp.TB;
         int64_t stride = 1;
         for (int i = pd.nvars - 1; i >= 0; --i) {
-            int v = hp.node_vars[c][i];
-            int j = find_var(p.vars, v);
+            const int v = host_vars[i];
+            const int j = find_var(p.vars, v);
+            bool whole = false;
+            for (size_t g = 0; g < p.group_pos.size(); ++g) whole = whole || p.group_pos[g] == p.pos[j];
             pd.pos[i] = (uint8_t)p.pos[j];
             pd.nb[i] = (uint8_t)p.nb[j];
             pd.card[i] = hp.card[v];
             pd.hstride[i] = stride;
+            pd.dstride[i] = p.nb[j] > 0 ? (uint32_t)p.bitw[p.pos[j]] : 0u;
+            pd.dmod[i] = whole ? hp.card[v] : 1 << p.nb[j];
             stride *= hp.card[v];
         }
         pd.host_elems = stride;
+        return pd;
+    };
+    for (int c = 0; c < NP; ++c) {
+        PNode &p = hp.pn[c];
+        if (!mine(c)) continue;
+        p.arena_off = hp.arena_elems;
+        hp.arena_elems += p.phys_elems;
+        hp.arena_elems = (hp.arena_elems + 255) & ~(int64_t)255;
+        double he = 1;
+        for (int v : p.vars) he *= hp.card[v];
+        hp.host_table_elems += he;
+        if (p.real < 0) hp.virtual_fills.push_back({pack_of(p, p.vars)});     // virtual clique: a resident 0/1 table
     }
-
+    hp.pack.assign(N, JtPackDesc());
+    for (int c = 0; c < N; ++c) hp.pack[c] = pack_of(hp.pn[c], hp.node_vars[c]);
     return JTP_OK;
 }
 
@@ -790,7 +889,7 @@ int PlanBuilder::level_work() {
     // task the same way because the partial-copy counts of the cut messages follow from it)
     for (int ph = 0; ph < 2; ++ph) lvl_elems[ph].assign(hp.n_ranks + 1, std::vector<double>(maxdepth + 1, 0.0));
     for (int c = 0; c < NP; ++c) {
-        double e = (double)((int64_t)1 << hp.pn[c].nbits);
+        double e = (double)hp.pn[c].phys_elems;
         if (c != hp.root) lvl_elems[0][hp.pn[c].owner][hp.pn[c].depth] += e;
         lvl_elems[1][hp.pn[c].owner][hp.pn[c].depth] += e;
     }
@@ -825,8 +924,8 @@ int PlanBuilder::make_tasks() {
                     int real_bits = 0;
                     for (int nb : p.nb) real_bits += nb;
                     std::vector<int32_t> itab;
-                    int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_SMALL);
-                    if (rc != JTP_OK) rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
+                    int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_SMALL);
+                    if (rc != JTP_OK) rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
                     if (rc != JTP_OK) return rc;
                     tk.itab_off = (int64_t)hp.itab.size();
                     hp.itab.insert(hp.itab.end(), itab.begin(), itab.end());
@@ -860,10 +959,10 @@ int PlanBuilder::make_tasks() {
             int real_bits = 0;
             for (int nb : p.nb) real_bits += nb;
             std::vector<int32_t> itab;
-            int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err,
+            int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err,
                                 hp.multiset ? JT_SETB_SMALL : 0);
             if (rc != JTP_OK && hp.multiset)
-                rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
+                rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
             if (rc != JTP_OK) return rc;
             tk.itab_off = (int64_t)hp.itab.size();
             hp.itab.insert(hp.itab.end(), itab.begin(), itab.end());
@@ -1059,13 +1158,13 @@ int PlanBuilder::schedule() {
             for (int t : L.tasks) {
                 const JtTask &tk = hp.tasks[t];
                 for (uint32_t f = 0; f < (1u << tk.nF); ++f) {
-                    hp.blocks.push_back(jtp_make_block(tk, (uint32_t)t, f));
+                    hp.blocks.push_back(jtp_make_block(hp, tk, (uint32_t)t, f));
                     hp.block_chunk.push_back(f);
                 }
                 L.lds_bytes = std::max(L.lds_bytes, tk.lds_bytes);
                 L.alg_bytes += task_bytes[t];
                 for (int k = 0; k < tk.n_in; ++k) hp.staging_bytes += (double)(1u << tk.nF) * (8.0 * (1 << tk.msg[k].nfree)) * tk.msg[k].npart;
-                hp.table_bytes += (double)((int64_t)1 << tk.nbits) * esize * (phase == 1 && !hp.multiset ? 2 : 1);
+                hp.table_bytes += (double)hp.pn[tk.pnode].phys_elems * esize * (phase == 1 && !hp.multiset ? 2 : 1);
             }
             L.nblocks = (int)(hp.blocks.size() - L.blk_off);
             hp.max_lds = std::max(hp.max_lds, L.lds_bytes);
@@ -1100,7 +1199,7 @@ int PlanBuilder::schedule() {
         L.blk_off = (int64_t)hp.blocks.size();
         for (int t : tasks)
             for (uint32_t f = 0; f < (1u << hp.tasks[t].nF); ++f) {
-                hp.blocks.push_back(jtp_make_block(hp.tasks[t], (uint32_t)t, f));
+                hp.blocks.push_back(jtp_make_block(hp, hp.tasks[t], (uint32_t)t, f));
                 hp.block_chunk.push_back(f);
             }
         L.nblocks = (int)(hp.blocks.size() - L.blk_off);
@@ -1247,7 +1346,7 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int>
     outs.push_back(make_view(p, s, -1, true));
     int real_bits = 0;
     for (int nb : p.nb) real_bits += nb;
-    int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
+    int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
     tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
     for (size_t k = 0; k < src.size(); ++k) {
@@ -1258,7 +1357,7 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int>
     out_bits = bit;
     npart = tk.msg[JT_MAX_IN].npart;
     blocks.clear();
-    for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(tk, 0u, f));
+    for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(hp, tk, 0u, f));
     return JTP_OK;
 }
 
@@ -1276,7 +1375,7 @@ int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<
     if ((int)ins.size() > JT_MAX_IN) FAIL(JTP_EUNSUPPORTED, "clique with %zu neighbours", ins.size());
     int real_bits = 0;
     for (int nb : p.nb) real_bits += nb;
-    int rc = plan_loops(hp, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
+    int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
     tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
     for (size_t k = 0; k < src.size(); ++k) {
@@ -1285,7 +1384,7 @@ int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<
         tk.msg[k].same_launch = 0;
     }
     blocks.clear();
-    for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(tk, 0u, f));
+    for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(hp, tk, 0u, f));
     return JTP_OK;
 }
 
@@ -1328,6 +1427,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
       << ",\"root\":" << hp.root << ",\"arena_elems\":" << hp.arena_elems << ",\"msg_doubles\":" << hp.msg_doubles
       << ",\"dbg_base\":" << hp.dbg_base << ",\"max_lds\":" << hp.max_lds << ",\"alg_bytes\":" << (long long)hp.alg_bytes
       << ",\"staging_bytes\":" << (long long)hp.staging_bytes << ",\"table_bytes\":" << (long long)hp.table_bytes
+      << ",\"compact\":" << (hp.compact ? 1 : 0) << ",\"host_table_elems\":" << (long long)hp.host_table_elems
       << ",\"multiset\":" << (hp.multiset ? 1 : 0) << ",\"alg_table_bytes\":" << (long long)hp.alg_table_bytes
       << ",\"alg_msg_bytes\":" << (long long)hp.alg_msg_bytes
       << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
@@ -1338,8 +1438,22 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         if (i) o << ",";
         o << "{\"real\":" << p.real << ",\"parent\":" << p.parent << ",\"psep\":" << p.psep << ",\"depth\":" << p.depth
           << ",\"owner\":" << p.owner << ",\"nbits\":" << p.nbits << ",\"arena_off\":" << p.arena_off
-          << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"down_tasks\":";
+          << ",\"phys_elems\":" << p.phys_elems << ",\"pad_mask\":" << p.pad_mask << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"down_tasks\":";
         json_vec(o, p.down_tasks);
+        o << ",\"bitw\":";
+        json_vec(o, p.bitw);
+        o << ",\"group_mask\":";
+        json_vec(o, p.group_mask);
+        o << ",\"group_pos\":";
+        json_vec(o, p.group_pos);
+        o << ",\"group_card\":";
+        json_vec(o, p.group_card);
+        {
+            std::vector<int> cards;
+            for (int v : p.vars) cards.push_back(hp.card[v]);
+            o << ",\"card\":";
+            json_vec(o, cards);
+        }
         o << ",\"vars\":";
         json_vec(o, p.vars);
         o << ",\"pos\":";
@@ -1349,6 +1463,22 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         o << ",\"children\":";
         json_vec(o, p.children);
         o << "}";
+    }
+    o << "],\"pack\":[";                      // host <-> device conversion records of the real cliques (host variable order)
+    for (size_t i = 0; i < hp.pack.size(); ++i) {
+        const JtPackDesc &pd = hp.pack[i];
+        if (i) o << ",";
+        o << "{\"pos\":";
+        json_list(o, pd.pos, pd.pos + pd.nvars);
+        o << ",\"nb\":";
+        json_list(o, pd.nb, pd.nb + pd.nvars);
+        o << ",\"card\":";
+        json_list(o, pd.card, pd.card + pd.nvars);
+        o << ",\"dstride\":";
+        json_list(o, pd.dstride, pd.dstride + pd.nvars);
+        o << ",\"dmod\":";
+        json_list(o, pd.dmod, pd.dmod + pd.nvars);
+        o << ",\"phys_elems\":" << pd.phys_elems << "}";
     }
     o << "],\"pseps\":[";
     for (size_t i = 0; i < hp.ps.size(); ++i) {
@@ -1414,6 +1544,10 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";
             json_list(o, tk.f_x, tk.f_x + tk.nF);
+            o << ",\"f_lx\":";
+            json_list(o, tk.f_lx, tk.f_lx + tk.nF);
+            o << ",\"loop_pos\":";
+            json_list(o, tk.loop_pos, tk.loop_pos + tk.nA + tk.nR);
             o << ",\"total\":" << tk.total << ",\"itab_lds\":" << tk.itab_lds << ",\"itab\":[";
             for (int i = 0; i < tk.total; ++i) {
                 if (i) o << ",";
@@ -1440,6 +1574,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             for (int i = 0; i < JT_MAX_OUT; ++i) o << "," << k.pnum[i];
             o << "," << k.psi_x0;
             for (int i = 0; i < 8; ++i) o << "," << k.first_x[i];
+            o << "," << k.lxF << "," << k.flags;
             o << "]";
         }
         o << "]";

@@ -19,6 +19,14 @@ struct PNode {                       // a clique of the (binarised) tree
     int layout = 0;                  // bit-order heuristic used for this clique (jtp_tree_desc.layout_policy)
     int owner = 0;                   // owning rank
     int64_t arena_off = -1;          // element offset in the potential/belief arenas (real, owned)
+    // physical layout (jtp_internal.h, JT_NO_ROW): element weight of every logical index bit (0: padding bit), the
+    // variables stored at their true cardinality (their bits must stay in ONE of chunk / loop bits in every task),
+    // the padding bits above the variables, and the number of elements actually stored
+    std::vector<int64_t> bitw;
+    std::vector<uint32_t> group_mask;
+    std::vector<int> group_pos, group_card;
+    uint32_t pad_mask = 0;
+    int64_t phys_elems = 0;
     int collect_task = -1, distribute_task = -1;
     std::vector<int> down_tasks;     // multi-set plans: one task per child (its downward message), child order
 };
@@ -74,10 +82,11 @@ struct Segment {
     int ticket_idx = 0;              // word of the sync buffer
 };
 
-struct VirtualFill { int64_t off; int nbits, real_bits; };   // all-ones table of a virtual clique
+struct VirtualFill { JtPackDesc d; };   // all-ones table of a virtual clique (1 where the index names an entry, else 0)
 
+struct HostPlan;
 // decode chunk number -> workgroup record (element base, message bases, partial numbers)
-JtBlock jtp_make_block(const JtTask &tk, uint32_t task_index, uint32_t chunk);
+JtBlock jtp_make_block(const HostPlan &hp, const JtTask &tk, uint32_t task_index, uint32_t chunk);
 
 // Development knobs, read from the environment ONCE per plan (jtp_read_knobs, at the top of jtp_build_plan):
 // nothing else in the product path calls getenv while planning or propagating.
@@ -91,6 +100,7 @@ struct PlanKnobs {
     int force_level_launches = 0, force_flow = 0, fake_comm = 0;   // JTP_FORCE_LEVEL_LAUNCHES / JTP_FORCE_FLOW / JTP_FAKE_COMM
     unsigned flow_debug = 0;                                        // JTP_FLOW_DEBUG
     int flow_tickets = 0;                                           // JTP_FLOW_TICKETS
+    int no_compact = 0;                                             // JTP_NO_COMPACT: every table padded to powers of two
 };
 PlanKnobs jtp_read_knobs();
 
@@ -123,7 +133,9 @@ struct HostPlan {
     std::vector<Step> flow_steps;        // as `steps`, launches replaced by segments (kind 0: first = segment)
     int sync_words = 0;                  // uint32 words of the per-evidence-set sync buffer
     std::vector<JtPackDesc> pack;    // per real clique (host order)
-    int64_t arena_elems = 0;         // potential arena == belief arena size (elements)
+    int64_t arena_elems = 0;         // potential arena == belief arena size (elements), zero row included
+    double host_table_elems = 0;     // sum of the true sizes of this rank's clique tables (arena_elems / this = padding factor)
+    bool compact = true;             // rows above the thread part stored at true cardinalities (JTP_NO_COMPACT clears it)
     int64_t msg_doubles = 0;
     int64_t dbg_base = -1;           // JTP_DEBUG & 2: time-stamp region inside the message arena
     int max_lds = 0;

@@ -57,7 +57,7 @@ class Plan:
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
                  layout_policy=0, split_variants=False, keep_root=False, level_launches=False,
-                 flow_tickets=False, share_potentials=False, multiset=False):
+                 flow_tickets=False, share_potentials=False, multiset=False, no_compact=False):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
@@ -117,7 +117,8 @@ class Plan:
                    | (_capi.JTP_LEVEL_LAUNCHES if level_launches else 0)
                    | (_capi.JTP_FLOW_TICKETS if flow_tickets else 0)
                    | (_capi.JTP_SHARE_POTENTIALS if share_potentials or multiset else 0)
-                   | (_capi.JTP_MULTISET if multiset else 0))
+                   | (_capi.JTP_MULTISET if multiset else 0)
+                   | (_capi.JTP_NO_COMPACT if no_compact else 0))
         self.multiset = bool(multiset)
         d.lds_budget = lds_budget
         d.block_log2 = block_log2

@@ -33,10 +33,25 @@ class Emulator:
         self.psi = np.zeros(max(desc["arena_elems"], 1), dtype=np.float64)
         self.bel = np.zeros_like(self.psi)
         self.msg = np.full(max(desc["msg_doubles"], 1), np.nan)     # NaN = never written
+        self.row = 1 << self.TB                                     # elements of one row; rows 0 / 1 of the arenas are shared:
+        assert desc["arena_elems"] >= 2 * self.row                  # row 0 all zero (rows that do not exist), row 1 scratch
         for p in desc["pnodes"]:                                    # virtual cliques: resident 0/1 tables
             if p["real"] < 0 and p["arena_off"] >= 0:
-                n = np.arange(1 << p["nbits"])
-                self.psi[p["arena_off"] + n] = (n < (1 << sum(p["nb"]))).astype(np.float64)
+                cards = p["card"]
+                n = int(np.prod(cards)) if cards else 1
+                digits = np.unravel_index(np.arange(n), cards) if cards else ()
+                x = np.zeros(n, dtype=np.int64)
+                for pos, dig in zip(p["pos"], digits):
+                    x += dig.astype(np.int64) << pos
+                self.psi[p["arena_off"] + self._phys(p, x)] = 1.0
+
+    @staticmethod
+    def _phys(p, x):
+        """physical element offset of logical index x (offsets are linear in the index bits, jtp_internal.h)"""
+        out = np.zeros_like(x)
+        for b, w in enumerate(p["bitw"]):
+            out += ((x >> b) & 1) * w
+        return out
 
     # ---------------------------------------------------------------- layout conversion
     def _dev_index(self, pnode, host_vars, cards):
@@ -48,13 +63,15 @@ class Emulator:
         x = np.zeros(n, dtype=np.int64)
         for v, dig in zip(host_vars, digits):
             x += dig.astype(np.int64) << pos[v][0]
-        return x
+        phys = self._phys(p, x)
+        assert len(np.unique(phys)) == len(phys) and phys.max(initial=0) < p["phys_elems"]     # a table entry, a place
+        return phys
 
     def set_potential(self, clique, host_vars, cards, array):
         p = self.d["pnodes"][clique]
         x = self._dev_index(clique, host_vars, cards)
         lo = p["arena_off"]
-        self.psi[lo:lo + (1 << p["nbits"])] = 0.0
+        self.psi[lo:lo + p["phys_elems"]] = 0.0
         self.psi[lo + x] = np.broadcast_to(np.asarray(array, dtype=np.float64), cards).ravel()
 
     def belief(self, clique, host_vars, cards):
@@ -110,9 +127,28 @@ class Emulator:
                 for k in range(n_out):
                     gb_out[k] += outs[k]["f_w"][j]
                     pnum[k] += outs[k]["f_p"][j]
+        NO_ROW = 0xFFFFFFFF
+        pn = self.d["pnodes"][tk["pnode"]]
+        lxF = sum(tk["f_lx"][j] for j in range(tk["nF"]) if (chunk >> j) & 1)
+        fmask = sum(tk["f_lx"])
+
+        def exists(x, within):      # the rows named by the high bits of x (restricted to `within`) exist
+            if x & within & pn["pad_mask"]:
+                return False
+            for g, pos, card in zip(pn["group_mask"], pn["group_pos"], pn["group_card"]):
+                assert (g & within) in (0, g), "a variable stored at its true cardinality is split between chunk and loop bits"
+                if (g & within) == g and ((x & g) >> pos) >= card:
+                    return False
+            return True
+
+        chunk_ok = exists(lxF, fmask)
         if record is not None:      # the host-decoded workgroup record must agree with the bit decode
-            assert record[0] == xF and record[11] == tk["psi_off"] + xF
-            assert list(record[12:20]) == list(tk["first_x"])
+            assert record[20] == lxF and record[21] == (0 if chunk_ok else 1)
+            if chunk_ok:
+                assert record[0] == xF and record[11] == tk["psi_off"] + xF
+                assert list(record[12:20]) == list(tk["first_x"])
+            else:
+                assert record[0] == 0 and record[11] == 0 and all(v == NO_ROW for v in record[12:20])
             assert list(record[1:1 + n_in]) == gb_in and list(record[5:5 + n_out]) == gb_out
             assert list(record[8:8 + n_out]) == pnum
         # staging
@@ -164,6 +200,17 @@ class Emulator:
         xoff = itab[:, :, 0] & 0xFFFFFFFF
         for i in range(8):
             assert tk["first_x"][i] == (xoff.ravel()[i] if i < tk["total"] else 0)
+        # rows that do not exist are marked; the marks must agree with the digits of the row's loop bits
+        loopmask = sum(1 << b for b in tk["loop_pos"])
+        row_ok = np.ones((nA, nR), dtype=bool)
+        for i in range(nA * nR):
+            lx = sum(((i >> t) & 1) << b for t, b in enumerate(tk["loop_pos"]))
+            ok = exists(lx, loopmask)
+            assert ok == (xoff.ravel()[i] != NO_ROW), "row %d: mark and digits disagree" % i
+            row_ok[i // nR, i % nR] = ok and chunk_ok
+            if ok:
+                assert xoff.ravel()[i] == self._phys(pn, np.array([lx], dtype=np.int64))[0]
+        xoff = np.where(xoff == NO_ROW, 0, xoff)
         in_off = [_signed(itab[:, :, 1 + k]) for k in range(n_in)]
         out_off = [_signed(itab[:, :, 1 + JT_MAX_IN + j]) for j in range(n_out)]
         for j in range(n_out):      # the kernel reads outgoing offsets once per A iteration
@@ -171,9 +218,10 @@ class Emulator:
         # element index of every (a, r, tid, e)
         x = (xF + xoff[:, :, None, None]
              + (tid * VEC)[None, None, :, None] + np.arange(VEC)[None, None, None, :]) & 0xFFFFFFFF
-        assert x.max() < (1 << tk["nbits"])
-        assert len(np.unique(x)) == x.size            # every element visited exactly once
-        p = self.psi[tk["psi_off"] + x]
+        live = np.broadcast_to(row_ok[:, :, None, None], x.shape)
+        assert x[live].max(initial=0) < pn["phys_elems"]
+        assert len(np.unique(x[live])) == x[live].size            # every stored element visited at most once
+        p = np.where(live, self.psi[tk["psi_off"] + np.where(live, x, 0)], 0.0)      # rows that do not exist read zeros
         vals = []
         for k, m in enumerate(ins):
             slot = (in_off[k][:, :, None, None]
@@ -201,7 +249,7 @@ class Emulator:
             for v in vals[npar:]:
                 b = b * v
             if tk["bel_off"] >= 0:
-                self.bel[tk["bel_off"] + x] = b
+                self.bel[tk["bel_off"] + x[live]] = b[live]
         for j, m in enumerate(outs):
             slot = (out_off[j][:, :, None, None]
                     + thread_off(m)[None, None, :, None] + e_off(m)[None, None, None, :])

@@ -115,7 +115,17 @@ static bool consistent(const HostPlan &hp, std::string &why) {
     for (size_t t = 0; t < hp.tasks.size(); ++t) {
         const JtTask &tk = hp.tasks[t];
         if (tk.kind != 0 || !runs[t]) continue;
-        if (tk.psi_off < 0 || tk.psi_off + ((int64_t)1 << tk.nbits) > std::max<int64_t>(hp.arena_elems, 1) + 256) return why = "psi_off outside the arena", false;
+        if (tk.psi_off < 0 || tk.psi_off + hp.pn[tk.pnode].phys_elems > std::max<int64_t>(hp.arena_elems, 1) + 256) return why = "psi_off outside the arena", false;
+        {   // every row a workgroup of the task touches lies inside the table (or is marked as not existing)
+            const int64_t phys = hp.pn[tk.pnode].phys_elems;
+            int64_t fmax = 0;
+            for (int j = 0; j < tk.nF; ++j) fmax += tk.f_x[j];
+            for (int i = 0; i < tk.total; ++i) {
+                const uint32_t off = (uint32_t)hp.itab[tk.itab_off + (int64_t)i * JT_NCOL];
+                if (off != JT_NO_ROW && (int64_t)off + ((int64_t)1 << hp.TB) > phys) return why = "row outside the table", false;
+            }
+            (void)fmax;
+        }
         if (tk.itab_off < 0 || tk.itab_off + (int64_t)tk.total * JT_NCOL > (int64_t)hp.itab.size()) return why = "iteration table outside the buffer", false;
         for (int k = 0; k < tk.n_in + tk.n_out; ++k) {
             const JtMsg &m = tk.msg[k < tk.n_in ? k : JT_MAX_IN + (k - tk.n_in)];

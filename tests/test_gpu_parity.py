@@ -751,6 +751,56 @@ def test_propagate_restages_only_cliques_whose_factors_changed(golden):
         close(o, w)
 
 
+@pytest.mark.parametrize("card,width,sep", [(3, 8, 4), (5, 6, 3), (6, 5, 2), (7, 5, 3), (3, 9, 5)])
+def test_wide_cliques_of_odd_cardinalities(card, width, sep):
+    """Tables whose variables above the thread part are stored at their true cardinality (mixed-radix rows, rows that
+    do not exist read the zero row): beliefs, Z and marginals vs the oracle in float64 and float32, dataflow and
+    per-level launches, the padded round-1 layout for comparison (bit-identical results are not expected: the
+    summation order differs), hard evidence (its masks are over the LOGICAL index) and multi-set plans."""
+    spec = synthetic.wide_binary_tree(n_cliques=7, width=width, sep=sep, card=card, seed=card)
+    pots = synthetic.potentials_for(spec, seed=11)
+    want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+    arenas = {}
+    for opts in ({}, {"level_launches": True}, {"no_compact": True}, {"block_log2": 10}):
+        for dtype in ("f64", "f32"):
+            cast = [p.astype(np.float32) for p in pots] if dtype == "f32" else pots
+            ref = oracle.beliefs_exact(spec["tree"], cast, spec["node_vars"]) if dtype == "f32" else want
+            plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, **opts)
+            d = plan.describe()
+            arenas[bool(opts.get("no_compact"))] = d["arena_elems"]
+            assert d["compact"] == (0 if opts.get("no_compact") else 1)
+            for c in range(spec["n_cliques"]):
+                plan.set_potential(c, cast[c])
+            plan.propagate()
+            for node in range(len(spec["node_vars"])):
+                close(plan.belief(node), ref[node], rtol=RTOL32 if dtype == "f32" else RTOL64, what="%r %s node %d" % (opts, dtype, node))
+            assert abs(plan.z() - z) <= (1e-6 if dtype == "f32" else 1e-11) * z
+            lab = list(spec["node_vars"][3])[1:3]
+            close(plan.marginal(3, lab), ref[3].sum(axis=tuple(i for i in range(width) if i not in (1, 2))), rtol=RTOL32 if dtype == "f32" else RTOL64)
+            plan.close()
+    assert arenas[False] < arenas[True]
+    # hard evidence on every position of a clique's variable list in turn (thread part, loop and chunk digits)
+    labels = sorted(spec["sizes"])
+    nb = 6
+    for multiset in (False, True):
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", n_batch=nb, share_potentials=True, multiset=multiset)
+        for c in range(spec["n_cliques"]):
+            plan.set_potential(c, pots[c])
+        observed = []
+        for b in range(nb):
+            rng = np.random.default_rng(900 + b)
+            obs = {labels[i]: int(rng.integers(0, card)) for i in rng.choice(len(labels), size=min(len(labels), 2 + b), replace=False)}
+            observed.append(obs)
+            plan.set_evidence(obs, batch=b)
+        plan.propagate(0, nb)
+        for b in range(nb):
+            w, zb = oracle.beliefs_exact(spec["tree"], _indicator_potentials(spec, pots, observed[b]), spec["node_vars"], return_z=True)
+            assert abs(plan.z(batch=b) - zb) <= 1e-11 * zb + 1e-300
+            for node in range(len(spec["node_vars"])):
+                close(plan.belief(node, batch=b), w[node], what="multiset %r set %d node %d" % (multiset, b, node))
+        plan.close()
+
+
 def test_grid_mrf_through_public_api_vs_bruteforce():
     """Loopy pairwise models (BASELINE config 3 family at brute-forceable size): 3x3, 4x4 and
     3x3x2 binary lattices through create_junction_tree / propagate (the reference is wrong or

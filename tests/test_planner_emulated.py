@@ -176,7 +176,7 @@ def test_full_scale_configs_plan():
     spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", plan_only=True)
     d = plan.describe()
-    assert d["n_messages"] == 510 and d["arena_elems"] == 256 << 20
+    assert d["n_messages"] == 510 and d["arena_elems"] == (256 << 20) + 2048      # + the two shared rows (zero row, scratch row)
     assert abs(d["alg_bytes"] / 1e9 - 3.22) < 0.03
     assert d["max_lds"] <= 64 * 1024
     assert max(max(s["up_npart"], s["dn_npart"]) for s in d["pseps"]) <= 64
@@ -318,3 +318,50 @@ def test_multiset_plans_on_the_emulator(opts):
                 got = emu.sep_belief(psep_of[plan.abi_of[sn]], ids, [spec["sizes"][lab] for lab in spec["node_vars"][sn]])
                 np.testing.assert_allclose(got, want[sn], rtol=1e-11, atol=1e-13, err_msg="separator %d" % sn)
             plan.close()
+
+
+@pytest.mark.parametrize("card,width,sep", [(3, 8, 4), (5, 6, 3), (6, 5, 2), (7, 5, 3), (3, 9, 5)])
+def test_rows_above_the_thread_part_are_stored_at_true_cardinalities(card, width, sep):
+    """Mixed-radix rows (round 2): a variable wholly above the thread part of a table counts its true cardinality,
+    padding index bits store nothing; rows that do not exist read the arena's zero row.  Checks results against
+    the oracle and the arena against the padded (round-1) layout."""
+    spec = synthetic.wide_binary_tree(n_cliques=7, width=width, sep=sep, card=card, seed=card)
+    pots = synthetic.potentials_for(spec, seed=11)
+    for opts in ({}, {"block_log2": 10}, {"multiset": True, "n_batch": 2}):
+        want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
+        sizes = {}
+        for compact in (True, False):
+            import os
+            os.environ["JTP_NO_COMPACT"] = "0" if compact else "1"
+            try:
+                plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", plan_only=True, **opts)
+            finally:
+                del os.environ["JTP_NO_COMPACT"]
+            desc = plan.describe()
+            assert desc["compact"] == (1 if compact else 0)
+            sizes[compact] = desc["arena_elems"]
+            emu = Emulator(desc)
+            for c in plan.cliques:
+                ids = [plan.var_id[lab] for lab in spec["node_vars"][c]]
+                emu.set_potential(plan.abi_of[c], ids, [spec["sizes"][lab] for lab in spec["node_vars"][c]], pots[c])
+            emu.propagate()
+            keep = emu.msg.copy()
+            emu.propagate_flow()
+            np.testing.assert_array_equal(emu.msg, keep)
+            psep_of = {s["node"]: i for i, s in enumerate(desc["pseps"]) if s["node"] >= 0}
+            for sn in plan.seps:
+                ids = [plan.var_id[lab] for lab in spec["node_vars"][sn]]
+                got = emu.sep_belief(psep_of[plan.abi_of[sn]], ids, [spec["sizes"][lab] for lab in spec["node_vars"][sn]])
+                np.testing.assert_allclose(got, want[sn], rtol=1e-11, atol=1e-13)
+            if not opts.get("multiset"):
+                for c in plan.cliques:
+                    ids = [plan.var_id[lab] for lab in spec["node_vars"][c]]
+                    got = emu.belief(plan.abi_of[c], ids, [spec["sizes"][lab] for lab in spec["node_vars"][c]])
+                    np.testing.assert_allclose(got, want[c], rtol=1e-11, atol=1e-13)
+            if compact:
+                assert any(p["group_mask"] for p in desc["pnodes"])           # some variable is stored at its true cardinality
+            plan.close()
+        host = 7 * card ** width
+        assert sizes[True] < sizes[False]
+        print("card %d width %d: host %d, compact arena %d (%.2fx), padded arena %d (%.2fx)" % (
+            card, width, host, sizes[True], sizes[True] / host, sizes[False], sizes[False] / host))
