@@ -87,6 +87,37 @@ static int load() {
 }
 }  // namespace rccl
 
+// ------------------------------------------------------------------------------------------ roctx ranges (lazy, optional)
+// phases show up as named ranges in rocprofv3 --marker-trace.  The library is looked up at the
+// first propagate of a plan created with JTP_ROCTX=1 in the environment; without it (or without the library) the
+// calls are no-ops.
+namespace roctx {
+typedef int (*Push_t)(const char *);
+typedef int (*Pop_t)(void);
+static Push_t Push = nullptr;
+static Pop_t Pop = nullptr;
+static int state = 0;                   // 0 not looked up, 1 available, -1 absent
+static void load() {
+    if (state != 0) return;
+    state = -1;
+    for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) continue;
+        Push = (Push_t)dlsym(h, "roctxRangePushA");
+        Pop = (Pop_t)dlsym(h, "roctxRangePop");
+        if (Push && Pop) {
+            state = 1;
+            return;
+        }
+    }
+}
+struct Range {
+    bool on;
+    Range(bool enabled, const char *name) : on(enabled && state == 1) { if (on) Push(name); }
+    ~Range() { if (on) Pop(); }
+};
+}  // namespace roctx
+
 #define NCCL_TRY(expr)                                                                          \
     do {                                                                                        \
         int _r = (expr);                                                                        \
@@ -177,6 +208,7 @@ struct jtp_plan {
     bool counted = false;           // included in g_live_plans
     uint32_t flow_debug = 0;        // JTP_FLOW_DEBUG at plan creation, or jtp_debug_set(plan, "flow_debug", v)
     bool env_tickets = false;       // JTP_FLOW_TICKETS at plan creation
+    bool roctx = false;             // JTP_ROCTX at plan creation: named ranges around the phases of a propagate
     // multi-set plans (JTP_MULTISET): evidence sets in groups of JT_MSETS, one allocation each for all sets'
     // message arenas, evidence tables and sync areas (bufs[b] point into them; bufs[b].psi/.bel are shared)
     bool multiset = false;
@@ -409,6 +441,8 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     pl->device = true;
     pl->flow_debug = hp.knobs.flow_debug;
     pl->env_tickets = hp.knobs.flow_tickets != 0;
+    pl->roctx = hp.knobs.roctx != 0;
+    if (pl->roctx) roctx::load();
     CREATE_TRY(hipSetDevice(hp.device));
     const int nstreams = pl->multiset ? 1 : std::min(hp.n_batch, 16);
     pl->streams.resize(nstreams);
@@ -887,6 +921,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
     HostPlan &hp = pl->hp;
     if (batch_end <= batch_begin || batch_end > hp.n_batch) return set_err(JTP_EINVAL, "bad batch range [%d,%d)", batch_begin, batch_end);
     HIP_TRY(hipSetDevice(hp.device));
+    roctx::Range whole(pl->roctx, pl->multiset ? "jtp_propagate (multi-set: collect + distribute)" : "jtp_propagate (collect + distribute)");
     if ((hp.flags & JTP_SHARE_POTENTIALS) && pl->psi_dirty) {
         HIP_TRY(hipStreamSynchronize(pl->streams[0]));        // the shared tables were written on stream 0
         pl->psi_dirty = false;
@@ -1078,6 +1113,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
     if (node < 0 || node >= hp.n_nodes) return set_err(JTP_EINVAL, "node %d out of range", node);
     if (host_dtype != JTP_F32 && host_dtype != JTP_F64) return set_err(JTP_EINVAL, "bad host dtype");
     HIP_TRY(hipSetDevice(hp.device));
+    roctx::Range range(pl->roctx, "jtp_get_belief");
     rc = settle(pl, batch);
     if (rc) return rc;
     hipStream_t s = pl->streams[batch % pl->streams.size()];
@@ -1201,6 +1237,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
     }
     HostPlan &hp = pl->hp;
     HIP_TRY(hipSetDevice(hp.device));
+    roctx::Range range(pl->roctx, "jtp_get_marginals");
     rc = settle(pl, batch);
     if (rc) return rc;
     hipStream_t s = pl->streams[batch % pl->streams.size()];

@@ -337,6 +337,7 @@ PlanKnobs jtp_read_knobs() {
     k.flow_debug = (unsigned)geti("JTP_FLOW_DEBUG", 0);
     k.flow_tickets = geti("JTP_FLOW_TICKETS", 0);
     k.no_compact = geti("JTP_NO_COMPACT", 0);
+    k.roctx = geti("JTP_ROCTX", 0);
     return k;
 }
 
