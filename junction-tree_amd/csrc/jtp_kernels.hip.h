@@ -235,27 +235,70 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                     gp1[k] = (gp0[k] + per < m.npart) ? gp0[k] + per : m.npart;
                     maxper = per > maxper ? per : maxper;
                 } else {
-                    // one thread per entry, all copies (eight loads in flight)
+                    // One thread per entry and round of 256 entries, eight loads in flight per thread: eight entries
+                    // of a single-copy message, else 2^plog copies of 8 >> plog entries (a sub-box of 1024 single-copy
+                    // entries used to cost four dependent round trips, now one).  Every entry's copies are still
+                    // summed in ascending order from 0.0.
                     double *sub = reinterpret_cast<double *>(smem + m.lds_off);
                     const int n = 1 << nfree;
-                    for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
+                    const int npart = m.npart;
+                    auto entry_at = [&](int it, int pc) {
                         int idx = idx_t[k];
 #pragma unroll
                         for (int b = 8; b < JT_MAX_FREE; ++b)
                             if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
-                        double sum = 0.0;
-                        for (int p = 0; p < m.npart; p += 8) {
+                        return src[k] + ((int64_t)pc * ps[k] + idx);
+                    };
+                    if (npart == 1) {
+                        for (int it0 = 0; it0 * JT_THREADS < n; it0 += 8) {
                             double c[8];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) c[u] = (p + u < m.npart) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(p + u) * ps[k] + idx), thr_mem[k]) : 0.0;
+                            for (int u = 0; u < 8; ++u)
+                                c[u] = (it0 + u) * JT_THREADS + tid < n ? jt_msg_load<FLOW>(entry_at(it0 + u, 0), thr_mem[k]) : 0.0;
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
-                                if (FLOW && p + u < m.npart) c[u] = jt_msg_settle<FLOW>(src[k] + ((int64_t)(p + u) * ps[k] + idx), c[u], thr_mem[k], settle_attempt);
-                                sum += c[u];
-                                if (FLOW && jt_unwritten(c[u])) unready = src[k] + ((int64_t)(p + u) * ps[k] + idx);
+                                if ((it0 + u) * JT_THREADS + tid >= n) continue;
+                                if (FLOW) c[u] = jt_msg_settle<FLOW>(entry_at(it0 + u, 0), c[u], thr_mem[k], settle_attempt);
+                                if (FLOW && jt_unwritten(c[u])) unready = entry_at(it0 + u, 0);
+                                sub[(it0 + u) * JT_THREADS + tid] = 0.0 + c[u];
                             }
                         }
-                        sub[s] = sum;
+                    } else {
+                        const int plog = npart >= 8 ? 3 : (npart >= 4 ? 2 : 1);
+                        const int pmask = (1 << plog) - 1, E = 8 >> plog;
+                        for (int it0 = 0; it0 * JT_THREADS < n; it0 += E) {
+                            double sum[4] = {0.0, 0.0, 0.0, 0.0};
+                            for (int p0 = 0; p0 < npart; p0 += 1 << plog) {
+                                double c[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int e = u >> plog, pc = p0 + (u & pmask);
+                                    const bool ok = (it0 + e) * JT_THREADS + tid < n && pc < npart;
+                                    c[u] = ok ? jt_msg_load<FLOW>(entry_at(it0 + e, pc), thr_mem[k]) : 0.0;
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int e = u >> plog, pc = p0 + (u & pmask);
+                                    const bool ok = (it0 + e) * JT_THREADS + tid < n && pc < npart;
+                                    if (FLOW && ok) c[u] = jt_msg_settle<FLOW>(entry_at(it0 + e, pc), c[u], thr_mem[k], settle_attempt);
+                                    if (FLOW && jt_unwritten(c[u])) unready = entry_at(it0 + e, pc);
+                                }
+                                // (plog is uniform: the entry a value belongs to is picked with compile-time indices)
+                                if (plog == 1) {
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) sum[u >> 1] += c[u];
+                                } else if (plog == 2) {
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) sum[u >> 2] += c[u];
+                                } else {
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) sum[0] += c[u];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (e < E && (it0 + e) * JT_THREADS + tid < n) sub[(it0 + e) * JT_THREADS + tid] = sum[e];
+                        }
                     }
                 }
             }
@@ -768,7 +811,7 @@ __global__ __launch_bounds__(JT_THREADS) void jt_reduce_level(const JtTask *__re
 // Entry points (these names appear in rocprofv3 traces).  One launch covers every clique of
 // one tree level, whatever its number of neighbours: the workgroup dispatches on its task.
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS) void jt_collect_level(const JtTask *__restrict__ tasks,
+__global__ __launch_bounds__(JT_THREADS, 4) void jt_collect_level(const JtTask *__restrict__ tasks,
                                                                const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                const T *__restrict__ psi, T *__restrict__ bel,
                                                                double *__restrict__ msg, JtFlow fl) {
@@ -783,7 +826,7 @@ __global__ __launch_bounds__(JT_THREADS) void jt_collect_level(const JtTask *__r
 }
 
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS) void jt_distribute_level(const JtTask *__restrict__ tasks,
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_level(const JtTask *__restrict__ tasks,
                                                                   const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                   const T *__restrict__ psi, T *__restrict__ bel,
                                                                   double *__restrict__ msg, JtFlow fl) {
@@ -817,7 +860,7 @@ __device__ __forceinline__ uint32_t jt_flow_ticket(const JtFlow &fl, uint32_t *f
 }
 
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS) void jt_collect_flow(const JtTask *__restrict__ tasks,
+__global__ __launch_bounds__(JT_THREADS, 4) void jt_collect_flow(const JtTask *__restrict__ tasks,
                                                               const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                               const T *__restrict__ psi, T *__restrict__ bel,
                                                               double *__restrict__ msg, JtFlow fl) {
@@ -839,7 +882,7 @@ __global__ __launch_bounds__(JT_THREADS) void jt_collect_flow(const JtTask *__re
 }
 
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS) void jt_distribute_flow(const JtTask *__restrict__ tasks,
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_flow(const JtTask *__restrict__ tasks,
                                                                  const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                  const T *__restrict__ psi, T *__restrict__ bel,
                                                                  double *__restrict__ msg, JtFlow fl) {

@@ -10,6 +10,7 @@
 #include "jtp_plan.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +66,132 @@ MsgView make_view(const PNode &p, const PSep &s, int psep, bool up) {
     return mv;
 }
 
+// ---- layout policy 4: a cost model of one task, searched over loop sets (and, in layouts(), over thread parts) -----
+// Made for cliques whose messages are not small beside the table (config 3: 2 MiB messages, 8-64 MiB tables), where
+// the greedy F/A/R split below ends at 8 iterations per workgroup under 50-70 KiB of sub-boxes and 8-16 partial
+// copies.  The model prices a task as workgroups x (start-up + staging + iterations + epilogues + flush) over the
+// workgroups the chip holds, floored by its bytes at streaming speed, plus the reduce tasks of its partial copies.
+// The constants are from in-kernel time stamps on config 3 and 4 (profiles/r02_stage_times*.txt): they only have to
+// rank candidates, not to predict microseconds.
+struct CostEnv {
+    int TB = 10, EB = 2, nbits = 0;
+    bool dist = false;           // distribute pass: the table is written as well as read
+    int max_iter_log2 = JT_MAX_ITER_LOG2;
+    double share = 1.0;          // part of the chip this clique can count on (its share of the level's elements)
+    double fill = 1.0;           // rows that exist / rows of the index space (variables stored at their true cardinality)
+    long lds_cap = 150 * 1024;
+    std::vector<uint32_t> units; // atomic groups of bits above the thread part (a compact variable stays together)
+};
+
+double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const std::vector<uint32_t> &outs, uint32_t L, long *lds_out = nullptr) {
+    const uint32_t tmask = (1u << e.TB) - 1u;
+    const uint32_t himask = (e.nbits >= 32 ? ~0u : ((1u << e.nbits) - 1u)) & ~tmask;
+    const uint32_t F = himask & ~L, cover = tmask | L;
+    const int nL = popc(L);
+    if (nL < JT_MIN_ITER_LOG2 || nL > e.max_iter_log2 || popc(F) > JT_MAX_HI) return 1e30;
+    const double nwg = std::max(1.0, std::ldexp(e.fill, popc(F))), iters = std::ldexp(1.0, nL);
+    long lds = JT_RING_BYTES;
+    double stage = 0, flush = 0, red_bytes = 0, epi = 0;
+    int n_red = 0;
+    for (uint32_t m : ins) {
+        const int fb = popc(m & cover);
+        if (fb > JT_MAX_FREE) return 1e30;
+        lds += (8L << fb) + JT_STAGE_SCRATCH;
+        stage += 8.0 * (double)(1L << fb);
+    }
+    uint32_t allout = 0;
+    const uint32_t wave_bits = 3u << (e.TB - 2), lane_bits = 63u << e.EB;
+    for (uint32_t o : outs) {
+        const int fb = popc(o & cover);
+        if (fb > JT_MAX_FREE) return 1e30;
+        lds += 8L << fb;
+        flush += 8.0 * (double)(1L << fb);
+        const int np = popc(F & ~o);
+        if (np > 6) return 1e30;
+        if (np) {
+            red_bytes += (std::ldexp(1.0, np) + 1.0) * 8.0 * std::ldexp(1.0, popc(o));
+            ++n_red;
+        }
+        allout |= o;
+        // an epilogue folds the register sums into the sub-box: butterflies over summed lane bits, one ordered
+        // phase (barriers) per summed wave bit
+        epi += 0.28 * (1.0 + 1.5 * popc(~o & wave_bits)) + 0.03 * popc(~o & lane_bits);
+    }
+    if (lds > e.lds_cap) return 1e30;
+    if (lds_out) *lds_out = lds;
+    const int nA = popc(L & allout);
+    const double epilogues = outs.empty() ? 0.0 : std::ldexp(1.0, nA);
+    // (start-up, staging and flush are latency chains: record -> addresses -> message loads -> LDS -> barrier cost
+    //  6-7 us even for a few KiB)
+    const double t_wg = 1.5 + (ins.empty() ? 0.0 : 5.0) + stage / 16384.0 + iters * (e.dist ? 0.55 : 0.45) + epilogues * epi +
+                        (outs.empty() ? 0.0 : 1.0) + flush / 16384.0;
+    const int per_cu = (int)std::min(5L, std::max(1L, 160L * 1024 / lds));
+    const double conc = std::max(1.0, 256.0 * per_cu * e.share);
+    const double t_lat = std::max(t_wg, nwg * t_wg / conc);
+    const double bytes = nwg * (iters * 4096.0 * (e.dist ? 2.0 : 1.0) + 0.5 * stage + flush);
+    // (neither bound hides the other completely: a workgroup's start-up and epilogues issue no loads)
+    const double t_bw = bytes / (5.0e6 * e.share);
+    double t = std::max(t_lat, t_bw) + 0.5 * std::min(t_lat, t_bw);
+    if (n_red) t += 4.0 + red_bytes / (3.0e6 * e.share);
+    return t;
+}
+
+struct LoopChoice {
+    uint32_t L = 0;
+    double us = 1e30;
+    long lds = 0;
+};
+
+// best loop set of one task: every subset of the units with 2..max_iter_log2 bits (`exhaustive`), or units added
+// one at a time, cheapest first
+LoopChoice search_loops(const CostEnv &e, const std::vector<uint32_t> &ins, const std::vector<uint32_t> &outs, bool exhaustive) {
+    LoopChoice best;
+    const int n = (int)e.units.size();
+    auto consider = [&](uint32_t L) {
+        long lds = 0;
+        const double us = task_cost_us(e, ins, outs, L, &lds);
+        if (us < best.us) best.L = L, best.us = us, best.lds = lds;
+        return us;
+    };
+    if (exhaustive) {
+        // depth first over the units, low bits first, pruned by the iteration cap
+        std::vector<std::pair<int, uint32_t>> stack;      // (next unit, L)
+        stack.push_back({0, 0u});
+        while (!stack.empty()) {
+            auto [i, L] = stack.back();
+            stack.pop_back();
+            if (i == n) {
+                consider(L);
+                continue;
+            }
+            stack.push_back({i + 1, L});
+            if (popc(L | e.units[i]) <= e.max_iter_log2) stack.push_back({i + 1, L | e.units[i]});
+        }
+    } else {
+        uint32_t L = 0;
+        for (;;) {
+            int pick = -1;
+            double pick_us = 1e31;
+            for (int i = 0; i < n; ++i) {
+                if ((L & e.units[i]) || popc(L | e.units[i]) > e.max_iter_log2) continue;
+                const double us = popc(L | e.units[i]) < JT_MIN_ITER_LOG2 ? 1e30 : consider(L | e.units[i]);
+                // (below four iterations nothing can be priced: take the unit the fewest messages contain)
+                double key = us;
+                if (us >= 1e30) {
+                    int cnt = 0;
+                    for (uint32_t m : ins) cnt += (m & e.units[i]) != 0;
+                    for (uint32_t o : outs) cnt += 2 * ((o & e.units[i]) != 0);
+                    key = 1e30 + cnt;
+                }
+                if (key < pick_us) pick_us = key, pick = i;
+            }
+            if (pick < 0) break;
+            L |= e.units[pick];
+        }
+    }
+    return best;
+}
+
 // Choose the F / A / R split of the high bits and fill every index table of the task.
 // Does the high part (bits >= TB) of logical index `x`, restricted to the bits in `within`, name rows that exist?
 // A compact variable whose bits all lie in `within` must have a digit below its cardinality; a padding bit in
@@ -80,7 +207,7 @@ bool high_digits_exist(const PNode &p, uint32_t x, uint32_t within) {
 
 int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32_t> &itab, int nbits, int real_bits,
                const std::vector<MsgView> &ins, const std::vector<MsgView> &outs, int block_log2, std::string &err,
-               int strict_budget = 0) {
+               int strict_budget = 0, double share = 1.0) {
     const int TB = hp.TB;
     // the bits of a compact variable (stored at its true cardinality) go to the chunk bits or stay loop bits TOGETHER
     auto unit = [&](int b) {
@@ -121,8 +248,30 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
     };
 
     uint32_t F = 0;
+    bool searched = false;
+    if (p.layout == 4 && strict_budget == 0) {
+        // searched split (cost model above): every loop set the iteration cap allows
+        CostEnv e;
+        e.TB = TB, e.EB = hp.EB, e.nbits = nbits, e.dist = tk.mode == 1, e.share = share;
+        e.max_iter_log2 = std::min(std::max(block_log2 - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
+        if (hp.lds_budget > 0) e.lds_cap = JT_RING_BYTES + hp.lds_budget + JT_STAGE_SCRATCH * (long)ins.size();
+        uint32_t seen = 0;
+        for (int b = TB; b < nbits; ++b)
+            if (!(seen >> b & 1)) e.units.push_back(unit(b)), seen |= unit(b);
+        for (size_t g = 0; g < p.group_mask.size(); ++g) e.fill *= (double)p.group_card[g] / (double)(1 << popc(p.group_mask[g]));
+        e.fill = std::ldexp(e.fill, -popc(p.pad_mask & himask));
+        std::vector<uint32_t> im, om;
+        for (auto &m : ins) im.push_back(m.mask);
+        for (auto &o : outs) om.push_back(o.mask);
+        LoopChoice ch = search_loops(e, im, om, true);
+        if (getenv("JTP_PLAN_DEBUG") && nbits >= 24) {
+            fprintf(stderr, "pnode %d mode %d nbits %d cap %d share %.3f best L %x us %.1f lds %ld\n", tk.pnode, tk.mode, nbits, e.max_iter_log2, e.share, ch.L, ch.us, ch.lds);
+            for (int k = 2; k <= 6; ++k) { CostEnv e2 = e; e2.max_iter_log2 = k; LoopChoice c2 = search_loops(e2, im, om, true); fprintf(stderr, "   cap %d: L %x us %.1f lds %ld\n", k, c2.L, c2.us, c2.lds); }
+        }
+        if (ch.us < 1e30) F = himask & ~ch.L, searched = true;
+    }
     // 1. LDS must fit: fix the high bit that shrinks the staged sub-boxes most.
-    while (lds_of(F) > budget || max_free(F) > JT_MAX_FREE) {
+    while (!searched && (lds_of(F) > budget || max_free(F) > JT_MAX_FREE)) {
         int best = -1;
         long best_lds = 0;
         int best_part = 0;
@@ -147,7 +296,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
     //    bits that every outgoing message contains (no partial copies), highest bit first.
     block_log2 = std::max(block_log2, TB + JT_MIN_ITER_LOG2);   // a workgroup always runs >= 4 iterations
     block_log2 = std::min(block_log2, TB + JT_MAX_ITER_LOG2);   // and at most 2^JT_MAX_ITER_LOG2
-    while (nbits - popc(F) > block_log2) {
+    while (!searched && nbits - popc(F) > block_log2) {
         int best = -1;
         auto fits = [&](int b) { return nbits - popc(F | unit(b)) >= TB + JT_MIN_ITER_LOG2; };      // >= 4 iterations stay
         for (int b = nbits - 1; b >= TB; --b)
@@ -337,6 +486,7 @@ PlanKnobs jtp_read_knobs() {
     k.flow_debug = (unsigned)geti("JTP_FLOW_DEBUG", 0);
     k.flow_tickets = geti("JTP_FLOW_TICKETS", 0);
     k.no_compact = geti("JTP_NO_COMPACT", 0);
+    k.no_search = geti("JTP_NO_SEARCH", 0);
     k.roctx = geti("JTP_ROCTX", 0);
     return k;
 }
@@ -364,6 +514,7 @@ struct PlanBuilder {
     int binarise();              // at most three children per node (virtual all-ones cliques)
     int depths();
     int layouts();               // bit order of every clique and separator table
+    bool searched_order(int c, const std::vector<int> &host, const std::vector<int> &seps, std::vector<int> &order);   // layout policy 4
     int arenas();                // table offsets, host<->device conversion records
     int level_work();
     int make_tasks();            // one task per (clique, phase) - multi-set plans: per (clique, child) in distribute
@@ -643,8 +794,161 @@ int PlanBuilder::depths() {
     return JTP_OK;
 }
 
+// Layout policy 4: the variables of the thread part (and their order) chosen by the cost model of plan_loops' search,
+// summed over the clique's collect and distribute tasks.  Candidates: every set of variables that fills the thread
+// part (cliques of up to 12 variables), else a hill climb from the "traffic first" order by swapping one variable in
+// and one out.  Inside the thread part variables of the fewest messages go lowest (element bits that are summed cost
+// nothing, wave bits that are summed cost a barrier phase each), as in policy 2.
+bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std::vector<int> &seps, std::vector<int> &order) {
+    const PNode &p = hp.pn[c];
+    const int n = (int)host.size(), TB = hp.TB;
+    if (n == 0 || n > 31) return false;
+    std::vector<int> cnt(n, 0), canon(n), rank_of(n);
+    for (int i = 0; i < n; ++i) {
+        for (int sp : seps) cnt[i] += find_var(hp.ps[sp].vars, host[i]) >= 0;
+        canon[i] = i;
+    }
+    auto waste = [&](int i) { return (double)(1 << hp.vbits[host[i]]) / hp.card[host[i]]; };
+    std::stable_sort(canon.begin(), canon.end(), [&](int a, int b) { return cnt[a] != cnt[b] ? cnt[a] < cnt[b] : waste(a) < waste(b); });
+    for (int r = 0; r < n; ++r) rank_of[canon[r]] = r;
+    int total_bits = 0;
+    for (int v : host) total_bits += hp.vbits[v];
+    if (total_bits <= TB) return false;           // one workgroup row: nothing to choose
+    auto bits_of = [&](uint32_t S) {
+        int b = 0;
+        for (int i = 0; i < n; ++i)
+            if (S >> i & 1) b += hp.vbits[host[i]];
+        return b;
+    };
+    auto valid = [&](uint32_t S) {                // fills the thread part, and would not without its last variable
+        if (!S) return false;
+        int last = -1;
+        for (int r = n - 1; r >= 0 && last < 0; --r)
+            if (S >> canon[r] & 1) last = canon[r];
+        const int b = bits_of(S);
+        return b >= TB && b - hp.vbits[host[last]] < TB;
+    };
+    struct Eval { double us = 1e30; uint32_t Ld = 0, Lc = 0; };
+    std::vector<int> idx;                          // scratch: candidate order as indices into host
+    auto order_of = [&](uint32_t S) {
+        idx.clear();
+        for (int r = 0; r < n; ++r) if (S >> canon[r] & 1) idx.push_back(canon[r]);
+        for (int r = 0; r < n; ++r) if (!(S >> canon[r] & 1)) idx.push_back(canon[r]);
+    };
+    std::vector<int> pos(n);
+    auto evaluate = [&](uint32_t S) {
+        Eval ev;
+        order_of(S);
+        int bit = 0;
+        for (int i : idx) pos[i] = bit, bit += hp.vbits[host[i]];
+        CostEnv e;
+        e.TB = TB, e.EB = hp.EB, e.nbits = std::max(bit, TB + JT_MIN_ITER_LOG2);
+        uint32_t grouped = 0;
+        for (int i : idx) {
+            const int card = hp.card[host[i]], nb = hp.vbits[host[i]];
+            if (pos[i] >= TB && hp.compact && (card & (card - 1)) != 0) {
+                const uint32_t g = ((1u << nb) - 1u) << pos[i];
+                e.units.push_back(g), grouped |= g;
+                e.fill *= (double)card / (double)(1 << nb);
+            }
+        }
+        for (int b = TB; b < e.nbits; ++b)
+            if (!(grouped >> b & 1)) e.units.push_back(1u << b);
+        if (hp.compact) e.fill = std::ldexp(e.fill, -(e.nbits - std::max(bit, TB)));
+        std::sort(e.units.begin(), e.units.end());
+        if (hp.lds_budget > 0) e.lds_cap = JT_RING_BYTES + hp.lds_budget + JT_STAGE_SCRATCH * 4L;
+        auto mask_of = [&](int sp) {
+            uint32_t m = 0;
+            for (int v : hp.ps[sp].vars) {
+                const int i = find_var(host, v);
+                if (i >= 0) m |= ((1u << hp.vbits[v]) - 1u) << pos[i];
+            }
+            return m;
+        };
+        std::vector<uint32_t> kids, none;
+        for (int k : p.children) kids.push_back(mask_of(hp.pn[k].psep));
+        const double elems = std::ldexp(1.0, e.nbits);
+        ev.us = 0;
+        if (c != hp.root && p.psep >= 0) {
+            e.dist = false;
+            e.max_iter_log2 = std::min(std::max(block_log2_for(0, p.depth, p.owner) - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
+            e.share = std::min(1.0, elems / std::max(elems, lvl_elems[0][p.owner][p.depth]));
+            LoopChoice ch = search_loops(e, kids, {mask_of(p.psep)}, false);
+            ev.us += ch.us, ev.Lc = ch.L;
+        }
+        {
+            e.dist = true;
+            e.max_iter_log2 = std::min(std::max(block_log2_for(1, p.depth, p.owner) - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
+            e.share = std::min(1.0, elems / std::max(elems, lvl_elems[1][p.owner][p.depth]));
+            std::vector<uint32_t> ins;
+            if (p.psep >= 0) ins.push_back(mask_of(p.psep));
+            ins.insert(ins.end(), kids.begin(), kids.end());
+            LoopChoice ch = search_loops(e, ins, kids, false);
+            ev.us += ch.us, ev.Ld = ch.L;
+        }
+        return ev;
+    };
+    uint32_t bestS = 0;
+    Eval best;
+    if (n <= 12) {
+        for (uint32_t S = 1; S < (1u << n); ++S) {
+            if (!valid(S)) continue;
+            Eval ev = evaluate(S);
+            if (ev.us < best.us) best = ev, bestS = S;
+        }
+    } else {
+        uint32_t S = 0;                              // start: the canonical prefix
+        for (int r = 0; r < n && bits_of(S) < TB; ++r) S |= 1u << canon[r];
+        best = evaluate(S), bestS = S;
+        for (int pass = 0; pass < 4; ++pass) {
+            bool better = false;
+            for (int i = 0; i < n; ++i) {
+                if (!(bestS >> i & 1)) continue;
+                for (int j = 0; j < n; ++j) {
+                    if (bestS >> j & 1) continue;
+                    const uint32_t S2 = (bestS & ~(1u << i)) | (1u << j);
+                    if (!valid(S2)) continue;
+                    Eval ev = evaluate(S2);
+                    if (ev.us < best.us) {
+                        best = ev, bestS = S2, better = true;
+                        break;                       // i has left the set
+                    }
+                }
+            }
+            if (!better) break;
+        }
+    }
+    if (best.us >= 1e30) return false;
+    // thread part in canonical order; above it the variables the distribute task loops over first (its rows are
+    // then consecutive 4 KiB pieces), then the collect task's, then the chunk bits
+    order_of(bestS);
+    int bit = 0;
+    for (int i : idx) pos[i] = bit, bit += hp.vbits[host[i]];
+    auto klass = [&](int i) {
+        const uint32_t m = ((1u << hp.vbits[host[i]]) - 1u) << pos[i];
+        if (pos[i] < TB) return 0;
+        return (m & best.Ld) ? 1 : (m & best.Lc) ? 2 : 3;
+    };
+    std::vector<int> fin = idx;
+    std::stable_sort(fin.begin(), fin.end(), [&](int a, int b) { return klass(a) < klass(b); });
+    order.clear();
+    for (int i : fin) order.push_back(host[i]);
+    return true;
+}
+
 int PlanBuilder::layouts() {
     // ---- bit layouts ----------------------------------------------------------------------
+    // (level sizes from the padded index spaces, for the searched layouts: level_work() recomputes them from the
+    //  physical sizes once the layouts are known)
+    for (int ph = 0; ph < 2; ++ph) lvl_elems[ph].assign(hp.n_ranks + 1, std::vector<double>(maxdepth + 1, 0.0));
+    for (int c = 0; c < NP; ++c) {
+        const PNode &p = hp.pn[c];
+        int cb = 0;
+        for (int v : (p.real >= 0 ? hp.node_vars[p.real] : p.vars)) cb += hp.vbits[v];
+        const double e = std::ldexp(1.0, std::max(cb, hp.TB + JT_MIN_ITER_LOG2));
+        if (c != hp.root) lvl_elems[0][p.owner][p.depth] += e;
+        lvl_elems[1][p.owner][p.depth] += e;
+    }
     for (int c = 0; c < NP; ++c) {
         PNode &p = hp.pn[c];
         std::vector<int> host = p.real >= 0 ? hp.node_vars[p.real] : p.vars;
@@ -673,9 +977,15 @@ int PlanBuilder::layouts() {
             // (wide variables move the crossover down: the classes of policy 3 cannot split a variable)
             const double thr = (double)cb / std::max<size_t>(host.size(), 1) >= 2.0 ? 0.04 : 0.12;
             policy = (r >= thr || (p.children.size() <= 1 && r >= 0.01)) ? 2 : 3;
+            // where the messages weigh that much: search the thread part with the cost model (multi-set plans keep
+            // the heuristic: their sub-boxes have a hard per-set budget that the model does not know)
+            if (policy == 2 && !hp.multiset && !hp.knobs.no_search) policy = 4;
         }
+        if (policy == 4 && (seps.empty() || !searched_order(c, host, seps, order))) policy = 2, order.clear();
         p.layout = policy;
-        if (policy == 1 || seps.empty()) {
+        if (policy == 4) {
+            // order filled by searched_order
+        } else if (policy == 1 || seps.empty()) {
             order.assign(host.rbegin(), host.rend());
         } else if (policy == 2) {
             // Message traffic first (separators nearly as large as the cliques: every message entry is
@@ -960,8 +1270,9 @@ int PlanBuilder::make_tasks() {
             int real_bits = 0;
             for (int nb : p.nb) real_bits += nb;
             std::vector<int32_t> itab;
+            const double share = std::min(1.0, (double)p.phys_elems / std::max(1.0, lvl_elems[phase][p.owner][p.depth]));
             int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err,
-                                hp.multiset ? JT_SETB_SMALL : 0);
+                                hp.multiset ? JT_SETB_SMALL : 0, share);
             if (rc != JTP_OK && hp.multiset)
                 rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
             if (rc != JTP_OK) return rc;
