@@ -97,10 +97,14 @@ struct JtTask {
                                // task (planner), bit 1 = no evidence set observes a variable on them (engine, updated by
                                // jtp_set_evidence).  Both set: the four elements are summed BEFORE they meet the message
                                // product - one fused multiply-add per evidence set and row instead of four.
-    int32_t pad1;
+    uint32_t out_run;          // byte j: log2 of the iterations over which outgoing message j's sums stay in registers
+                               // (the leading loop-counter bits that message j does not contain: the nR bits no
+                               // outgoing message contains, then A bits of other messages only); message j's epilogue
+                               // follows every 2^run iterations
     uint32_t f_x[JT_MAX_HI];   // element-offset weight of F bit j (physical)
     uint32_t f_lx[JT_MAX_HI];  // logical index weight of F bit j (1 << bit): evidence masks are over the logical index
-    uint8_t loop_pos[8];       // logical index bit of loop-counter bit t (t < nR: R bits, then A bits)
+    uint8_t loop_pos[8];       // logical index bit of loop-counter bit t (t < nR: R bits, then A bits, those of the fewest
+                               // outgoing messages first)
     uint32_t first_x[8];       // element offsets of loop iterations 0..7 (relative to the chunk base; 0 past the end;
                                // JT_NO_ROW: the row does not exist)
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer

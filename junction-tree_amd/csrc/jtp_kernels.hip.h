@@ -144,7 +144,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     T *bel = bel_arena + (MODE == 1 ? tk.bel_off : 0);   // distribute always stores (virtual cliques: scratch)
     const int total = tk.total;                       // loop iterations of this workgroup (>= U)
     const int dbg = tk.debug;
-    const int rmask = (1 << tk.nR) - 1;               // an outgoing-message epilogue follows every 2^nR
+    // outgoing message j's epilogue follows every 2^run_j iterations (JtTask::out_run)
+    int rmask[NOUT > 0 ? NOUT : 1];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) rmask[j] = (1 << ((tk.out_run >> (8 * j)) & 0xffu)) - 1;
     // hard evidence of this evidence set on this clique (jtp_set_evidence): table entries whose index
     // contradicts it count as zero (read here, before the first store: see the scalar-cache note below)
     uint32_t ev_mask = 0, ev_val = 0;
@@ -442,10 +445,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[j][e] = 0.0;
 
-    // fold this thread's sums of one A iteration into the outgoing sub-boxes
-    auto epilogue = [&](const int (&oo)[NOUT > 0 ? NOUT : 1]) {
-#pragma unroll
-        for (int j = 0; j < NOUT; ++j) {
+    // fold this thread's sums for outgoing message j (one run of iterations) into its sub-box
+    auto epilogue = [&](auto j_tag, const int oo_j) {
+        {
+            constexpr int j = decltype(j_tag)::value;
             const int red_e = o_rede[j], red_lane = o_redl[j], red_wave = o_redw[j];
             if constexpr (VEC == 4) {
                 if (red_e & 1) {
@@ -468,7 +471,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 }
             }
             const bool rep = (lane & red_lane) == 0;
-            const int slot = oo[j] + thr[NIN + j];
+            const int slot = oo_j + thr[NIN + j];
             const int nph = (dbg & 8) ? 1 : 1 << __builtin_popcount((unsigned)red_wave);
             // waves that share slots (wave bits not in the message) take turns, in wave order
             int myph = 0;
@@ -600,11 +603,12 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             }
         }
         if constexpr (NOUT > 0) {
-            if ((i & rmask) == rmask && !(dbg & 1)) {
-                int oo[NOUT];
-#pragma unroll
-                for (int j = 0; j < NOUT; ++j) oo[j] = ooff[j];
-                epilogue(oo);
+            if (!(dbg & 1)) {
+                if ((i & rmask[0]) == rmask[0]) epilogue(std::integral_constant<int, 0>{}, ooff[0]);
+                if constexpr (NOUT > 1)
+                    if ((i & rmask[1]) == rmask[1]) epilogue(std::integral_constant<int, 1>{}, ooff[1]);
+                if constexpr (NOUT > 2)
+                    if ((i & rmask[2]) == rmask[2]) epilogue(std::integral_constant<int, 2>{}, ooff[2]);
             }
         }
     };

@@ -73,6 +73,42 @@ MsgView make_view(const PNode &p, const PSep &s, int psep, bool up) {
 // workgroups the chip holds, floored by its bytes at streaming speed, plus the reduce tasks of its partial copies.
 // The constants are from in-kernel time stamps on config 3 and 4 (profiles/r02_stage_times*.txt): they only have to
 // rank candidates, not to predict microseconds.
+// Loop order of the A bits (loop bits some outgoing message contains): bits of the fewest outgoing messages first, and
+// among those the largest class first, so that the messages which do NOT contain the leading bits keep their sums in
+// registers over the longest runs (JtTask::out_run).
+void order_a_bits(std::vector<int> &Ab, const std::vector<uint32_t> &outs) {
+    auto klass = [&](int b) {
+        uint32_t k = 0;
+        for (size_t j = 0; j < outs.size(); ++j) k |= (outs[j] >> b & 1u) << j;
+        return k;
+    };
+    int size[1 << JT_MAX_OUT] = {0};
+    for (int b : Ab) ++size[klass(b)];
+    std::stable_sort(Ab.begin(), Ab.end(), [&](int a, int b) {
+        const uint32_t ka = klass(a), kb = klass(b);
+        if (popc(ka) != popc(kb)) return popc(ka) < popc(kb);
+        if (size[ka] != size[kb]) return size[ka] > size[kb];
+        if (ka != kb) return ka < kb;
+        return a < b;
+    });
+}
+
+struct CostK {               // constants of the model (JTP_COST_* environment overrides are experiments only)
+    double wg = 1.5, stage_fix = 5.0, stage_bw = 4096.0, iter_c = 0.45, iter_d = 0.55, epi = 0.5, wave = 1.5, lane = 0.1,
+           flush_fix = 1.0, flush_bw = 16384.0, bw = 5.0e6, red_fix = 4.0, red_bw = 3.0e6, overlap = 0.5, max_cu = 3;
+    CostK() {
+        auto g = [](const char *n, double &v) { if (const char *e = getenv(n)) v = atof(e); };
+        g("JTP_COST_WG", wg), g("JTP_COST_STAGE_FIX", stage_fix), g("JTP_COST_STAGE_BW", stage_bw), g("JTP_COST_ITER_C", iter_c);
+        g("JTP_COST_ITER_D", iter_d), g("JTP_COST_EPI", epi), g("JTP_COST_WAVE", wave), g("JTP_COST_LANE", lane);
+        g("JTP_COST_FLUSH_FIX", flush_fix), g("JTP_COST_FLUSH_BW", flush_bw), g("JTP_COST_BW", bw), g("JTP_COST_RED_FIX", red_fix);
+        g("JTP_COST_RED_BW", red_bw), g("JTP_COST_OVERLAP", overlap), g("JTP_COST_MAX_CU", max_cu);
+    }
+};
+const CostK &cost_k() {
+    static const CostK k;
+    return k;
+}
+
 struct CostEnv {
     int TB = 10, EB = 2, nbits = 0;
     bool dist = false;           // distribute pass: the table is written as well as read
@@ -84,6 +120,7 @@ struct CostEnv {
 };
 
 double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const std::vector<uint32_t> &outs, uint32_t L, long *lds_out = nullptr) {
+    const CostK &K = cost_k();
     const uint32_t tmask = (1u << e.TB) - 1u;
     const uint32_t himask = (e.nbits >= 32 ? ~0u : ((1u << e.nbits) - 1u)) & ~tmask;
     const uint32_t F = himask & ~L, cover = tmask | L;
@@ -100,6 +137,12 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
         stage += 8.0 * (double)(1L << fb);
     }
     uint32_t allout = 0;
+    for (uint32_t o : outs) allout |= o;
+    std::vector<int> Ab;
+    for (int b = e.TB; b < e.nbits; ++b)
+        if ((L & allout) >> b & 1) Ab.push_back(b);
+    if (outs.size() > 1) order_a_bits(Ab, outs);
+    const int nR = popc(L & ~allout);
     const uint32_t wave_bits = 3u << (e.TB - 2), lane_bits = 63u << e.EB;
     for (uint32_t o : outs) {
         const int fb = popc(o & cover);
@@ -112,27 +155,31 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
             red_bytes += (std::ldexp(1.0, np) + 1.0) * 8.0 * std::ldexp(1.0, popc(o));
             ++n_red;
         }
-        allout |= o;
         // an epilogue folds the register sums into the sub-box: butterflies over summed lane bits, one ordered
-        // phase (barriers) per summed wave bit
-        epi += 0.28 * (1.0 + 1.5 * popc(~o & wave_bits)) + 0.03 * popc(~o & lane_bits);
+        // phase (barriers) per summed wave bit; it follows every run of iterations whose loop bits the message lacks
+        int run = nR;
+        for (int b : Ab) {
+            if (o >> b & 1) break;
+            ++run;
+        }
+        epi += std::ldexp(K.epi * (1.0 + K.wave * popc(~o & wave_bits)) + K.lane * popc(~o & lane_bits), nL - run);
     }
     if (lds > e.lds_cap) return 1e30;
     if (lds_out) *lds_out = lds;
-    const int nA = popc(L & allout);
-    const double epilogues = outs.empty() ? 0.0 : std::ldexp(1.0, nA);
+    const double epilogues = 1.0;          // (epi already holds every message's epilogues of the whole loop)
     // (start-up, staging and flush are latency chains: record -> addresses -> message loads -> LDS -> barrier cost
     //  6-7 us even for a few KiB)
-    const double t_wg = 1.5 + (ins.empty() ? 0.0 : 5.0) + stage / 16384.0 + iters * (e.dist ? 0.55 : 0.45) + epilogues * epi +
-                        (outs.empty() ? 0.0 : 1.0) + flush / 16384.0;
-    const int per_cu = (int)std::min(5L, std::max(1L, 160L * 1024 / lds));
+    const double t_wg = K.wg + (ins.empty() ? 0.0 : K.stage_fix) + stage / K.stage_bw + iters * (e.dist ? K.iter_d : K.iter_c) + epilogues * epi +
+                        (outs.empty() ? 0.0 : K.flush_fix) + flush / K.flush_bw;
+    // (workgroups a CU holds: LDS, and the kernels' registers - four waves per SIMD in collect, three in distribute)
+    const int per_cu = (int)std::min((long)K.max_cu + (e.dist ? 0 : 1), std::max(1L, 160L * 1024 / lds));
     const double conc = std::max(1.0, 256.0 * per_cu * e.share);
     const double t_lat = std::max(t_wg, nwg * t_wg / conc);
     const double bytes = nwg * (iters * 4096.0 * (e.dist ? 2.0 : 1.0) + 0.5 * stage + flush);
     // (neither bound hides the other completely: a workgroup's start-up and epilogues issue no loads)
-    const double t_bw = bytes / (5.0e6 * e.share);
-    double t = std::max(t_lat, t_bw) + 0.5 * std::min(t_lat, t_bw);
-    if (n_red) t += 4.0 + red_bytes / (3.0e6 * e.share);
+    const double t_bw = bytes / (K.bw * e.share);
+    double t = std::max(t_lat, t_bw) + K.overlap * std::min(t_lat, t_bw);
+    if (n_red) t += K.red_fix + red_bytes / (K.red_bw * e.share);
     return t;
 }
 
@@ -335,6 +382,11 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         else if (allout >> b & 1) Ab.push_back(b);
         else Rb.push_back(b);
     }
+    {
+        std::vector<uint32_t> om;
+        for (auto &o : outs) om.push_back(o.mask);
+        order_a_bits(Ab, om);
+    }
     tk.nbits = nbits;
     tk.real_bits = real_bits;
     tk.debug = hp.knobs.debug;
@@ -350,6 +402,15 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
     }
     for (int t = 0; t < tk.nR; ++t) tk.loop_pos[t] = (uint8_t)Rb[t];
     for (int t = 0; t < tk.nA; ++t) tk.loop_pos[tk.nR + t] = (uint8_t)Ab[t];
+    tk.out_run = 0;
+    for (size_t j = 0; j < outs.size(); ++j) {
+        int run = tk.nR;
+        for (int b : Ab) {
+            if (outs[j].mask >> b & 1) break;
+            ++run;
+        }
+        tk.out_run |= (uint32_t)run << (8 * j);
+    }
     uint32_t loopmask = 0;
     for (int b : Rb) loopmask |= 1u << b;
     for (int b : Ab) loopmask |= 1u << b;
@@ -1851,7 +1912,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             if (t) o << ",";
             o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
-              << ",\"nR\":" << tk.nR << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
+              << ",\"nR\":" << tk.nR << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
             json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";

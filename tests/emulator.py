@@ -213,8 +213,11 @@ class Emulator:
         xoff = np.where(xoff == NO_ROW, 0, xoff)
         in_off = [_signed(itab[:, :, 1 + k]) for k in range(n_in)]
         out_off = [_signed(itab[:, :, 1 + JT_MAX_IN + j]) for j in range(n_out)]
-        for j in range(n_out):      # the kernel reads outgoing offsets once per A iteration
-            assert np.all(out_off[j] == out_off[j][:, :1])
+        for j in range(n_out):      # the kernel reads message j's offsets once per run of 2^run_j iterations (JtTask::out_run)
+            run = (tk["out_run"] >> (8 * j)) & 0xFF
+            assert tk["nR"] <= run <= tk["nA"] + tk["nR"]
+            flat = out_off[j].reshape(-1, 1 << run)
+            assert np.all(flat == flat[:, :1])
         # element index of every (a, r, tid, e)
         x = (xF + xoff[:, :, None, None]
              + (tid * VEC)[None, None, :, None] + np.arange(VEC)[None, None, None, :]) & 0xFFFFFFFF
