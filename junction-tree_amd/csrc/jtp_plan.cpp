@@ -548,6 +548,7 @@ PlanKnobs jtp_read_knobs() {
     k.flow_tickets = geti("JTP_FLOW_TICKETS", 0);
     k.no_compact = geti("JTP_NO_COMPACT", 0);
     k.no_search = geti("JTP_NO_SEARCH", 0);
+    k.search_all = geti("JTP_SEARCH_ALL", 1);
     k.roctx = geti("JTP_ROCTX", 0);
     return k;
 }
@@ -874,7 +875,7 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
     for (int r = 0; r < n; ++r) rank_of[canon[r]] = r;
     int total_bits = 0;
     for (int v : host) total_bits += hp.vbits[v];
-    if (total_bits <= TB) return false;           // one workgroup row: nothing to choose
+    if (total_bits <= TB || total_bits > JT_MAX_BITS) return false;           // one workgroup row: nothing to choose; too large: refused by layouts()
     auto bits_of = [&](uint32_t S) {
         int b = 0;
         for (int i = 0; i < n; ++i)
@@ -1040,7 +1041,7 @@ int PlanBuilder::layouts() {
             policy = (r >= thr || (p.children.size() <= 1 && r >= 0.01)) ? 2 : 3;
             // where the messages weigh that much: search the thread part with the cost model (multi-set plans keep
             // the heuristic: their sub-boxes have a hard per-set budget that the model does not know)
-            if (policy == 2 && !hp.multiset && !hp.knobs.no_search) policy = 4;
+            if ((policy == 2 || hp.knobs.search_all) && !hp.multiset && !hp.knobs.no_search) policy = 4;
         }
         if (policy == 4 && (seps.empty() || !searched_order(c, host, seps, order))) policy = 2, order.clear();
         p.layout = policy;

@@ -101,6 +101,7 @@ struct PlanKnobs {
     unsigned flow_debug = 0;                                        // JTP_FLOW_DEBUG
     int flow_tickets = 0;                                           // JTP_FLOW_TICKETS
     int no_compact = 0;                                             // JTP_NO_COMPACT: every table padded to powers of two
+    int search_all = 1;                                             // JTP_SEARCH_ALL=0: the search only where policy 2 would have been chosen (else policy 3 stays)
     int no_search = 0;                                              // JTP_NO_SEARCH: layout policy 2 where the cost-model search (policy 4) would run
     int roctx = 0;                                                  // JTP_ROCTX: roctx ranges around propagates and read-outs
 };
