@@ -569,7 +569,7 @@ struct PlanBuilder {
         for (int v : vars) e *= hp.card[v];
         return e;
     }
-    int block_log2_for(int phase, int level, int owner) const;
+    int block_log2_for(int phase, int level, int owner, bool tiny_rule = true) const;
     int read_description();      // validate and copy the caller's description
     int link_nodes();            // cliques, separators, reachability, replicated part
     int reroot();                // single rank: root at the tree's centre
@@ -596,7 +596,7 @@ struct PlanBuilder {
     }
 };
 
-int PlanBuilder::block_log2_for(int phase, int level, int owner) const {
+int PlanBuilder::block_log2_for(int phase, int level, int owner, bool tiny_rule) const {
         if (hp.block_log2 > 0) return std::max(hp.block_log2, hp.TB);
         // aim at ~1024 workgroups per tree level (one round of resident workgroups; in a dataflow launch
         // the next level fills the tail), each streaming 16 KiB .. 256 KiB.  Measured on C4: 1024 is
@@ -606,7 +606,8 @@ int PlanBuilder::block_log2_for(int phase, int level, int owner) const {
         // levels of a clique or two are latency bound: 4 iterations per workgroup, so that every element
         // load is already in flight while the workgroup waits for its messages
         const double tiny = hp.knobs.tiny_level_elems;
-        if (lvl_elems[phase][owner][level] <= tiny) return hp.TB + JT_MIN_ITER_LOG2;
+        // (searched layouts price a lone workgroup's latency themselves: config 2 6.87 -> 6.49 ms without the rule)
+        if (tiny_rule && lvl_elems[phase][owner][level] <= tiny) return hp.TB + JT_MIN_ITER_LOG2;
         double want = lvl_elems[phase][owner][level] / target;
         int lg = lgmin;
         while (lg < lgmax && (double)(1 << (lg + 1)) <= want) ++lg;
@@ -933,14 +934,14 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
         ev.us = 0;
         if (c != hp.root && p.psep >= 0) {
             e.dist = false;
-            e.max_iter_log2 = std::min(std::max(block_log2_for(0, p.depth, p.owner) - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
+            e.max_iter_log2 = std::min(std::max(block_log2_for(0, p.depth, p.owner, false) - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
             e.share = std::min(1.0, elems / std::max(elems, lvl_elems[0][p.owner][p.depth]));
             LoopChoice ch = search_loops(e, kids, {mask_of(p.psep)}, false);
             ev.us += ch.us, ev.Lc = ch.L;
         }
         {
             e.dist = true;
-            e.max_iter_log2 = std::min(std::max(block_log2_for(1, p.depth, p.owner) - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
+            e.max_iter_log2 = std::min(std::max(block_log2_for(1, p.depth, p.owner, false) - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
             e.share = std::min(1.0, elems / std::max(elems, lvl_elems[1][p.owner][p.depth]));
             std::vector<uint32_t> ins;
             if (p.psep >= 0) ins.push_back(mask_of(p.psep));
@@ -1333,7 +1334,7 @@ int PlanBuilder::make_tasks() {
             for (int nb : p.nb) real_bits += nb;
             std::vector<int32_t> itab;
             const double share = std::min(1.0, (double)p.phys_elems / std::max(1.0, lvl_elems[phase][p.owner][p.depth]));
-            int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err,
+            int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner, p.layout != 4), err,
                                 hp.multiset ? JT_SETB_SMALL : 0, share);
             if (rc != JTP_OK && hp.multiset)
                 rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
@@ -1369,9 +1370,12 @@ int PlanBuilder::make_tasks() {
 }
 
 int PlanBuilder::messages() {
-    {   // plans whose tasks are mostly the 4-iteration workgroups of latency-bound levels (chains): settle in place
+    {   // plans whose tasks mostly sit on latency-bound levels - a clique or two - (chains): settle in place
         size_t tiny = 0;
-        for (const JtTask &tk : hp.tasks) tiny += tk.kind == 0 && tk.total == (1 << JT_MIN_ITER_LOG2);
+        for (const JtTask &tk : hp.tasks) {
+            const PNode &p = hp.pn[tk.pnode];
+            tiny += tk.kind == 0 && lvl_elems[tk.mode == 1 ? 1 : 0][p.owner][p.depth] <= hp.knobs.tiny_level_elems;
+        }
         if (2 * tiny > hp.tasks.size())
             for (JtTask &tk : hp.tasks) tk.settle = 1;
     }
