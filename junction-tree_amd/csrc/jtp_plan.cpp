@@ -646,7 +646,7 @@ int PlanBuilder::read_description() {
         // Bit order: "epilogue first" (3) measured 2x faster than "traffic first" (2) on the width-20 tree (fewer
         // epilogues per row; its sub-boxes still fit the 4 KiB regions).  jtp_plan_create falls back to 2 - the
         // smallest sub-boxes - when a clique's sub-boxes do not fit one evidence set's LDS region under 3.
-        if (hp.layout_policy == 0 && !getenv("JTP_MULTISET_SEARCH")) hp.layout_policy = 3;
+        if (hp.layout_policy == 0) hp.layout_policy = 3;
     }
     hp.VEC = d->dtype == JTP_F32 ? 4 : 2;
     hp.EB = d->dtype == JTP_F32 ? 2 : 1;
@@ -1042,7 +1042,7 @@ int PlanBuilder::layouts() {
             policy = (r >= thr || (p.children.size() <= 1 && r >= 0.01)) ? 2 : 3;
             // where the messages weigh that much: search the thread part with the cost model (multi-set plans keep
             // the heuristic: their sub-boxes have a hard per-set budget that the model does not know)
-            if ((policy == 2 || hp.knobs.search_all) && (!hp.multiset || getenv("JTP_MULTISET_SEARCH")) && !hp.knobs.no_search) policy = 4;
+            if ((policy == 2 || hp.knobs.search_all) && !hp.multiset && !hp.knobs.no_search) policy = 4;
         }
         if (policy == 4 && (seps.empty() || !searched_order(c, host, seps, order))) policy = 2, order.clear();
         p.layout = policy;
