@@ -1203,9 +1203,10 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     // entry is read per element, four reads; otherwise one read per message serves the four elements).
     // The choice is made once per workgroup, outside the loop: inside, a step has no branch at all, so the
     // LDS reads of one evidence set are in flight while the previous set's products are formed.
-    auto step = [&](auto slot_tag, auto edep_tag, const int i) {
+    auto step = [&](auto slot_tag, auto edep_tag, auto rowev_tag, const int i) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr bool EDEP = decltype(edep_tag)::value;
+        constexpr bool ROWEV = decltype(rowev_tag)::value;      // some set of the group observes a variable on the row bits
         constexpr int NV = EDEP ? VEC : 1;
         jt_wait_vmcnt<U - 1>();
         const VT v = *reinterpret_cast<const VT *>(ring + SLOT * 1024);
@@ -1223,12 +1224,13 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
             jt_dma16((xnext == JT_NO_ROW || !chunk_ok) ? zero_row : psi + (xF + xnext),
                      __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
         }
-        uint32_t xrow = bk.lxF;                             // LOGICAL index of the row (uniform): chunk + loop bits
-        if (has_row_ev) {
+        uint32_t rowok = 0xffffffffu;                       // bit s: the row agrees with set s
+        if constexpr (ROWEV) {
+            uint32_t xrow = bk.lxF;                         // LOGICAL index of the row (uniform): chunk + loop bits
 #pragma unroll
             for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) xrow += (((uint32_t)i >> t) & 1u) << loop_pos[t];
+            rowok = (uint32_t)__ballot(((xrow ^ row_v) & row_m) == 0);
         }
-        const uint32_t rowok = (uint32_t)__ballot(((xrow ^ row_v) & row_m) == 0);         // bit s: the row agrees with set s
         // byte offsets (inside a set's region) of this thread's entries of every incoming message
         int ad[NIN > 0 ? NIN : 1][NV];
 #pragma unroll
@@ -1258,26 +1260,45 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
             psum = p[0] + p[1];
             if constexpr (VEC == 4) psum += p[2] + p[3];
         }
-        // (the explicit look-ahead only where it is cheap in registers: one entry per message and set)
-        double cur[NIN > 0 ? NIN : 1][NV], nxt[NIN > 0 ? NIN : 1][NV];
-        if constexpr (!EDEP) load_set(0, cur);
+        if constexpr (!EDEP) {
+            // No message depends on the element bits: one entry per message and set, so the entries of ALL eight sets
+            // are requested at once (16 LDS reads in flight for two messages; a look-ahead of one set left every
+            // set's products waiting a full LDS latency: 0.57 us per row with three waves per SIMD to hide it) and
+            // ONE product of a set's entries serves the four elements (NIN multiplications + VEC fused multiply-adds
+            // per set and row; with ESUM one).
+            double all[G][NIN > 0 ? NIN : 1];
 #pragma unroll
-        for (int s = 0; s < G; ++s) {
-            if constexpr (EDEP) load_set(s, cur);
-            else if (s + 1 < G) load_set(s + 1, nxt);
-            const double rs = ((rowok >> s) & 1u) ? 1.0 : 0.0;
-            if constexpr (!EDEP) {
-                // no message depends on the element bits: ONE product of the set's message entries serves the four
-                // elements (NIN multiplications + VEC fused multiply-adds per set and row; with ESUM one)
-                double t = rs;
+            for (int s = 0; s < G; ++s)
 #pragma unroll
-                for (int k = 0; k < NIN; ++k) t *= cur[k][0];
+                for (int k = 0; k < NIN; ++k) all[s][k] = *reinterpret_cast<const double *>(sets + s * SETB + ad[k][0]);
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                // (the factor of a row that contradicts the set's evidence is uniform: built in scalar registers it is
+                //  one more multiplication per set, not a select as well; without row evidence in the group - decided
+                //  once per workgroup - it is not there at all: 24 instead of 56 vector operations per row with two
+                //  incoming messages)
+                double t = 1.0;
+                if constexpr (ROWEV) t = __hiloint2double(__builtin_amdgcn_readfirstlane(((rowok >> s) & 1u) ? 0x3FF00000 : 0), 0);
+                if constexpr (NIN > 0 && !ROWEV) {
+                    t = all[s][0];
+#pragma unroll
+                    for (int k = 1; k < NIN; ++k) t *= all[s][k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NIN; ++k) t *= all[s][k];
+                }
                 if constexpr (ESUM) acc[s][0] = __builtin_fma(psum, t, acc[s][0]);
                 else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) acc[s][e] = __builtin_fma(p[e], t, acc[s][e]);
                 }
-            } else {
+            }
+        } else {
+            double cur[NIN > 0 ? NIN : 1][NV];
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                load_set(s, cur);
+                const double rs = __hiloint2double(__builtin_amdgcn_readfirstlane(((rowok >> s) & 1u) ? 0x3FF00000 : 0), 0);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     double w = p[e];
@@ -1285,10 +1306,6 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
                     for (int k = 0; k < NIN; ++k) w *= cur[k][e];
                     acc[s][e] = __builtin_fma(w, rs, acc[s][e]);
                 }
-            }
-            if constexpr (!EDEP) {
-#pragma unroll
-                for (int k = 0; k < NIN; ++k) cur[k][0] = nxt[k][0];
             }
         }
         if ((i & rmask) == rmask) epilogue(__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], i));
@@ -1299,27 +1316,25 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     bool any_edep = false;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) any_edep = any_edep || in_edep[k] != 0;
-    if constexpr (ESUM) {                               // (the planner sets JtTask::esum only where no message has element bits)
+    auto loop = [&](auto edep_tag, auto rowev_tag) {
         for (int i0 = 0; i0 < total; i0 += U) {
-            step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, i0);
-            step(integral_constant<int, 1>{}, integral_constant<bool, false>{}, i0 + 1);
-            step(integral_constant<int, 2>{}, integral_constant<bool, false>{}, i0 + 2);
-            step(integral_constant<int, 3>{}, integral_constant<bool, false>{}, i0 + 3);
+            step(integral_constant<int, 0>{}, edep_tag, rowev_tag, i0);
+            step(integral_constant<int, 1>{}, edep_tag, rowev_tag, i0 + 1);
+            step(integral_constant<int, 2>{}, edep_tag, rowev_tag, i0 + 2);
+            step(integral_constant<int, 3>{}, edep_tag, rowev_tag, i0 + 3);
         }
-    } else if (any_edep) {
-        for (int i0 = 0; i0 < total; i0 += U) {
-            step(integral_constant<int, 0>{}, integral_constant<bool, true>{}, i0);
-            step(integral_constant<int, 1>{}, integral_constant<bool, true>{}, i0 + 1);
-            step(integral_constant<int, 2>{}, integral_constant<bool, true>{}, i0 + 2);
-            step(integral_constant<int, 3>{}, integral_constant<bool, true>{}, i0 + 3);
+    };
+    // (ESUM: the planner sets JtTask::esum only where no message has element bits)
+    bool plain = true;
+    if constexpr (!ESUM) {
+        if (any_edep) {
+            loop(integral_constant<bool, true>{}, integral_constant<bool, true>{});
+            plain = false;
         }
-    } else {
-        for (int i0 = 0; i0 < total; i0 += U) {
-            step(integral_constant<int, 0>{}, integral_constant<bool, false>{}, i0);
-            step(integral_constant<int, 1>{}, integral_constant<bool, false>{}, i0 + 1);
-            step(integral_constant<int, 2>{}, integral_constant<bool, false>{}, i0 + 2);
-            step(integral_constant<int, 3>{}, integral_constant<bool, false>{}, i0 + 3);
-        }
+    }
+    if (plain) {
+        if (has_row_ev) loop(integral_constant<bool, false>{}, integral_constant<bool, true>{});
+        else loop(integral_constant<bool, false>{}, integral_constant<bool, false>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the ring's last (repeated) loads land before LDS is given back
     stamp[4] = __builtin_amdgcn_s_memrealtime();

@@ -1,0 +1,43 @@
+"""Diagnostic: JTP_DEBUG=2 python tools/timeline.py [multi SETS | single] -> what the resident workgroups of a dataflow
+launch are doing over time (10 us bins): staging / waiting for producers, looping, flushing; per phase."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
+from junctiontree_amd import _capi, engine, synthetic
+spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+multi = len(sys.argv) > 1 and sys.argv[1] == "multi"
+plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", multiset=multi, n_batch=int(sys.argv[2]) if multi else 1)
+plan.fill_synthetic(1, spec["scales"])
+for _ in range(3):
+    plan.propagate()
+d = plan.describe()
+base, nb = d["dbg_base"], d["n_blocks"]
+buf = np.empty(nb * 8)
+_capi.check(plan._lib.jtp_debug_read_msg(plan._handle, 0, base, nb * 8, buf.ctypes.data_as(C.POINTER(C.c_double))))
+st = buf.reshape(nb, 8)[:, :6] * 0.01
+kind = np.array([d["tasks"][b[0]]["kind"] for b in d["blocks"]])
+BIN = 10.0
+for ph in (0, 1):
+    Ls = [L for L in d["launches"] if L["phase"] == ph]
+    lo, hi = min(L["blk_off"] for L in Ls), max(L["blk_off"] + L["nblocks"] for L in Ls)
+    s, k = st[lo:hi], kind[lo:hi]
+    ok = (k == 0) & (s[:, 5] > 0)
+    t0 = s[ok, 0].min()
+    s = s - t0
+    end = s[ok, 5].max()
+    level = np.zeros(hi - lo, dtype=int)
+    for L in Ls:
+        level[L["blk_off"] - lo:L["blk_off"] - lo + L["nblocks"]] = L["level"]
+    print("phase %d: %d pass blocks, %d reduce blocks, span %.0f us" % (ph, ok.sum(), (k != 0).sum(), end))
+    print("   t(us)  resident  staging/waiting  looping  flushing | levels looping")
+    for b in range(int(end / BIN) + 1):
+        a, z = b * BIN, (b + 1) * BIN
+        def overlap(x0, x1):
+            return np.clip(np.minimum(x1, z) - np.maximum(x0, a), 0, None)[ok].sum() / BIN
+        res, stg, lp, fl = overlap(s[:, 0], s[:, 5]), overlap(s[:, 0], s[:, 2]), overlap(s[:, 2], s[:, 4]), overlap(s[:, 4], s[:, 5])
+        per = {}
+        for lv in np.unique(level[ok]):
+            m = ok & (level == lv)
+            v = np.clip(np.minimum(s[m, 4], z) - np.maximum(s[m, 2], a), 0, None).sum() / BIN
+            if v >= 1: per[int(lv)] = int(v)
+        print("   %5.0f  %8.0f  %15.0f  %7.0f  %8.0f | %s" % (a, res, stg, lp, fl, per))
