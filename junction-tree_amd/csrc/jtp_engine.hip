@@ -154,7 +154,7 @@ struct KernelTable {
         }
         return nullptr;
     }
-    static fn get_flow(int phase) { return phase == 0 ? jt_collect_flow<T> : jt_distribute_flow<T>; }
+    static fn get_flow(int phase, bool chain) { return phase == 0 ? jt_collect_flow<T> : (chain ? jt_distribute_flow_chain<T> : jt_distribute_flow<T>); }
 };
 
 static const char *k_names[JT_K_COUNT] = {
@@ -240,6 +240,7 @@ struct jtp_plan {
     int prof_cursor = 0;            // propagates recorded since profiling was switched on
     bool prof_per_launch = false;   // event pair per launch instead of three per propagate
     bool flow = true;               // dataflow launches (one per phase) instead of one per level
+    bool chain = false;             // the plan is made of latency-bound levels (JtTask::settle): distribute runs the build without spills
     uint32_t *host_abort = nullptr; // pinned: set by a workgroup that gave up waiting
     int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
     bool fake_comm = false;         // JTP_FAKE_COMM
@@ -411,6 +412,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     // then idles a whole CU, and staging is a large share of the traffic, which per-level launches read
     // through L2 while a dataflow launch has to read through to memory.  Measured 39.6 vs 46.9 ms.
     if (hp.max_lds > 64 * 1024 && !pl->multiset && !hp.knobs.force_flow) pl->flow = false;
+    for (const JtTask &tk : hp.tasks) pl->chain = pl->chain || tk.settle != 0;
     if (hp.flags & JTP_PLAN_ONLY) {
         *out = pl;
         return JTP_OK;
@@ -531,7 +533,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hp.max_lds));
         }
         for (int ph = 0; ph < 2; ++ph) {
-            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph) : (const void *)KernelTable<double>::get_flow(ph);
+            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain) : (const void *)KernelTable<double>::get_flow(ph, pl->chain);
             CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hp.max_lds));
         }
     }
@@ -1052,10 +1054,10 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 fl.blk_base = (uint32_t)sg.blk_off;
                 fl.ticket_base = (bb.flow_runs - 1u) * (uint32_t)sg.nblocks;
                 if (hp.dtype == JTP_F32)
-                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase, pl->chain), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const float *)bb.psi, (float *)bb.bel, bb.msg, fl);
                 else
-                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase, pl->chain), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const double *)bb.psi, (double *)bb.bel, bb.msg, fl);
             } else if (st.kind == 0) {
                 const Launch &L = hp.launches[st.first];

@@ -886,11 +886,9 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_collect_flow(const JtTask *_
 }
 
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_flow(const JtTask *__restrict__ tasks,
-                                                                 const JtBlock *__restrict__ blk, const int *__restrict__ itab,
-                                                                 const T *__restrict__ psi, T *__restrict__ bel,
-                                                                 double *__restrict__ msg, JtFlow fl) {
-    __shared__ uint32_t flow_ctl[28];
+__device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                        const int *__restrict__ itab, const T *__restrict__ psi, T *__restrict__ bel,
+                                                        double *__restrict__ msg, const JtFlow &fl, uint32_t *flow_ctl) {
     const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
@@ -909,6 +907,28 @@ __global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_flow(const JtTask
         case 6: jt_pass<T, 3, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
         default: jt_pass<T, 4, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
     }
+}
+
+// Two builds of the distribute pass.  Compiled for four waves per SIMD (128 registers, a few spills) a CU holds four
+// workgroups instead of three and a third more table rows are in flight: config 4 0.4505 -> 0.4385 ms (A/B on one box).
+// On plans made of latency-bound levels (chains, JtTask::settle) the spills sit on the dependent path - config 2
+// 3.56 -> 3.69 ms - so those run the build without (168 registers, three waves).
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 4) void jt_distribute_flow(const JtTask *__restrict__ tasks,
+                                                                    const JtBlock *__restrict__ blk, const int *__restrict__ itab,
+                                                                    const T *__restrict__ psi, T *__restrict__ bel,
+                                                                    double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28];
+    jt_distribute_flow_body<T>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
+}
+
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_flow_chain(const JtTask *__restrict__ tasks,
+                                                                          const JtBlock *__restrict__ blk, const int *__restrict__ itab,
+                                                                          const T *__restrict__ psi, T *__restrict__ bel,
+                                                                          double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28];
+    jt_distribute_flow_body<T>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
 }
 
 // ------------------------------------------------------------------------------------------
