@@ -25,7 +25,9 @@
 #define JT_REDUCE_ENTRIES 64   // entries of a message summed by one reduce workgroup: its four waves each take a quarter of the
                                // partial copies of those entries (all loads of a wave in flight together), then the four
                                // partial sums are added in wave order
+#ifndef JT_RING_BYTES
 #define JT_RING_BYTES 16384      // LDS bytes at offset 0: per wave a ring of 4 x 1 KiB element slots (LDS-DMA)
+#endif
 #define JT_STAGE_SCRATCH 2048    // bytes of LDS for staging sums
 #define JT_MIN_ITER_LOG2 2       // a workgroup runs at least 4 loop iterations (one per ring slot)
 #define JT_MAX_ITER_LOG2 6       // a workgroup runs at most 64 loop iterations: its offset table lives in

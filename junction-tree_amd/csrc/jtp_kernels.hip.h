@@ -128,7 +128,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     constexpr int NMSG = NIN + NOUT;
     constexpr int NPAR = NIN - NOUT * (MODE == 1);   // distribute: leading inputs that are not children
     constexpr int U = JT_U;                          // element loads in flight per wave
-    static_assert(U == 4 && (1 << JT_MIN_ITER_LOG2) == U, "the loop groups below are written out for four slots");
+    static_assert((U == 4 || U == 8) && (1 << JT_MIN_ITER_LOG2) == 4 && JT_RING_BYTES == U * 4096, "the loop groups below are written out for four or eight slots");
     using VT = typename JtVec<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -624,12 +624,26 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         step(integral_constant<int, 1>{}, integral_constant<int, U - 1 + 1 * ST>{}, 1);
         step(integral_constant<int, 2>{}, integral_constant<int, U - 1 + 2 * ST>{}, 2);
         step(integral_constant<int, 3>{}, integral_constant<int, U - 1 + 3 * ST>{}, 3);
+        if constexpr (U == 8) {
+            if (total > 4) {          // (a workgroup of four iterations: the other four slots hold repeats of its last row)
+                step(integral_constant<int, 4 % U>{}, integral_constant<int, U - 1 + 4 * ST>{}, 4);
+                step(integral_constant<int, 5 % U>{}, integral_constant<int, U - 1 + 5 * ST>{}, 5);
+                step(integral_constant<int, 6 % U>{}, integral_constant<int, U - 1 + 6 * ST>{}, 6);
+                step(integral_constant<int, 7 % U>{}, integral_constant<int, U - 1 + 7 * ST>{}, 7);
+            }
+        }
     }
     for (int i0 = U; i0 < total; i0 += U) {
         step(integral_constant<int, 0>{}, integral_constant<int, U - 1 + U * ST>{}, i0);
         step(integral_constant<int, 1>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 1);
         step(integral_constant<int, 2>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 2);
         step(integral_constant<int, 3>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 3);
+        if constexpr (U == 8) {
+            step(integral_constant<int, 4 % U>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 4);
+            step(integral_constant<int, 5 % U>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 5);
+            step(integral_constant<int, 6 % U>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 6);
+            step(integral_constant<int, 7 % U>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 7);
+        }
     }
     if (dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp[4] = __builtin_amdgcn_s_memrealtime();
