@@ -95,13 +95,13 @@ void order_a_bits(std::vector<int> &Ab, const std::vector<uint32_t> &outs) {
 
 struct CostK {               // constants of the model (JTP_COST_* environment overrides are experiments only)
     double wg = 1.5, stage_fix = 5.0, stage_bw = 4096.0, iter_c = 0.45, iter_d = 0.55, epi = 0.5, wave = 1.5, lane = 0.1,
-           flush_fix = 1.0, flush_bw = 16384.0, bw = 5.0e6, red_fix = 4.0, red_bw = 3.0e6, overlap = 0.5, max_cu = 3;
+           flush_fix = 1.0, flush_bw = 16384.0, bw = 5.0e6, red_fix = 4.0, red_bw = 3.0e6, overlap = 0.5, max_cu = 3, lds_cap = 150.0 * 1024;
     CostK() {
         auto g = [](const char *n, double &v) { if (const char *e = getenv(n)) v = atof(e); };
         g("JTP_COST_WG", wg), g("JTP_COST_STAGE_FIX", stage_fix), g("JTP_COST_STAGE_BW", stage_bw), g("JTP_COST_ITER_C", iter_c);
         g("JTP_COST_ITER_D", iter_d), g("JTP_COST_EPI", epi), g("JTP_COST_WAVE", wave), g("JTP_COST_LANE", lane);
         g("JTP_COST_FLUSH_FIX", flush_fix), g("JTP_COST_FLUSH_BW", flush_bw), g("JTP_COST_BW", bw), g("JTP_COST_RED_FIX", red_fix);
-        g("JTP_COST_RED_BW", red_bw), g("JTP_COST_OVERLAP", overlap), g("JTP_COST_MAX_CU", max_cu);
+        g("JTP_COST_RED_BW", red_bw), g("JTP_COST_OVERLAP", overlap), g("JTP_COST_MAX_CU", max_cu), g("JTP_COST_LDS_CAP", lds_cap);
     }
 };
 const CostK &cost_k() {
@@ -164,7 +164,7 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
         }
         epi += std::ldexp(K.epi * (1.0 + K.wave * popc(~o & wave_bits)) + K.lane * popc(~o & lane_bits), nL - run);
     }
-    if (lds > e.lds_cap) return 1e30;
+    if (lds > e.lds_cap || lds > (long)K.lds_cap) return 1e30;
     if (lds_out) *lds_out = lds;
     const double epilogues = 1.0;          // (epi already holds every message's epilogues of the whole loop)
     // (start-up, staging and flush are latency chains: record -> addresses -> message loads -> LDS -> barrier cost
