@@ -181,6 +181,7 @@ def test_refsafe_synthetic_trees_f64_and_f32(golden):
     {"split_variants": True}, {"split_variants": True, "block_log2": 10}, {"keep_root": True},
     {"level_launches": True}, {"level_launches": True, "block_log2": 10, "lds_budget": 256},
     {"layout_policy": 2}, {"layout_policy": 3}, {"layout_policy": 2, "block_log2": 10, "level_launches": True},
+    {"layout_policy": 4, "block_log2": 10}, {"layout_policy": 4, "lds_budget": 2048}, {"layout_policy": 4, "lds_budget": 128, "block_log2": 11, "level_launches": True},
 ])
 def test_planner_options_do_not_change_results(opts):
     specs = [

@@ -76,6 +76,7 @@ def test_divergent_cases(golden):
     {}, {"block_log2": 10}, {"block_log2": 11, "lds_budget": 256}, {"layout_policy": 1},
     {"layout_policy": 1, "block_log2": 10, "lds_budget": 128}, {"keep_root": True},
     {"layout_policy": 2}, {"layout_policy": 3, "block_log2": 11}, {"layout_policy": 2, "block_log2": 10, "lds_budget": 256},
+    {"layout_policy": 4, "block_log2": 10}, {"layout_policy": 4, "lds_budget": 2048}, {"layout_policy": 4, "lds_budget": 128, "block_log2": 11},
 ])
 def test_synthetic_trees(opts):
     specs = [
