@@ -95,7 +95,7 @@ void order_a_bits(std::vector<int> &Ab, const std::vector<uint32_t> &outs) {
 
 struct CostK {               // constants of the model (JTP_COST_* environment overrides are experiments only)
     double wg = 1.5, stage_fix = 5.0, stage_bw = 4096.0, iter_c = 0.45, iter_d = 0.55, epi = 0.5, wave = 1.5, lane = 0.1,
-           flush_fix = 1.0, flush_bw = 16384.0, bw = 5.0e6, red_fix = 4.0, red_bw = 3.0e6, overlap = 0.5, max_cu = 3, lds_cap = 150.0 * 1024;
+           flush_fix = 1.0, flush_bw = 16384.0, bw = 5.0e6, red_fix = 4.0, red_bw = 3.0e6, overlap = 0.5, max_cu = 4, lds_cap = 150.0 * 1024;
     CostK() {
         auto g = [](const char *n, double &v) { if (const char *e = getenv(n)) v = atof(e); };
         g("JTP_COST_WG", wg), g("JTP_COST_STAGE_FIX", stage_fix), g("JTP_COST_STAGE_BW", stage_bw), g("JTP_COST_ITER_C", iter_c);
@@ -171,8 +171,8 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
     //  6-7 us even for a few KiB)
     const double t_wg = K.wg + (ins.empty() ? 0.0 : K.stage_fix) + stage / K.stage_bw + iters * (e.dist ? K.iter_d : K.iter_c) + epilogues * epi +
                         (outs.empty() ? 0.0 : K.flush_fix) + flush / K.flush_bw;
-    // (workgroups a CU holds: LDS, and the kernels' registers - four waves per SIMD in collect, three in distribute)
-    const int per_cu = (int)std::min((long)K.max_cu + (e.dist ? 0 : 1), std::max(1L, 160L * 1024 / lds));
+    // (workgroups a CU holds: LDS, and the kernels' registers - four waves per SIMD)
+    const int per_cu = (int)std::min((long)K.max_cu, std::max(1L, 160L * 1024 / (lds + 128)));
     const double conc = std::max(1.0, 256.0 * per_cu * e.share);
     const double t_lat = std::max(t_wg, nwg * t_wg / conc);
     const double bytes = nwg * (iters * 4096.0 * (e.dist ? 2.0 : 1.0) + 0.5 * stage + flush);
