@@ -116,6 +116,8 @@ struct CostEnv {
     double share = 1.0;          // part of the chip this clique can count on (its share of the level's elements)
     double fill = 1.0;           // rows that exist / rows of the index space (variables stored at their true cardinality)
     long lds_cap = 150 * 1024;
+    int red_log2 = 6;            // partial copies from 2^red_log2 on are summed by a reduce task, fewer by the consumers
+    bool chain = false;          // latency-bound plan: a consumer that waits for several producers pays a staging attempt each
     std::vector<uint32_t> units; // atomic groups of bits above the thread part (a compact variable stays together)
 };
 
@@ -151,9 +153,12 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
         flush += 8.0 * (double)(1L << fb);
         const int np = popc(F & ~o);
         if (np > 6) return 1e30;
-        if (np) {
+        if (np >= e.red_log2) {               // many partial copies: a reduce task sums them once
             red_bytes += (std::ldexp(1.0, np) + 1.0) * 8.0 * std::ldexp(1.0, popc(o));
             ++n_red;
+        } else if (np) {                      // fewer: the consumers sum the copies while they stage
+            red_bytes += std::ldexp(1.0, np) * 8.0 * std::ldexp(1.0, popc(o));
+            if (e.chain) ++n_red;             // (on a chain that wait is on the critical path: priced like the reduce hop)
         }
         // an epilogue folds the register sums into the sub-box: butterflies over summed lane bits, one ordered
         // phase (barriers) per summed wave bit; it follows every run of iterations whose loop bits the message lacks
@@ -179,7 +184,8 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
     // (neither bound hides the other completely: a workgroup's start-up and epilogues issue no loads)
     const double t_bw = bytes / (K.bw * e.share);
     double t = std::max(t_lat, t_bw) + K.overlap * std::min(t_lat, t_bw);
-    if (n_red) t += K.red_fix + red_bytes / (K.red_bw * e.share);
+    if (n_red) t += K.red_fix;
+    t += red_bytes / (K.red_bw * e.share);
     return t;
 }
 
@@ -300,6 +306,8 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         // searched split (cost model above): every loop set the iteration cap allows
         CostEnv e;
         e.TB = TB, e.EB = hp.EB, e.nbits = nbits, e.dist = tk.mode == 1, e.share = share;
+        e.red_log2 = hp.knobs.reduce_min >= 0 ? std::max(0, ceil_log2(std::max(hp.knobs.reduce_min, 1))) : (hp.chain_plan ? 3 : 6);
+        e.chain = hp.chain_plan;
         e.max_iter_log2 = std::min(std::max(block_log2 - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
         if (hp.lds_budget > 0) e.lds_cap = JT_RING_BYTES + hp.lds_budget + JT_STAGE_SCRATCH * (long)ins.size();
         uint32_t seen = 0;
@@ -906,6 +914,8 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
         for (int i : idx) pos[i] = bit, bit += hp.vbits[host[i]];
         CostEnv e;
         e.TB = TB, e.EB = hp.EB, e.nbits = std::max(bit, TB + JT_MIN_ITER_LOG2);
+        e.red_log2 = hp.knobs.reduce_min >= 0 ? std::max(0, ceil_log2(std::max(hp.knobs.reduce_min, 1))) : (hp.chain_plan ? 3 : 6);
+        e.chain = hp.chain_plan;
         uint32_t grouped = 0;
         for (int i : idx) {
             const int card = hp.card[host[i]], nb = hp.vbits[host[i]];
@@ -1011,6 +1021,11 @@ int PlanBuilder::layouts() {
         const double e = std::ldexp(1.0, std::max(cb, hp.TB + JT_MIN_ITER_LOG2));
         if (c != hp.root) lvl_elems[0][p.owner][p.depth] += e;
         lvl_elems[1][p.owner][p.depth] += e;
+    }
+    {
+        int tiny = 0;
+        for (int c = 0; c < NP; ++c) tiny += lvl_elems[1][hp.pn[c].owner][hp.pn[c].depth] <= hp.knobs.tiny_level_elems;
+        hp.chain_plan = 2 * tiny > NP;
     }
     for (int c = 0; c < NP; ++c) {
         PNode &p = hp.pn[c];
@@ -1370,21 +1385,18 @@ int PlanBuilder::make_tasks() {
 }
 
 int PlanBuilder::messages() {
-    {   // plans whose tasks mostly sit on latency-bound levels - a clique or two - (chains): settle in place
-        size_t tiny = 0;
-        for (const JtTask &tk : hp.tasks) {
-            const PNode &p = hp.pn[tk.pnode];
-            tiny += tk.kind == 0 && lvl_elems[tk.mode == 1 ? 1 : 0][p.owner][p.depth] <= hp.knobs.tiny_level_elems;
-        }
-        if (2 * tiny > hp.tasks.size())
-            for (JtTask &tk : hp.tasks) tk.settle = 1;
-    }
+    // plans whose cliques mostly sit on latency-bound levels - a clique or two - (chains): settle in place
+    if (hp.chain_plan)
+        for (JtTask &tk : hp.tasks) tk.settle = 1;
     // ---- message arena ----------------------------------------------------------------------
     // A message written as many partial copies costs every consuming workgroup (sub-box x copies)
     // loads before it can start, on the critical path of the small levels near the root.  From
     // `red_min` copies on, a reduce task behind the producer sums them once and consumers read the sum.
     // (multi-set plans: 2 and 8 measured within 4 % of each other on the width-20 tree, 8 ahead)
-    const int red_min = hp.knobs.reduce_min >= 0 ? hp.knobs.reduce_min : 8;
+    // Single-set plans (round 2, with eight entry loads in flight per staging thread): only messages of 64 copies get a
+    // reduce task - config 3 13.3 -> 12.8 ms, config 4 within noise for any threshold from 8 up.
+    // Chains keep 8: there a reduce task between two levels beats every consumer summing eight copies (config 2 6.5 against 6.85 ms).
+    const int red_min = hp.knobs.reduce_min >= 0 ? hp.knobs.reduce_min : (hp.multiset || hp.chain_plan ? 8 : 64);
     hp.msg_doubles = 0;
     for (auto &s : hp.ps) {
         if (!mine(s.child) && !mine(s.parent)) continue;

@@ -142,6 +142,7 @@ struct HostPlan {
     int64_t msg_doubles = 0;
     int64_t dbg_base = -1;           // JTP_DEBUG & 2: time-stamp region inside the message arena
     int max_lds = 0;
+    bool chain_plan = false;     // most cliques sit on levels of a clique or two: a chain of hand-overs (latency bound)
     double alg_bytes = 0;
     // multi-set plans: algorithmic bytes of one pass over the tables (once per GROUP of JT_MSETS evidence sets)
     // and of one set's messages (once per set); alg_bytes = table + msg (one group of one set)

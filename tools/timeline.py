@@ -4,9 +4,24 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
 from junctiontree_amd import _capi, engine, synthetic
-spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
 multi = len(sys.argv) > 1 and sys.argv[1] == "multi"
-plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", multiset=multi, n_batch=int(sys.argv[2]) if multi else 1)
+if len(sys.argv) > 1 and sys.argv[1] == "c3":          # BASELINE config 3, shortened: 6 x W lattice, cardinality 8
+    import junctiontree_amd as jt
+    H, W, K = 6, int(sys.argv[2]) if len(sys.argv) > 2 else 40, 8
+    names = {(i, j): i * W + j for i in range(H) for j in range(W)}
+    factors = []
+    for i in range(H):
+        for j in range(W):
+            if i + 1 < H: factors.append([names[i, j], names[i + 1, j]])
+            if j + 1 < W: factors.append([names[i, j], names[i, j + 1]])
+    sizes = {v: K for v in names.values()}
+    tree = jt.create_junction_tree(factors, sizes)
+    node_vars = [list(c) for c in tree.clique_tree.maxcliques] + [list(s) for s in tree.separators]
+    plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32")
+    spec = {"scales": [8.0 ** -(len(c) - 1) for c in tree.clique_tree.maxcliques]}
+else:
+    spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", multiset=multi, n_batch=int(sys.argv[2]) if multi else 1)
 plan.fill_synthetic(1, spec["scales"])
 for _ in range(3):
     plan.propagate()
@@ -16,7 +31,7 @@ buf = np.empty(nb * 8)
 _capi.check(plan._lib.jtp_debug_read_msg(plan._handle, 0, base, nb * 8, buf.ctypes.data_as(C.POINTER(C.c_double))))
 st = buf.reshape(nb, 8)[:, :6] * 0.01
 kind = np.array([d["tasks"][b[0]]["kind"] for b in d["blocks"]])
-BIN = 10.0
+BIN = float(os.environ.get("TIMELINE_BIN", "10"))
 for ph in (0, 1):
     Ls = [L for L in d["launches"] if L["phase"] == ph]
     lo, hi = min(L["blk_off"] for L in Ls), max(L["blk_off"] + L["nblocks"] for L in Ls)
