@@ -622,8 +622,11 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     {
         step(integral_constant<int, 0>{}, integral_constant<int, U - 1 + 0 * ST>{}, 0);
         step(integral_constant<int, 1>{}, integral_constant<int, U - 1 + 1 * ST>{}, 1);
-        step(integral_constant<int, 2>{}, integral_constant<int, U - 1 + 2 * ST>{}, 2);
-        step(integral_constant<int, 3>{}, integral_constant<int, U - 1 + 3 * ST>{}, 3);
+        if (total > 2) {              // (a workgroup of two iterations - searched splits on latency-bound levels: the
+                                      //  other slots hold repeats of its last row)
+            step(integral_constant<int, 2>{}, integral_constant<int, U - 1 + 2 * ST>{}, 2);
+            step(integral_constant<int, 3>{}, integral_constant<int, U - 1 + 3 * ST>{}, 3);
+        }
         if constexpr (U == 8) {
             if (total > 4) {          // (a workgroup of four iterations: the other four slots hold repeats of its last row)
                 step(integral_constant<int, 4 % U>{}, integral_constant<int, U - 1 + 4 * ST>{}, 4);

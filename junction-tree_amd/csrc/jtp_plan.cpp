@@ -127,7 +127,7 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
     const uint32_t himask = (e.nbits >= 32 ? ~0u : ((1u << e.nbits) - 1u)) & ~tmask;
     const uint32_t F = himask & ~L, cover = tmask | L;
     const int nL = popc(L);
-    if (nL < JT_MIN_ITER_LOG2 || nL > e.max_iter_log2 || popc(F) > JT_MAX_HI) return 1e30;
+    if (nL < JT_MIN_LOOP_LOG2 || nL > e.max_iter_log2 || popc(F) > JT_MAX_HI) return 1e30;
     const double nwg = std::max(1.0, std::ldexp(e.fill, popc(F))), iters = std::ldexp(1.0, nL);
     long lds = JT_RING_BYTES;
     double stage = 0, flush = 0, red_bytes = 0, epi = 0;
@@ -227,7 +227,7 @@ LoopChoice search_loops(const CostEnv &e, const std::vector<uint32_t> &ins, cons
             double pick_us = 1e31;
             for (int i = 0; i < n; ++i) {
                 if ((L & e.units[i]) || popc(L | e.units[i]) > e.max_iter_log2) continue;
-                const double us = popc(L | e.units[i]) < JT_MIN_ITER_LOG2 ? 1e30 : consider(L | e.units[i]);
+                const double us = popc(L | e.units[i]) < JT_MIN_LOOP_LOG2 ? 1e30 : consider(L | e.units[i]);
                 // (below four iterations nothing can be priced: take the unit the fewest messages contain)
                 double key = us;
                 if (us >= 1e30) {

@@ -196,7 +196,7 @@ class Emulator:
             assert bool(m["e_dep"]) == any(m["e_w"][e] != 0 for e in range(EB))
 
         itab = np.asarray(tk["itab"], dtype=np.int64).reshape(nA, nR, 8)      # row i = a * nR + r
-        assert tk["total"] == nA * nR and 4 <= tk["total"] <= 64
+        assert tk["total"] == nA * nR and 2 <= tk["total"] <= 64
         xoff = itab[:, :, 0] & 0xFFFFFFFF
         for i in range(8):
             assert tk["first_x"][i] == (xoff.ravel()[i] if i < tk["total"] else 0)
