@@ -30,7 +30,9 @@
 #endif
 #define JT_STAGE_SCRATCH 2048    // bytes of LDS for staging sums
 #define JT_MIN_ITER_LOG2 2       // a clique table is padded to at least 4 rows; the heuristic splits keep >= 4 loop iterations per workgroup
+#ifndef JT_MIN_LOOP_LOG2
 #define JT_MIN_LOOP_LOG2 1       // the searched splits (layout policy 4) may go down to 2 iterations (the other ring slots load repeats)
+#endif
 #define JT_MAX_ITER_LOG2 6       // a workgroup runs at most 64 loop iterations: its offset table lives in
                                  // registers, row r in lane r
 #define JT_SYNC_ABORT 0        // dataflow launches, per evidence set: word 0 = abort flag, then one ticket
