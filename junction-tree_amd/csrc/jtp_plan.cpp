@@ -118,6 +118,8 @@ struct CostEnv {
     long lds_cap = 150 * 1024;
     int red_log2 = 6;            // partial copies from 2^red_log2 on are summed by a reduce task, fewer by the consumers
     bool chain = false;          // latency-bound plan: a consumer that waits for several producers pays a staging attempt each
+    int min_loop_log2 = JT_MIN_ITER_LOG2;   // chains: JT_MIN_LOOP_LOG2 (two-iteration workgroups: config 2 6.46 -> 5.75 ms; at the top
+                                            // of a tree they cost 3 %: an 8-rank share of config 4 205 -> 212 us)
     std::vector<uint32_t> units; // atomic groups of bits above the thread part (a compact variable stays together)
 };
 
@@ -127,7 +129,7 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
     const uint32_t himask = (e.nbits >= 32 ? ~0u : ((1u << e.nbits) - 1u)) & ~tmask;
     const uint32_t F = himask & ~L, cover = tmask | L;
     const int nL = popc(L);
-    if (nL < JT_MIN_LOOP_LOG2 || nL > e.max_iter_log2 || popc(F) > JT_MAX_HI) return 1e30;
+    if (nL < e.min_loop_log2 || nL > e.max_iter_log2 || popc(F) > JT_MAX_HI) return 1e30;
     const double nwg = std::max(1.0, std::ldexp(e.fill, popc(F))), iters = std::ldexp(1.0, nL);
     long lds = JT_RING_BYTES;
     double stage = 0, flush = 0, red_bytes = 0, epi = 0;
@@ -227,7 +229,7 @@ LoopChoice search_loops(const CostEnv &e, const std::vector<uint32_t> &ins, cons
             double pick_us = 1e31;
             for (int i = 0; i < n; ++i) {
                 if ((L & e.units[i]) || popc(L | e.units[i]) > e.max_iter_log2) continue;
-                const double us = popc(L | e.units[i]) < JT_MIN_LOOP_LOG2 ? 1e30 : consider(L | e.units[i]);
+                const double us = popc(L | e.units[i]) < e.min_loop_log2 ? 1e30 : consider(L | e.units[i]);
                 // (below four iterations nothing can be priced: take the unit the fewest messages contain)
                 double key = us;
                 if (us >= 1e30) {
@@ -308,6 +310,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         e.TB = TB, e.EB = hp.EB, e.nbits = nbits, e.dist = tk.mode == 1, e.share = share;
         e.red_log2 = hp.knobs.reduce_min >= 0 ? std::max(0, ceil_log2(std::max(hp.knobs.reduce_min, 1))) : (hp.chain_plan ? 3 : 6);
         e.chain = hp.chain_plan;
+        e.min_loop_log2 = hp.chain_plan ? JT_MIN_LOOP_LOG2 : JT_MIN_ITER_LOG2;
         e.max_iter_log2 = std::min(std::max(block_log2 - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
         if (hp.lds_budget > 0) e.lds_cap = JT_RING_BYTES + hp.lds_budget + JT_STAGE_SCRATCH * (long)ins.size();
         uint32_t seen = 0;
@@ -916,6 +919,7 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
         e.TB = TB, e.EB = hp.EB, e.nbits = std::max(bit, TB + JT_MIN_ITER_LOG2);
         e.red_log2 = hp.knobs.reduce_min >= 0 ? std::max(0, ceil_log2(std::max(hp.knobs.reduce_min, 1))) : (hp.chain_plan ? 3 : 6);
         e.chain = hp.chain_plan;
+        e.min_loop_log2 = hp.chain_plan ? JT_MIN_LOOP_LOG2 : JT_MIN_ITER_LOG2;
         uint32_t grouped = 0;
         for (int i : idx) {
             const int card = hp.card[host[i]], nb = hp.vbits[host[i]];
