@@ -551,6 +551,7 @@ PlanKnobs jtp_read_knobs() {
     k.target_blocks_d = getd("JTP_TARGET_BLOCKS_D", k.target_blocks_c);
     k.min_block_log2 = geti("JTP_MIN_BLOCK_LOG2", 13);
     k.max_block_log2 = geti("JTP_MAX_BLOCK_LOG2", 16);
+    k.max_block_log2_d = geti("JTP_MAX_BLOCK_LOG2_D", std::min(k.max_block_log2, 15));
     k.tiny_level_elems = getd("JTP_TINY_LEVEL_ELEMS", 2097152.0);
     k.force_level_launches = geti("JTP_FORCE_LEVEL_LAUNCHES", 0);
     k.force_flow = geti("JTP_FORCE_FLOW", 0);
@@ -613,7 +614,10 @@ int PlanBuilder::block_log2_for(int phase, int level, int owner, bool tiny_rule)
         // the next level fills the tail), each streaming 16 KiB .. 256 KiB.  Measured on C4: 1024 is
         // 2-3 % faster than 2048 (which was best with one launch per level), 512 and 4096 slower.
         const double target = phase == 0 ? hp.knobs.target_blocks_c : hp.knobs.target_blocks_d;
-        const int lgmin = hp.knobs.min_block_log2, lgmax = hp.knobs.max_block_log2;
+        // (the distribute pass - read + write - streams best in workgroups of at most 32 rows: config 4 0.4345 -> 0.4300 ms,
+        //  the collect pass in up to 64: 0.2055 against 0.2084 ms; multi-set plans - whose second phase is marginalisations,
+        //  not a read + write pass - keep 64: 1.058 against 1.074 ms)
+        const int lgmin = hp.knobs.min_block_log2, lgmax = phase == 1 && !hp.multiset ? hp.knobs.max_block_log2_d : hp.knobs.max_block_log2;
         // levels of a clique or two are latency bound: 4 iterations per workgroup, so that every element
         // load is already in flight while the workgroup waits for its messages
         const double tiny = hp.knobs.tiny_level_elems;
