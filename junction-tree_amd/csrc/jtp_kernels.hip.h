@@ -144,6 +144,25 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     T *bel = bel_arena + (MODE == 1 ? tk.bel_off : 0);   // distribute always stores (virtual cliques: scratch)
     const int total = tk.total;                       // loop iterations of this workgroup (>= U)
     const int dbg = tk.debug;
+    // What staging needs from the task record, read HERE: the element loads below are issued by inline assembly that the
+    // compiler treats as a barrier for memory operations - left where they are used, these scalar loads would be one more
+    // dependent round trip between the workgroup's start and its message loads.
+    int64_t sm_off[NIN > 0 ? NIN : 1], sm_ps[NIN > 0 ? NIN : 1];
+    int sm_npart[NIN > 0 ? NIN : 1], sm_nfree[NIN > 0 ? NIN : 1], sm_lds[NIN > 0 ? NIN : 1];
+    bool sm_same[NIN > 0 ? NIN : 1];
+    uint32_t sm_fp[NIN > 0 ? NIN : 1][4];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const JtMsg &m = tk.msg[k];
+        const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+        sm_off[k] = m.off + bk.gbase[k];
+        sm_ps[k] = m.pstride;
+        sm_npart[k] = m.npart;
+        sm_nfree[k] = m.nfree;
+        sm_lds[k] = m.lds_off;
+        sm_same[k] = m.same_launch != 0;
+        sm_fp[k][0] = fpw[0], sm_fp[k][1] = fpw[1], sm_fp[k][2] = fpw[2], sm_fp[k][3] = fpw[3];
+    }
     // outgoing message j's epilogue follows every 2^run_j iterations (JtTask::out_run)
     int rmask[NOUT > 0 ? NOUT : 1];
 #pragma unroll
@@ -217,34 +236,32 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             int maxper = 0;
 #pragma unroll
             for (int k = 0; k < NIN; ++k) {
-                const JtMsg &m = tk.msg[k];
-                const int nfree = m.nfree;
-                const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
-                const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
-                src[k] = msg_cur + m.off + bk.gbase[k];
-                ps[k] = m.pstride;
+                const int nfree = sm_nfree[k];
+                const uint32_t fp[4] = {sm_fp[k][0], sm_fp[k][1], sm_fp[k][2], sm_fp[k][3]};
+                src[k] = msg_cur + sm_off[k];
+                ps[k] = sm_ps[k];
                 idx_t[k] = 0;
 #pragma unroll
                 for (int b = 0; b < 8; ++b)
                     if (b < nfree) idx_t[k] += ((tid >> b) & 1) << JT_FPOS(fp, b);
-                thr_mem[k] = m.same_launch != 0;
-                grouped[k] = nfree < 8 && m.npart > 1;
+                thr_mem[k] = sm_same[k];
+                grouped[k] = nfree < 8 && sm_npart[k] > 1;
                 psum[k] = 0.0;
                 gp0[k] = gp1[k] = 0;
                 if (grouped[k]) {
                     const int groups = JT_THREADS >> nfree;   // >= 2
-                    const int per = (m.npart + groups - 1) / groups;
+                    const int per = (sm_npart[k] + groups - 1) / groups;
                     gp0[k] = (tid >> nfree) * per;
-                    gp1[k] = (gp0[k] + per < m.npart) ? gp0[k] + per : m.npart;
+                    gp1[k] = (gp0[k] + per < sm_npart[k]) ? gp0[k] + per : sm_npart[k];
                     maxper = per > maxper ? per : maxper;
                 } else {
                     // One thread per entry and round of 256 entries, eight loads in flight per thread: eight entries
                     // of a single-copy message, else 2^plog copies of 8 >> plog entries (a sub-box of 1024 single-copy
                     // entries used to cost four dependent round trips, now one).  Every entry's copies are still
                     // summed in ascending order from 0.0.
-                    double *sub = reinterpret_cast<double *>(smem + m.lds_off);
+                    double *sub = reinterpret_cast<double *>(smem + sm_lds[k]);
                     const int n = 1 << nfree;
-                    const int npart = m.npart;
+                    const int npart = sm_npart[k];
                     auto entry_at = [&](int it, int pc) {
                         int idx = idx_t[k];
 #pragma unroll
@@ -393,13 +410,12 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     }
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
-        const JtMsg &m = tk.msg[k];
-        const int nfree = m.nfree;
-        if (nfree < 8 && m.npart > 1 && tid < (1 << nfree)) {
+        const int nfree = sm_nfree[k];
+        if (nfree < 8 && sm_npart[k] > 1 && tid < (1 << nfree)) {
             const int groups = JT_THREADS >> nfree;
             double sum = 0.0;
             for (int g = 0; g < groups; ++g) sum += scratch[k * JT_THREADS + (g << nfree) + tid];
-            reinterpret_cast<double *>(smem + m.lds_off)[tid] = sum;
+            reinterpret_cast<double *>(smem + sm_lds[k])[tid] = sum;
         }
     }
     __syncthreads();
