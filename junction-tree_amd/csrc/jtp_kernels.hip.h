@@ -163,6 +163,21 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         sm_same[k] = m.same_launch != 0;
         sm_fp[k][0] = fpw[0], sm_fp[k][1] = fpw[1], sm_fp[k][2] = fpw[2], sm_fp[k][3] = fpw[3];
     }
+    // ... and, in the collect pass, what the flush needs: read after the loop these are one more dependent round trip on
+    // the hand-over to the parent (config 2: collect 2.52 -> 2.40 ms).  Not in the distribute pass: there the registers
+    // they occupy through the loop cost more (spills) than the round trip, which hides behind the belief stores.
+    constexpr bool EARLY_OUT = MODE == 0;
+    int64_t so_at[NOUT > 0 ? NOUT : 1];
+    int so_nfree[NOUT > 0 ? NOUT : 1];
+    uint32_t so_fp[NOUT > 0 ? NOUT : 1][4];
+#pragma unroll
+    for (int j = 0; j < (EARLY_OUT ? NOUT : 0); ++j) {
+        const JtMsg &m = tk.msg[JT_MAX_IN + j];
+        const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+        so_at[j] = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+        so_nfree[j] = m.nfree;
+        so_fp[j][0] = fpw[0], so_fp[j][1] = fpw[1], so_fp[j][2] = fpw[2], so_fp[j][3] = fpw[3];
+    }
     // outgoing message j's epilogue follows every 2^run_j iterations (JtTask::out_run)
     int rmask[NOUT > 0 ? NOUT : 1];
 #pragma unroll
@@ -676,15 +691,20 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
-            const JtMsg &m = tk.msg[JT_MAX_IN + j];
-            const int64_t at = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+            if constexpr (!EARLY_OUT) {
+                const JtMsg &m = tk.msg[JT_MAX_IN + j];
+                const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+                so_at[j] = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+                so_nfree[j] = m.nfree;
+                so_fp[j][0] = fpw[0], so_fp[j][1] = fpw[1], so_fp[j][2] = fpw[2], so_fp[j][3] = fpw[3];
+            }
+            const int64_t at = so_at[j];
             double *dst = msg_arena + fl.cur_off + at + fl.out_shift;
             double *oth = msg_arena + fl.oth_off + at;          // the half the next propagate will use
             const bool mark = fl.oth_off >= 0;
-            const int nfree = m.nfree;
+            const int nfree = so_nfree[j];
             const int n = 1 << nfree;
-            const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
-            const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
+            const uint32_t fp[4] = {so_fp[j][0], so_fp[j][1], so_fp[j][2], so_fp[j][3]};
             int idx_t = 0;
 #pragma unroll
             for (int b = 0; b < 8; ++b)
