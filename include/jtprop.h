@@ -106,6 +106,11 @@ typedef struct jtp_stats {
     double  kernel_bytes[32];       /* algorithmic bytes processed per kernel variant        */
     int32_t kernel_launches[32];    /* launches per kernel variant                           */
     int32_t flow_fallbacks;         /* dataflow launches that timed out and were re-run per level (expected 0) */
+    int32_t launch_mode;            /* of the last jtp_propagate: 0 = one launch per tree level, 1 = dataflow launches in
+                                       blockIdx order (the default), 2 = dataflow launches in ticket order            */
+    int32_t tickets_used;           /* propagates (counted per evidence set) since plan creation that ran in ticket order */
+    int32_t flow_propagates;        /* propagates (per evidence set) since plan creation that ran as dataflow launches  */
+    double  device_bytes;           /* device memory the plan allocated at creation (arenas, messages, task tables)     */
 } jtp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -128,7 +133,13 @@ const char *jtp_plan_describe(jtp_plan *plan);
  * axis i: the variable's cardinality, or 1 to broadcast along it (numpy semantics the
  * reference relies on, junctiontree.py:52-61).  `host_dtype` is JTP_F32 or JTP_F64.
  * Stands in for `np.copy(p)` of computation.py:245.  Separator potentials are never
- * uploaded: the reference overwrites them before use. */
+ * uploaded: the reference overwrites them before use.
+ * LIFETIME OF `host`: the call enqueues the copy on the plan's stream and does NOT wait for it.  From pageable
+ * memory the HIP runtime has staged the caller's bytes when the call returns, so the array may be changed or freed at
+ * once.  From PAGE-LOCKED memory (jtp_host_alloc, hipHostMalloc, hipHostRegister) the copy is truly asynchronous:
+ * the caller must keep the array alive and unmodified until the next jtp_sync (or any read-out call, which
+ * synchronises the evidence set's stream) of this plan.  jtp_set_potential_product copies its tables before it
+ * returns and has no such rule. */
 int jtp_set_potential(jtp_plan *plan, int32_t batch, int32_t node, const void *host,
                       const int64_t *shape, int32_t host_dtype);
 
@@ -230,10 +241,13 @@ int jtp_comm_selftest(int32_t n);
 /* ---- misc ----------------------------------------------------------------------------- */
 
 int jtp_device_count(int32_t *count);
+/* Free and total memory of a device (hipMemGetInfo): the Python layer budgets its plan cache with it. */
+int jtp_device_memory(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* Page-locked host memory for potentials and results: copies to and from it run at PCIe speed and
  * without an intermediate buffer (a pageable numpy array reads back at ~5 GB/s, a pinned one at
- * ~50).  Nothing in the reference corresponds (it has no device). */
+ * ~50).  Nothing in the reference corresponds (it has no device).  An array from here that was handed to
+ * jtp_set_potential must stay alive and unmodified until jtp_sync (see the lifetime rule there). */
 int jtp_host_alloc(void **ptr, size_t bytes);
 int jtp_host_free(void *ptr);
 const char *jtp_last_error(void);

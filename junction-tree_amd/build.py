@@ -17,11 +17,35 @@ SOURCES = ["jtp_plan.cpp", "jtp_engine.hip"]
 DEPS = SOURCES + ["jtp_internal.h", "jtp_plan.h", "jtp_kernels.hip.h", os.path.join("..", "..", "include", "jtprop.h")]
 
 
+ID_FILE = os.path.join(LIBDIR, "BUILD_ID")
+
+
+def source_id():
+    """Digest of everything libjtprop.so is compiled from: identifies the CODE a profile was measured on
+    (jtp_version() ends in it; tools/collect_profiles.sh stamps it into the files under profiles/)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        with open(os.path.join(CSRC, d), "rb") as fh:
+            h.update(d.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
+def built_id():
+    try:
+        with open(ID_FILE) as fh:
+            return fh.read().split()[0]
+    except (OSError, IndexError):
+        return None
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    try:                       # (the sources do not travel with every copy of the tree: then the built library stands)
+        return built_id() != source_id()
+    except OSError:
+        return False
 
 
 def build(force=False, verbose=True, extra=(), out=None):
@@ -30,13 +54,25 @@ def build(force=False, verbose=True, extra=(), out=None):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    sid = source_id() + ("+" + "".join(sorted(extra)).replace(" ", "") if extra else "")
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-variable"] + list(extra)
+           "-Wall", "-Wno-unused-function", "-Wno-unused-variable", '-DJTP_SOURCE_ID="%s"' % sid] + list(extra)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", out, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if out == LIB:
+        head = "unknown"
+        try:
+            head = subprocess.check_output(["git", "-C", HERE, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+            if subprocess.check_output(["git", "-C", HERE, "status", "--porcelain", "--", CSRC, os.path.join(HERE, "..", "include")],
+                                       stderr=subprocess.DEVNULL).strip():
+                head += "+uncommitted"
+        except (OSError, subprocess.CalledProcessError):
+            pass
+        with open(ID_FILE, "w") as fh:
+            fh.write("%s\ngit %s\n" % (sid, head))
     return out
 
 

@@ -5,9 +5,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -198,14 +200,30 @@ struct MargBatch {
     }
 };
 
-// device plans alive in this process, per device: dataflow kernels of two plans running at once need
-// ticket order (see jtp_propagate)
-static int g_live_plans[64];
+// Plans with a dataflow propagate enqueued and not yet synchronised, per device: dataflow kernels of two plans running
+// at once need ticket order (see jtp_propagate).  A plan that merely EXISTS costs the others nothing (round 2 counted
+// live plans: a library user with two junction trees paid the ticket round trip - +10 % on config 4 - on every propagate).
+static std::atomic<int> g_inflight[64];
+
+// dynamic LDS above 64 KiB must be allowed per kernel function: remember what each function was raised to
+static std::map<const void *, int> g_lds_raised;
+static hipError_t raise_lds(const void *func, int bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int &have = g_lds_raised[func];
+    if (have >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 struct jtp_plan {
     HostPlan hp;
     bool device = false;
-    bool counted = false;           // included in g_live_plans
+    bool inflight = false;          // counted in g_inflight: a dataflow propagate of this plan may still be running
+    int launch_mode = 0;            // of the last propagate: 0 one launch per level, 1 dataflow in blockIdx order, 2 dataflow, ticket order
+    int tickets_used = 0;           // propagates (per evidence set) that ran in ticket order
+    double device_bytes = 0;        // device memory allocated at plan creation (arenas, message arenas, tables)
+    int flow_propagates = 0;        // propagates (per evidence set) that ran as dataflow launches
     uint32_t flow_debug = 0;        // JTP_FLOW_DEBUG at plan creation, or jtp_debug_set(plan, "flow_debug", v)
     bool env_tickets = false;       // JTP_FLOW_TICKETS at plan creation
     bool roctx = false;             // JTP_ROCTX at plan creation: named ranges around the phases of a propagate
@@ -256,6 +274,25 @@ struct jtp_plan {
     int esize = 4;
 };
 
+// Dataflow launches in blockIdx order are safe only while no OTHER dataflow kernel can be resident on the device at the
+// same time (jtp_propagate).  A plan enters the count at its first dataflow propagate and leaves it when the host has
+// seen all its streams idle (jtp_sync, a read-out's settle, jtp_plan_destroy).
+static bool enter_flight(jtp_plan *pl) {          // returns whether ANOTHER plan is in flight on the device
+    std::atomic<int> &g = g_inflight[pl->hp.device & 63];
+    if (!pl->inflight) {
+        pl->inflight = true;
+        return g.fetch_add(1) > 0;
+    }
+    return g.load() > 1;
+}
+static void leave_flight(jtp_plan *pl) {
+    if (!pl->inflight) return;
+    for (const auto &b : pl->bufs)
+        if (b.unchecked) return;                   // some evidence set's stream has not been waited for yet
+    pl->inflight = false;
+    g_inflight[pl->hp.device & 63]--;
+}
+
 static int ensure_stage(jtp_plan *pl, size_t bytes) {
     if (pl->stage_bytes >= bytes) return JTP_OK;
     if (pl->stage) HIP_TRY(hipFree(pl->stage));
@@ -286,7 +323,12 @@ static void launch_pack(const JtPackDesc &d, const S *stage, T *arena, hipStream
 extern "C" {
 
 const char *jtp_last_error(void) { return g_err.c_str(); }
-const char *jtp_version(void) { return "jtprop 0.1.0 (gfx950, HIP, RCCL p2p)"; }
+// JTP_SOURCE_ID: digest of the library's sources, passed in by junction-tree_amd/build.py; profiles/ files carry the id of
+// the build they were measured on, and bench.py quotes a traffic figure only from a file whose id matches the running one
+#ifndef JTP_SOURCE_ID
+#define JTP_SOURCE_ID "unknown"
+#endif
+const char *jtp_version(void) { return "jtprop 0.3.0 (gfx950, HIP, RCCL p2p) src:" JTP_SOURCE_ID; }
 
 int jtp_host_alloc(void **ptr, size_t bytes) {
     if (!ptr) return set_err(JTP_EINVAL, "null argument");
@@ -313,6 +355,15 @@ int jtp_device_count(int32_t *count) {
     return JTP_OK;
 }
 
+int jtp_device_memory(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    size_t f = 0, t = 0;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return JTP_OK;
+}
+
 const char *jtp_kernel_name(int32_t variant) {
     if (variant < 0 || variant >= JT_K_COUNT) return nullptr;
     return k_names[variant];
@@ -322,10 +373,10 @@ const char *jtp_kernel_name(int32_t variant) {
 
 void jtp_plan_destroy(jtp_plan *pl) {
     if (!pl) return;
-    if (pl->counted) g_live_plans[pl->hp.device & 63]--;
     if (pl->device) {
         (void)hipSetDevice(pl->hp.device);
         for (auto s : pl->streams) (void)hipStreamSynchronize(s);
+        if (pl->inflight) g_inflight[pl->hp.device & 63]--, pl->inflight = false;
         if (pl->multiset) {
             if (!pl->bufs.empty()) {
                 if (pl->bufs[0].psi) (void)hipFree(pl->bufs[0].psi);
@@ -523,24 +574,34 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         CREATE_TRY(hipMalloc((void **)&pl->d_itab, hp.itab.size() * sizeof(int32_t)));
         CREATE_TRY(hipMemcpy(pl->d_itab, hp.itab.data(), hp.itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    // dynamic LDS beyond 64 KiB has to be allowed per kernel function (raise_lds remembers what each one has)
+    auto kfunc = [&](int v) { return hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v); };
     if (pl->multiset) {
-        const void *f = hp.dtype == JTP_F32 ? (const void *)jt_multi_flow<float> : (const void *)jt_multi_flow<double>;
-        CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JT_RING_BYTES + JT_MSETS * JT_SETB_LARGE));
+        CREATE_TRY(raise_lds(kfunc(JT_K_MULTI_COLLECT), JT_RING_BYTES + JT_MSETS * JT_SETB_LARGE));
     } else if (hp.max_lds > 64 * 1024) {
         for (int v = 0; v < JT_K_COUNT; ++v) {
             if (v == JT_K_COLLECT_FLOW || v == JT_K_DISTRIBUTE_FLOW) continue;
-            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v);
-            CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hp.max_lds));
+            CREATE_TRY(raise_lds(kfunc(v), hp.max_lds));
         }
         for (int ph = 0; ph < 2; ++ph) {
             const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain) : (const void *)KernelTable<double>::get_flow(ph, pl->chain);
-            CREATE_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hp.max_lds));
+            CREATE_TRY(raise_lds(f, hp.max_lds));
         }
+    }
+    {   // what the plan holds on the device from now on (the plan cache of the Python layer budgets with it)
+        double b = 0;
+        if (pl->multiset) {
+            const size_t nsets = (size_t)pl->n_groups * JT_MSETS;
+            b = 2.0 * abytes + (double)mbytes * nsets + (double)pl->ev_stride * 4 * nsets + (double)hp.sync_words * 4 * pl->n_groups;
+        } else {
+            const size_t npsi = share_psi ? 1 : pl->bufs.size();
+            b = (double)abytes * (npsi + pl->bufs.size()) + ((double)mbytes + (double)hp.sync_words * 4) * pl->bufs.size();
+        }
+        b += (double)hp.tasks.size() * sizeof(JtTask) + (double)hp.blocks.size() * sizeof(JtBlock) + (double)hp.itab.size() * 4;
+        pl->device_bytes = b;
     }
     CREATE_TRY(hipStreamSynchronize(pl->streams[0]));
 #undef CREATE_TRY
-    g_live_plans[hp.device & 63]++;
-    pl->counted = true;
     *out = pl;
     return JTP_OK;
 }
@@ -790,6 +851,7 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
         // only what has actually finished is known to be good (sets sharing the stream finished with it)
         for (size_t i = 0; i < pl->bufs.size(); ++i)
             if (synced < 0 || i % pl->streams.size() == (size_t)synced % pl->streams.size()) pl->bufs[i].unchecked = false;
+        leave_flight(pl);
         return JTP_OK;
     }
     *(volatile uint32_t *)pl->host_abort = 0;
@@ -799,6 +861,7 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
         // the other ranks have moved on with whatever this rank sent them: no local repair is possible
         for (auto s : pl->streams) (void)hipStreamSynchronize(s);
         for (auto &b : pl->bufs) b.unchecked = false;
+        leave_flight(pl);
         return set_err(JTP_EHIP, "a dataflow launch of rank %d timed out waiting for a message (is the GPU shared with other "
                                  "work? then set JTP_FLOW_TICKETS=1); the results of this propagate are invalid on every rank; "
                                  "this plan launches per level from now on", pl->hp.rank);
@@ -835,6 +898,7 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
         if (rc) return rc;
     }
     for (auto s : pl->streams) HIP_TRY(hipStreamSynchronize(s));
+    leave_flight(pl);
     return JTP_OK;
 }
 
@@ -959,7 +1023,10 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
             b0.flow_runs++;
             for (auto &bb : pl->bufs) bb.unchecked = true;
         }
-        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->env_tickets || g_live_plans[hp.device & 63] > 1;
+        const bool others = flow ? enter_flight(pl) : false;
+        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->env_tickets || others;
+        pl->launch_mode = flow ? (tickets ? 2 : 1) : 0;
+        if (flow) pl->flow_propagates += hp.n_batch, pl->tickets_used += tickets ? hp.n_batch : 0;
         bool mid_done = false;
         if (prof) HIP_TRY(hipEventRecord(pl->ev[ev_base + 0], s));
         auto launch = [&](int phase, int64_t blk_off, int nblocks, int lds, int ticket_idx, uint32_t ticket_base) {
@@ -1039,10 +1106,14 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         // ticket is drawn by a workgroup that is already running, so the lowest unfinished record of every
         // kernel is always being worked on, whatever else shares the device.
         // The same holds for two plans of one process whose propagates overlap (plan_for caches plans, each on
-        // its own stream), hence tickets whenever another device plan is alive on this device.
+        // its own stream), hence tickets whenever another plan of this process has a dataflow propagate IN FLIGHT on
+        // this device (round 2: whenever another plan existed).  The plan that was there first keeps blockIdx order:
+        // the newcomer's ticket-ordered workgroups always make progress and drain, so it cannot be starved for good.
         // (JTP_FLOW_TICKETS=1 in the environment: for processes that share their GPU with other processes)
-        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->streams.size() > 1 || pl->env_tickets ||
-                             g_live_plans[hp.device & 63] > 1;
+        const bool others = flow ? enter_flight(pl) : false;
+        const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->streams.size() > 1 || pl->env_tickets || others;
+        pl->launch_mode = flow ? (tickets ? 2 : 1) : 0;
+        if (flow) pl->flow_propagates++, pl->tickets_used += tickets ? 1 : 0;
         for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {
             if (st.kind == 0 && flow) {
                 const Segment &sg = hp.segments[st.first];
@@ -1151,6 +1222,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
             one.cur_off = b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));
             one.oth_off = -1;
             one.ev = b.ev;
+            HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE) : (const void *)KernelTable<double>::get(JT_K_SINGLE), bt.lds));
             launch_variant(pl, JT_K_SINGLE, bt.nblocks, bt.lds, s, bt.d_task, bt.d_blk, bt.d_tab, b.psi, b.bel, b.msg, one);
             HIP_TRY(hipGetLastError());
         }
@@ -1351,10 +1423,10 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
             pl->marg_cache.erase(pl->marg_cache.begin());
         }
         pl->marg_cache.push_back(mb);
-        if (lds > 64 * 1024) {
-            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_COLLECT0) : (const void *)KernelTable<double>::get(JT_K_COLLECT0);
-            HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, hp.max_lds)));
-        }
+    }
+    {   // the kernel that is actually launched below must be allowed this much dynamic LDS
+        const int v = pl->multiset ? JT_K_SINGLE : JT_K_COLLECT0;
+        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v), mb->lds));
     }
     // marginalise the BELIEF tables: each is the "potential" argument of a childless collect
     JtFlow plain;
@@ -1425,6 +1497,10 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     st->algorithmic_bytes = pl->multiset ? hp.alg_table_bytes * std::max(pl->n_groups, (hp.n_batch + JT_MSETS - 1) / JT_MSETS) + hp.alg_msg_bytes * hp.n_batch
                                          : hp.alg_bytes;
     st->flow_fallbacks = pl->flow_fallbacks;
+    st->launch_mode = pl->launch_mode;
+    st->tickets_used = pl->tickets_used;
+    st->flow_propagates = pl->flow_propagates;
+    st->device_bytes = pl->device_bytes;
     if (pl->multiset) {
         const int groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS;
         for (const Launch &L : hp.launches) {

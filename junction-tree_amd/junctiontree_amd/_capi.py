@@ -71,6 +71,10 @@ class Stats(C.Structure):
         ("kernel_bytes", C.c_double * 32),
         ("kernel_launches", C.c_int32 * 32),
         ("flow_fallbacks", C.c_int32),
+        ("launch_mode", C.c_int32),
+        ("tickets_used", C.c_int32),
+        ("flow_propagates", C.c_int32),
+        ("device_bytes", C.c_double),
     ]
 
 
@@ -110,6 +114,7 @@ SYMBOLS = {
     "jtp_comm_destroy": (C.c_int, []),
     "jtp_comm_selftest": (C.c_int, [C.c_int32]),
     "jtp_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
+    "jtp_device_memory": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jtp_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "jtp_host_free": (C.c_int, [C.c_void_p]),
     "jtp_last_error": (C.c_char_p, []),

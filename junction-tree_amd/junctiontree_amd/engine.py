@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _capi
 
-__all__ = ["Plan", "flatten_tree", "plan_for", "clear_plan_cache"]
+__all__ = ["Plan", "flatten_tree", "plan_for", "clear_plan_cache", "plan_cache_info", "set_plan_cache_budget"]
 
 
 def flatten_tree(tree):
@@ -310,7 +310,9 @@ class Plan:
                 k["bytes"] += st.kernel_bytes[v]
         return {"n_launches": st.n_launches, "n_messages": st.n_messages, "n_tasks": st.n_tasks,
                 "algorithmic_bytes": st.algorithmic_bytes, "collect_ms": st.collect_ms,
-                "distribute_ms": st.distribute_ms, "kernels": kernels, "flow_fallbacks": st.flow_fallbacks}
+                "distribute_ms": st.distribute_ms, "kernels": kernels, "flow_fallbacks": st.flow_fallbacks,
+                "launch_mode": ("level", "flow", "flow_tickets")[st.launch_mode], "tickets_used": st.tickets_used,
+                "flow_propagates": st.flow_propagates, "device_bytes": st.device_bytes}
 
 
 def pinned_empty(shape, dtype=np.float64):
@@ -329,8 +331,59 @@ def pinned_empty(shape, dtype=np.float64):
 
 
 # ---------------------------------------------------------------------- plan cache
+# `compute_beliefs` and `JunctionTree.propagate` are stateless calls in the reference; here the compiled plan behind
+# them (device arenas, task tables) is kept for the next call on the same structure.  The cache is bounded by device
+# BYTES, least recently used first out (round 2 kept up to 16 plans whatever their size: 2 GiB each for a config-4
+# sized tree): by default a quarter of the device's memory, at most 16 plans.
 
-_cache = {}
+_cache = {}                       # key -> Plan, least recently used first
+_cache_stats = {"hits": 0, "misses": 0, "evictions": 0}
+_cache_budget = None              # bytes; None: a quarter of the device's total memory, asked for at first use
+_CACHE_MAX_PLANS = 16
+
+
+def set_plan_cache_budget(nbytes):
+    """Bound the device memory the cached plans may hold together (None: back to the default, a quarter of the
+    device).  Plans beyond it are forgotten least recently used first."""
+    global _cache_budget
+    _cache_budget = None if nbytes is None else int(nbytes)
+    _evict(keep=None)
+
+
+def _budget():
+    global _cache_budget
+    if _cache_budget is None:
+        free, total = C.c_uint64(0), C.c_uint64(0)
+        rc = _capi.lib().jtp_device_memory(0, C.byref(free), C.byref(total))
+        _cache_budget = int(total.value // 4) if rc == _capi.JTP_OK and total.value else 1 << 62
+    return _cache_budget
+
+
+def _plan_bytes(plan):
+    if "_device_bytes" not in plan.__dict__:
+        plan._device_bytes = int(plan.stats()["device_bytes"])
+    return plan._device_bytes
+
+
+def _evict(keep):
+    """Forget least recently used plans until the cache fits its budget.  A forgotten plan is destroyed when its last
+    holder lets go (JunctionTree.plan() hands these objects out: closing here could pull a plan from under its user)."""
+    budget = _budget() if _cache else 0
+    while _cache:
+        total = sum(_plan_bytes(p) for p in _cache.values())
+        if total <= budget and len(_cache) <= _CACHE_MAX_PLANS:
+            break
+        victim = next((k for k in _cache if k is not keep), None)
+        if victim is None:
+            break                     # the plan just asked for is larger than the budget on its own: it stays
+        _cache.pop(victim)
+        _cache_stats["evictions"] += 1
+
+
+def plan_cache_info():
+    """{"plans", "device_bytes", "budget_bytes", "hits", "misses", "evictions"} of the plan cache."""
+    return dict(_cache_stats, plans=len(_cache), device_bytes=sum(_plan_bytes(p) for p in _cache.values()),
+                budget_bytes=_budget() if _cache or _cache_budget is not None else None)
 
 
 def _freeze(tree):
@@ -347,14 +400,23 @@ def plan_for(tree, node_vars, sizes, dtype, **kwargs):
     key = (_freeze(tree), tuple((n, tuple(node_vars[n])) for n in used),
            tuple(sorted((repr(k), int(sizes[k])) for k in labels)),
            dtype, tuple(sorted(kwargs.items())))
-    plan = _cache.get(key)
-    if plan is None:
-        if len(_cache) >= 16:
-            # forget the oldest; it is destroyed when its last holder lets go (JunctionTree.plan() hands
-            # these objects out, so closing here could pull a plan from under its user)
-            _cache.pop(next(iter(_cache)))
+    plan = _cache.pop(key, None)
+    if plan is not None:
+        _cache_stats["hits"] += 1
+        _cache[key] = plan                # most recently used last
+        return plan
+    _cache_stats["misses"] += 1
+    try:
         plan = Plan(tree, node_vars, sizes, dtype=dtype, **kwargs)
-        _cache[key] = plan
+    except MemoryError:
+        # the device is full: let go of every cached plan (those nobody else holds are destroyed now) and try once more
+        import gc
+        _cache_stats["evictions"] += len(_cache)
+        _cache.clear()
+        gc.collect()
+        plan = Plan(tree, node_vars, sizes, dtype=dtype, **kwargs)
+    _cache[key] = plan
+    _evict(keep=key)
     return plan
 
 

@@ -92,12 +92,17 @@ def _stage_changed_cliques(plan, ct, xs):
     number of cliques staged (`plan.staged_cliques` keeps the count of the last call for tests and tools)."""
     seen = plan.__dict__.setdefault("_factor_digests", {})
     staged = 0
+    factors = ct.factor_graph.factors
     for c, members in enumerate(ct._members()):
+        # what is staged = which factors, over which variables in which axis order, with which values: two
+        # JunctionTree objects whose junction trees coincide share one cached plan (engine.plan_for keys on the
+        # tree, not on the factors), and the same bytes under a transposed label list are another table
         digests = tuple(_digest(xs[i]) for i in members)
-        if None not in digests and seen.get(c) == digests:
+        key = tuple((i, tuple(factors[i]), d) for i, d in zip(members, digests))
+        if None not in digests and seen.get(c) == key:
             continue
         plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
-        seen[c] = digests
+        seen[c] = key
         staged += 1
     plan.staged_cliques = staged
     return staged

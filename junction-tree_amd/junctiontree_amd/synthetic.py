@@ -170,3 +170,22 @@ def algorithmic_bytes(spec, itemsize):
     reads = (2 * sum(cl) - cl[0]) * itemsize + 2 * sum(sp) * itemsize
     writes = sum(cl) * itemsize + 3 * sum(sp) * itemsize
     return {"read": reads, "write": writes, "total": reads + writes, "messages": 2 * (n - 1)}
+
+
+def lattice_mrf(h=6, w=167, card=8, seed=0, dtype=np.float32):
+    """BASELINE configs[2] as restated in SURVEY.md 8d: a 2-D lattice of h x w variables of one cardinality with a
+    pairwise factor on every lattice edge (6 x 167: 1002 variables, 1831 factors).  Returns (factors, sizes,
+    values); the values are U(0.5, 1.5) scaled by card^(-V/E) so that Z stays O(1)."""
+    names = {(i, j): i * w + j for i in range(h) for j in range(w)}
+    factors = []
+    for i in range(h):
+        for j in range(w):
+            if i + 1 < h:
+                factors.append([names[i, j], names[i + 1, j]])
+            if j + 1 < w:
+                factors.append([names[i, j], names[i, j + 1]])
+    sizes = {v: card for v in names.values()}
+    rng = np.random.default_rng(seed)
+    scale = card ** (-len(names) / len(factors))
+    values = [(rng.uniform(0.5, 1.5, (card, card)) * scale).astype(dtype) for _ in factors]
+    return factors, sizes, values

@@ -19,19 +19,7 @@ pytestmark = pytest.mark.gpu
 
 
 def lattice(h, w, card, seed=0, dtype=np.float32):
-    names = {(i, j): i * w + j for i in range(h) for j in range(w)}
-    factors = []
-    for i in range(h):
-        for j in range(w):
-            if i + 1 < h:
-                factors.append([names[i, j], names[i + 1, j]])
-            if j + 1 < w:
-                factors.append([names[i, j], names[i, j + 1]])
-    sizes = {v: card for v in names.values()}
-    rng = np.random.default_rng(seed)
-    scale = card ** (-len(names) / len(factors))            # keeps Z = O(1)
-    values = [(rng.uniform(0.5, 1.5, (card, card)) * scale).astype(dtype) for _ in factors]
-    return factors, sizes, values
+    return synthetic.lattice_mrf(h, w, card, seed, dtype)
 
 
 def test_config2_chain_full_length_vs_oracle():

@@ -1,7 +1,8 @@
 """The multi-rank path end to end on ONE GPU: W processes, each a rank with its share of the tree, real
 kernels and the real exchange schedule; only the transport is replaced - tests/mock_rccl moves the
-ncclSend/ncclRecv payloads through /dev/shm (JTP_RCCL_LIB), because RCCL refuses several ranks on one
-device and the test box has a single GPU.  Checks, over three consecutive propagates (the message arena
+ncclSend/ncclRecv payloads through mailboxes in /dev/shm (JTP_RCCL_LIB), stream ordered and asynchronous like
+the real transport (wait kernel -> copy -> signal kernel on the caller's stream; nothing synchronises a stream),
+because RCCL refuses several ranks on one device and the test box has a single GPU.  Checks, over three consecutive propagates (the message arena
 alternates between its halves), every belief of every rank against the oracle, with the default
 dataflow launches and with one launch per level, with and without reduce tasks at the cuts."""
 import os
@@ -19,7 +20,8 @@ MOCK_LIB = os.path.join(HERE, "mock_rccl", "libmockrccl.so")
 
 def _build_mock():
     if not os.path.exists(MOCK_LIB) or os.path.getmtime(MOCK_LIB) < os.path.getmtime(MOCK_SRC):
-        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-fPIC", "-shared", MOCK_SRC, "-o", MOCK_LIB])
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "--offload-arch=gfx950", "-fPIC", "-shared",
+                               MOCK_SRC, "-o", MOCK_LIB])
     return MOCK_LIB
 
 
@@ -136,3 +138,37 @@ def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opt
     assert len(cut) >= world - 1
     assert sum(got[r][2] for r in range(world)) == sum(2 * (world - 1) if owner[spec["parent"][c]] == world else 4 for c in cut)
     assert all(got[r][3] == 0 for r in range(world))
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_bench_starts_its_own_ranks(gpus):
+    """`python bench.py --gpus N` with no launcher and WORLD_SIZE unset (how the driver may call it): the parent starts
+    the N rank processes itself before it touches a GPU, relays rank 0's JSON line and exits 0.  Here the N ranks share
+    the box's one GPU over the mock transport, on the FULL config-4 tree (256 x 2^20 float32, top part replicated):
+    Z of the sharded run must agree with the one-GPU / numpy-oracle value."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["JTP_RCCL_LIB"] = _build_mock()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "5", "--warmup", "2",
+                          "--cpu-sample", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout.decode()
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == gpus and out["steps"] == 5 and out["scaling"] == "strong"
+    assert out["config"]["Z_rel_err"] <= 1e-6, out["config"]
+    assert out["config"]["launch_mode"] == "flow_tickets"          # ranks share the GPU here
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+
+
+def test_bench_rank_failure_is_an_error():
+    """Ranks that fail (here: a configuration the rank processes refuse) must fail the whole run with a non-zero
+    exit code and no result line, not hang the parent.  Needs no GPU: the ranks exit before they load the library."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c3", "--steps", "2",
+                          "--spawn-timeout", "60"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert res.returncode != 0
+    assert not any(ln.startswith("{") for ln in res.stdout.decode().splitlines())
+    assert b"exited with code" in res.stderr

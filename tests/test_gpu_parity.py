@@ -30,11 +30,32 @@ def close(got, want, rtol=RTOL64, what=""):
         np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * scale + 1e-300, err_msg=what)
 
 
+@pytest.fixture(autouse=True)
+def _no_cached_plans():
+    """Explicit plans of a test must run in the launch mode they ask for (default: dataflow launches in blockIdx
+    order, the mode the benchmark times), whatever `compute_beliefs` / `propagate` of an earlier test left in the
+    plan cache.  (Since round 3 an idle cached plan no longer forces ticket order - only a propagate IN FLIGHT does,
+    `test_ticket_order_only_while_another_plan_is_in_flight` - the empty cache keeps the tests independent.)"""
+    engine.clear_plan_cache()
+    yield
+    engine.clear_plan_cache()
+
+
+def expected_mode(opts):
+    if opts.get("level_launches") or opts.get("split_variants"):
+        return "level"
+    return "flow_tickets" if opts.get("flow_tickets") or opts.get("n_batch", 1) > 1 else "flow"
+
+
 def run_plan(spec, pots, dtype, **opts):
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, **opts)
     for c in range(spec["n_cliques"]):
         plan.set_potential(c, pots[c])
     plan.propagate()
+    st = plan.stats()
+    # the launch mode is observable (jtp_stats): the default is dataflow launches in blockIdx order
+    assert st["launch_mode"] == expected_mode(opts), (st["launch_mode"], opts)
+    assert st["tickets_used"] == (1 if expected_mode(opts) == "flow_tickets" else 0) and st["flow_fallbacks"] == 0
     out = [plan.belief(n) for n in range(len(spec["node_vars"]))]
     z = plan.z()
     plan.close()
@@ -537,18 +558,70 @@ def test_launch_modes_are_bit_identical():
     workgroups on the same tables: every belief must agree to the last bit."""
     spec = synthetic.wide_binary_tree(n_cliques=31, width=15, sep=7, card=2, seed=9)
     pots = synthetic.potentials_for(spec, seed=77, dtype=np.float32)
-    results = []
+    results, modes = [], []
     for opts in ({}, {"level_launches": True}, {"flow_tickets": True}):
         plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", block_log2=11, **opts)
         for c in range(spec["n_cliques"]):
             plan.set_potential(c, pots[c])
         plan.propagate()
         plan.propagate()
+        st = plan.stats()
+        modes.append((st["launch_mode"], st["tickets_used"], st["flow_propagates"], st["n_launches"] > 2))
         results.append([plan.belief(node) for node in range(len(spec["node_vars"]))])
         plan.close()
+    # three genuinely different modes (round 2 compared tickets with tickets: cached plans forced them)
+    assert modes == [("flow", 0, 2, False), ("level", 0, 0, True), ("flow_tickets", 2, 2, False)], modes
     for other in results[1:]:
         for a, b in zip(results[0], other):
             assert np.array_equal(a, b)
+
+
+def test_ticket_order_only_while_another_plan_is_in_flight():
+    """Dataflow launches in blockIdx order are unsafe only while ANOTHER dataflow kernel may be resident (jtp_engine.hip:
+    enter_flight).  An idle second plan costs nothing; one with an unsynchronised propagate makes the newcomer draw
+    tickets; once it has been waited for, blockIdx order is back.  Results are identical either way."""
+    spec = synthetic.wide_binary_tree(n_cliques=15, width=14, sep=7, card=2, seed=4)
+    pots = synthetic.potentials_for(spec, seed=8)
+    want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
+    a = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64")
+    b = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64")
+    for plan in (a, b):
+        for c in range(spec["n_cliques"]):
+            plan.set_potential(c, pots[c])
+    a.propagate()                                            # waited for: a is idle again
+    b.propagate()
+    assert a.stats()["launch_mode"] == "flow" and b.stats()["launch_mode"] == "flow"
+    a.propagate(sync=False)                                  # a in flight ...
+    b.propagate(sync=False)                                  # ... so b draws tickets
+    assert a.stats()["launch_mode"] == "flow" and b.stats()["launch_mode"] == "flow_tickets"
+    a.propagate(sync=False)                                  # and now b is in flight when a launches again
+    assert a.stats()["launch_mode"] == "flow_tickets"
+    for plan in (a, b):
+        for node in range(len(spec["node_vars"])):           # (the read-out waits for the plan's stream)
+            close(plan.belief(node), want[node], what="node %d" % node)
+    a.propagate()
+    assert a.stats()["launch_mode"] == "flow" and a.stats()["tickets_used"] == 1 and b.stats()["tickets_used"] == 1
+    a.close()
+    b.close()
+
+
+def test_two_trees_sharing_one_cached_plan_with_transposed_factor():
+    """Two JunctionTree objects with the same junction tree share one cached plan (plan_for keys on the tree, not on
+    the factors).  The second model labels one factor's axes the other way round and gets byte-identical arrays: its
+    cliques must be staged again, not skipped (round-2 advisor finding: it silently returned the first model's
+    marginals)."""
+    sizes = {"a": 2, "b": 2, "c": 2, "d": 2}
+    f1 = [["a", "b", "c"], ["a", "b"], ["c", "d"]]
+    f2 = [["a", "b", "c"], ["b", "a"], ["c", "d"]]
+    rng = np.random.default_rng(5)
+    values = [rng.random((2, 2, 2)), rng.random((2, 2)), rng.random((2, 2))]
+    t1, t2 = jt.create_junction_tree(f1, dict(sizes)), jt.create_junction_tree(f2, dict(sizes))
+    assert t1.tree == t2.tree and t1.plan("f64") is t2.plan("f64")          # the premise: one plan
+    for tree, factors in ((t1, f1), (t2, f2), (t1, f1)):
+        out = tree.propagate(values)
+        joint = np.einsum(values[0], [0, 1, 2], values[1], [{"a": 0, "b": 1}[v] for v in factors[1]], values[2], [2, 3], [0, 1, 2, 3])
+        for o, labs in zip(out, factors):
+            close(o, np.einsum(joint, [0, 1, 2, 3], [{"a": 0, "b": 1, "c": 2, "d": 3}[v] for v in labs]), what=repr(labs))
 
 
 def test_dataflow_timeout_falls_back_to_level_launches():
@@ -842,3 +915,45 @@ def test_random_trees_mixed_cardinalities_on_device(seed):
         for o, w in zip(out, ref):
             close(o, w, rtol=RTOL32 if dtype == "f32" else RTOL64, what="seed %d %s" % (seed, dtype))
     assert abs(zz - z) <= 1e-5 * abs(z)
+
+
+def test_plan_cache_is_bounded_by_device_bytes():
+    """The plan cache behind `compute_beliefs` / `propagate` keeps device plans up to a byte budget, least recently
+    used first out (round 2: up to 16 plans of any size).  Twenty distinct mid-size trees under a budget of four of
+    them: the cached bytes stay within the budget, a plan used again is kept, and the device memory of forgotten plans
+    is given back."""
+    import ctypes as C
+    from junctiontree_amd import _capi
+
+    def free_bytes():
+        free, total = C.c_uint64(0), C.c_uint64(0)
+        _capi.check(_capi.lib().jtp_device_memory(0, C.byref(free), C.byref(total)))
+        return free.value
+
+    specs = [synthetic.wide_binary_tree(n_cliques=7, width=18, sep=9, card=2, seed=100 + i) for i in range(20)]
+    first = engine.plan_for(specs[0]["tree"], specs[0]["node_vars"], specs[0]["sizes"], "f32")
+    one = engine.plan_cache_info()["device_bytes"]
+    assert one >= 7 * 2 * 4 * 2 ** 18                          # seven tables of 2^18 floats, potentials and beliefs
+    start_free = free_bytes() + one
+    try:
+        engine.set_plan_cache_budget(4 * one + one // 2)
+        del first
+        for i, spec in enumerate(specs):
+            plan = engine.plan_for(spec["tree"], spec["node_vars"], spec["sizes"], "f32")
+            info = engine.plan_cache_info()
+            assert info["device_bytes"] <= info["budget_bytes"] and info["plans"] <= 4, info
+            if i % 3 == 0:                                       # keep plan 0 recently used: it must survive
+                assert engine.plan_for(specs[0]["tree"], specs[0]["node_vars"], specs[0]["sizes"], "f32").stats()["device_bytes"] == one
+            pots = synthetic.potentials_for(spec, seed=1, dtype=np.float32)
+            for c in range(spec["n_cliques"]):
+                plan.set_potential(c, pots[c])
+            plan.propagate()
+            assert np.isfinite(plan.z())
+            del plan
+        info = engine.plan_cache_info()
+        assert info["evictions"] >= 15 and info["hits"] >= 7
+        import gc
+        gc.collect()
+        assert start_free - free_bytes() <= 5 * one + (64 << 20)        # forgotten plans gave their memory back
+    finally:
+        engine.set_plan_cache_budget(None)
