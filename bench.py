@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="size of the CPU baseline's sample: cliques of the tree (c4: default 256 = the full workload, ~4-25 s "
-                         "on one core; c2: default 100 of the 1000 cliques) or lattice columns (c3: default 10); 0 = skip")
+                         "on one core; c2: default 100 of the 1000 cliques) or lattice columns (c3: default 60); 0 = skip")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the CPU port on every host core at once (independent evidence sets, SURVEY.md 8d)")
     ap.add_argument("--no-profile", action="store_true", help="no hipEvent pairs in the timed region")
@@ -455,7 +455,7 @@ def main():
                                   for kn, kv in stats["kernels"].items()},
                 "collect_ms": stats["collect_ms"], "distribute_ms": stats["distribute_ms"],
             }
-        cpu_n = args.cpu_sample if args.cpu_sample >= 0 else {"c4": n, "c2": 100, "c3": 10}[args.config]
+        cpu_n = args.cpu_sample if args.cpu_sample >= 0 else {"c4": n, "c2": 100, "c3": 60}[args.config]
         if cpu_n > 0 and world == 1:
             if args.config == "c4":
                 sample = synthetic.wide_binary_tree(n_cliques=cpu_n, width=args.width, sep=args.sep, card=args.card, seed=0)

@@ -174,7 +174,10 @@ struct BatchBuffers {
     uint32_t *ev = nullptr;         // hard evidence: (mask, value) per planner node, or null (jtp_set_evidence)
     uint32_t *sync = nullptr;       // dataflow launches: abort flag and ticket counters
     uint32_t epoch = 0;             // propagates enqueued so far; its parity selects the message arena half
-    uint32_t flow_runs = 0;         // of which dataflow (ticket counters only grow)
+    uint32_t flow_runs = 0;         // of which dataflow
+    uint32_t ticket_runs = 0;       // of which in ticket order: the segments' ticket counters only grow, by one launch's workgroups
+                                    // per such run (NOT per dataflow run: a plan changes between blockIdx and ticket order as other
+                                    // plans come and go)
     bool unchecked = false;         // a dataflow propagate was enqueued and its abort flag not looked at yet
     int64_t cur_off(int64_t half) const { return (epoch & 1u) ? half : 0; }     // half in use by the last propagate
 };
@@ -872,7 +875,7 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
     if (pl->multiset) {                                     // (all sets run together, the padding sets of the last group too)
         const size_t mbytes = (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 16;
         HIP_TRY(hipMemsetD32((hipDeviceptr_t)pl->msg_all, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), mbytes * pl->n_groups * JT_MSETS / 4));
-        for (auto &b : pl->bufs) b.epoch = 0, b.flow_runs = 0;
+        for (auto &b : pl->bufs) b.epoch = 0, b.flow_runs = 0, b.ticket_runs = 0;
     } else
     for (size_t i = 0; i < pl->bufs.size(); ++i) {
         BatchBuffers &b = pl->bufs[i];
@@ -881,6 +884,7 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
         HIP_TRY(hipMemsetD32((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 4));
         b.epoch = 0;
         b.flow_runs = 0;
+        b.ticket_runs = 0;
     }
     if (pl->multiset) {
         bool any = false;
@@ -1027,6 +1031,8 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->env_tickets || others;
         pl->launch_mode = flow ? (tickets ? 2 : 1) : 0;
         if (flow) pl->flow_propagates += hp.n_batch, pl->tickets_used += tickets ? hp.n_batch : 0;
+        const uint32_t ticket_run = b0.ticket_runs;            // ticket-ordered runs before this one
+        if (flow && tickets) b0.ticket_runs++;
         bool mid_done = false;
         if (prof) HIP_TRY(hipEventRecord(pl->ev[ev_base + 0], s));
         auto launch = [&](int phase, int64_t blk_off, int nblocks, int lds, int ticket_idx, uint32_t ticket_base) {
@@ -1051,7 +1057,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 const Segment &sg = hp.segments[st.first];
                 int lds = 0;
                 for (int i = sg.first_launch; i < sg.first_launch + sg.n_launch; ++i) lds = std::max(lds, multiset_lds(hp, hp.launches[i]));
-                launch(sg.phase, sg.blk_off, sg.nblocks, lds, tickets ? sg.ticket_idx : -1, (b0.flow_runs - 1u) * (uint32_t)sg.nblocks);
+                launch(sg.phase, sg.blk_off, sg.nblocks, lds, tickets ? sg.ticket_idx : -1, ticket_run * (uint32_t)sg.nblocks);
             } else {
                 const Launch &L = hp.launches[st.first];
                 launch(L.phase, L.blk_off, L.nblocks, multiset_lds(hp, L), -1, 0u);
@@ -1114,6 +1120,8 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         const bool tickets = (hp.flags & JTP_FLOW_TICKETS) != 0 || pl->streams.size() > 1 || pl->env_tickets || others;
         pl->launch_mode = flow ? (tickets ? 2 : 1) : 0;
         if (flow) pl->flow_propagates++, pl->tickets_used += tickets ? 1 : 0;
+        const uint32_t ticket_run = bb.ticket_runs;            // ticket-ordered runs of this evidence set before this one
+        if (flow && tickets) bb.ticket_runs++;
         for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {
             if (st.kind == 0 && flow) {
                 const Segment &sg = hp.segments[st.first];
@@ -1123,7 +1131,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 }
                 fl.ticket_idx = tickets ? (uint32_t)sg.ticket_idx : 0xffffffffu;
                 fl.blk_base = (uint32_t)sg.blk_off;
-                fl.ticket_base = (bb.flow_runs - 1u) * (uint32_t)sg.nblocks;
+                fl.ticket_base = ticket_run * (uint32_t)sg.nblocks;
                 if (hp.dtype == JTP_F32)
                     hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase, pl->chain), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const float *)bb.psi, (float *)bb.bel, bb.msg, fl);

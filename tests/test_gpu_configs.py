@@ -153,3 +153,44 @@ def test_config5_evidence_sets_on_the_width20_tree():
                 close(plan.belief(n + c - 1, batch=b), want[n + c - 1], rtol=RTOL32, what="set %d separator of %d" % (b, c))
         del want
     plan.close()
+
+
+def test_config5_multiset_64_sets_on_the_width20_tree():
+    """configs[4] through the multi-set kernel (jt_multi_flow: one pass over a table serves a group of evidence sets) at
+    CONFIG SCALE: 64 evidence sets of 16 observed variables on the full width-20 tree, one copy of the 256 x 2^20
+    float32 tables.  Five sets against the oracle on indicator-multiplied potentials - Z, sampled clique beliefs (formed
+    on demand: a multi-set plan keeps no belief tables) and the separator beliefs next to them; EVERY set through its
+    own consistency: sampled clique marginals sum to the set's Z, and the set's Z is P(evidence) * Z of the evidence-free
+    tree, i.e. at most that."""
+    spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
+    n, nb = spec["n_cliques"], 64
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", n_batch=nb, multiset=True)
+    assert plan.describe()["multiset"] == 1
+    plan.fill_synthetic(1, spec["scales"])
+    labels = sorted(spec["sizes"])
+    observed = []
+    for b in range(nb):
+        rng = np.random.default_rng(1000 + b)
+        observed.append({labels[i]: int(rng.integers(0, 2)) for i in rng.choice(len(labels), size=16, replace=False)})
+        plan.set_evidence(observed[b], batch=b)
+    for _ in range(2):                                       # both halves of the message arenas
+        plan.propagate()
+    st = plan.stats()
+    assert st["flow_fallbacks"] == 0 and st["launch_mode"] == "flow" and st["n_launches"] == 2
+    zs = [plan.z(batch=b) for b in range(nb)]
+    z_free = 1.0058528272803358                              # bench.py: Z of the evidence-free tree (oracle)
+    assert all(np.isfinite(z) and 0 < z < z_free for z in zs)
+    rng = np.random.default_rng(0)
+    for b in range(nb):
+        for c in rng.choice(n, size=2, replace=False):
+            assert abs(plan.marginal(int(c), [], batch=b) - zs[b]) <= 2e-6 * zs[b], (b, c)
+    base = synthetic.potentials_for(spec, seed=1, dtype=np.float32)
+    for b in (0, 7, 21, 40, 63):                              # (sets of different groups of the launch)
+        want, z = oracle.beliefs_exact(spec["tree"], _with_evidence(spec, base, observed[b]), spec["node_vars"], return_z=True)
+        assert abs(zs[b] - z) <= RTOL32 * z, b
+        for c in [0, 1, n - 1] + [int(x) for x in rng.choice(np.arange(2, n - 1), size=4, replace=False)]:
+            close(plan.belief(c, batch=b), want[c], rtol=RTOL32, what="set %d clique %d" % (b, c))
+            if c > 0:
+                close(plan.belief(n + c - 1, batch=b), want[n + c - 1], rtol=RTOL32, what="set %d separator of %d" % (b, c))
+        del want
+    plan.close()

@@ -364,8 +364,19 @@ def test_full_size_c4_properties():
         sb = plan.belief(sep_node)
         close(plan.marginal(c, labels), sb, rtol=2e-6)
         close(plan.marginal(par, labels), sb, rtol=2e-6)
-    # a sampled clique against an independent recomputation from its neighbours' messages is
-    # covered at reduced size by test_mid_size_wide_tree_vs_oracle; here check linearity
+    # sampled cliques and the separators next to them, elementwise against the oracle on the same values (the device
+    # fill and synthetic.potentials_for generate the same numbers): root, an inner clique of every level, leaves
+    pots = synthetic.potentials_for(spec, seed=1, dtype=np.float32)
+    want, z_want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+    del pots
+    assert abs(z - z_want) <= RTOL32 * z_want
+    for c in [0, 1, 2, 5, 12, 27, 60, 100, 127, 128, 200, n - 1] + [int(i) for i in rng.choice(np.arange(3, n), size=6, replace=False)]:
+        close(plan.belief(c), want[c], rtol=RTOL32, what="clique %d" % c)
+        if c > 0:
+            close(plan.belief(n + c - 1), want[n + c - 1], rtol=RTOL32, what="separator of clique %d" % c)
+    del want
+    assert plan.stats()["launch_mode"] == "flow" and plan.stats()["flow_fallbacks"] == 0
+    # linearity
     leaf = n - 1
     before = plan.belief(leaf)
     plan2 = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
