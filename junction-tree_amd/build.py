@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "junctiontree_amd", "lib")
 LIB = os.path.join(LIBDIR, "libjtprop.so")
-SOURCES = ["jtp_plan.cpp", "jtp_engine.hip"]
+INST = ["jtp_inst_%s_%s.hip" % (fam, t) for fam in ("multi", "both", "flow", "level", "shape") for t in ("f32", "f64")]
+SOURCES = ["jtp_plan.cpp", "jtp_engine.hip"] + INST       # (compiled in parallel, one object each, then linked)
 DEPS = SOURCES + ["jtp_internal.h", "jtp_plan.h", "jtp_kernels.hip.h", os.path.join("..", "..", "include", "jtprop.h")]
 
 
@@ -48,20 +49,36 @@ def needs_build():
         return False
 
 
-def build(force=False, verbose=True, extra=(), out=None):
+def build(force=False, verbose=True, extra=(), out=None, jobs=None):
     out = out or LIB
     if out == LIB and not force and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    import shutil
+    import tempfile
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     sid = source_id() + ("+" + "".join(sorted(extra)).replace(" ", "") if extra else "")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-variable", '-DJTP_SOURCE_ID="%s"' % sid] + list(extra)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", out, "-ldl"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+             '-DJTP_SOURCE_ID="%s"' % sid] + list(extra)
+    objdir = tempfile.mkdtemp(prefix="jtprop_build_")
+    try:
+        def compile_one(src):
+            obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj
+        jobs = jobs or max(1, min(len(SOURCES), (os.cpu_count() or 2)))
+        with ThreadPoolExecutor(jobs) as pool:          # (the heaviest translation units are listed first)
+            objs = list(pool.map(compile_one, INST + ["jtp_engine.hip", "jtp_plan.cpp"]))
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     if out == LIB:
         head = "unknown"
         try:

@@ -156,7 +156,10 @@ struct KernelTable {
         }
         return nullptr;
     }
-    static fn get_flow(int phase, bool chain) { return phase == 0 ? jt_collect_flow<T> : (chain ? jt_distribute_flow_chain<T> : jt_distribute_flow<T>); }
+    static fn get_flow(int phase, bool chain) {
+        if (phase == 2) return jt_propagate_flow<T>;                    // both phases in one launch
+        return phase == 0 ? jt_collect_flow<T> : (chain ? jt_distribute_flow_chain<T> : jt_distribute_flow<T>);
+    }
 };
 
 static const char *k_names[JT_K_COUNT] = {
@@ -164,7 +167,7 @@ static const char *k_names[JT_K_COUNT] = {
     "jt_distribute<T, 0, 0>", "jt_distribute<T, 0, 1>", "jt_distribute<T, 0, 2>", "jt_distribute<T, 0, 3>",
     "jt_distribute<T, 1, 0>", "jt_distribute<T, 1, 1>", "jt_distribute<T, 1, 2>", "jt_distribute<T, 1, 3>",
     "jt_collect_level<T>", "jt_distribute_level<T>", "jt_collect_flow<T>", "jt_distribute_flow<T>", "jt_reduce_level<T>",
-    "jt_multi_flow<T>", "jt_multi_flow<T>", "jt_single<T>",
+    "jt_multi_flow<T>", "jt_multi_flow<T>", "jt_single<T>", "jt_propagate_flow<T>",
 };
 
 struct BatchBuffers {
@@ -583,10 +586,10 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         CREATE_TRY(raise_lds(kfunc(JT_K_MULTI_COLLECT), JT_RING_BYTES + JT_MSETS * JT_SETB_LARGE));
     } else if (hp.max_lds > 64 * 1024) {
         for (int v = 0; v < JT_K_COUNT; ++v) {
-            if (v == JT_K_COLLECT_FLOW || v == JT_K_DISTRIBUTE_FLOW) continue;
+            if (kfunc(v) == nullptr) continue;                 // (the dataflow kernels: below)
             CREATE_TRY(raise_lds(kfunc(v), hp.max_lds));
         }
-        for (int ph = 0; ph < 2; ++ph) {
+        for (int ph = 0; ph < 3; ++ph) {
             const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain) : (const void *)KernelTable<double>::get_flow(ph, pl->chain);
             CREATE_TRY(raise_lds(f, hp.max_lds));
         }
@@ -1125,7 +1128,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {
             if (st.kind == 0 && flow) {
                 const Segment &sg = hp.segments[st.first];
-                if (per_phase && !mid_done && sg.phase == 1) {
+                if (per_phase && !mid_done && sg.phase >= 1) {       // (a merged launch counts as the second phase)
                     HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
                     mid_done = true;
                 }
@@ -1525,7 +1528,7 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
         for (const Segment &sg : hp.segments) st->kernel_launches[sg.phase == 0 ? JT_K_MULTI_COLLECT : JT_K_MULTI_DISTRIBUTE] += flow ? 1 : sg.n_launch;
     } else if (flow) {
         for (const Segment &sg : hp.segments) {
-            const int v = sg.phase == 0 ? JT_K_COLLECT_FLOW : JT_K_DISTRIBUTE_FLOW;
+            const int v = sg.phase == 0 ? JT_K_COLLECT_FLOW : (sg.phase == 1 ? JT_K_DISTRIBUTE_FLOW : JT_K_BOTH_FLOW);
             for (int i = sg.first_launch; i < sg.first_launch + sg.n_launch; ++i) st->kernel_bytes[v] += hp.launches[i].alg_bytes;
             st->kernel_launches[v] += 1;
         }
@@ -1568,8 +1571,18 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
                 st->kernel_ms[JT_K_MULTI_COLLECT] = st->collect_ms;
                 st->kernel_ms[JT_K_MULTI_DISTRIBUTE] = st->distribute_ms;
             } else if (flow) {
-                st->kernel_ms[JT_K_COLLECT_FLOW] = st->collect_ms;
-                st->kernel_ms[JT_K_DISTRIBUTE_FLOW] = st->distribute_ms;
+                bool merged = false;
+                for (const Segment &sg : hp.segments) merged = merged || sg.phase == 2;
+                if (merged && hp.segments.size() == 1) {
+                    st->kernel_ms[JT_K_BOTH_FLOW] = st->collect_ms + st->distribute_ms;       // one launch: the whole propagate
+                } else if (merged) {
+                    // (sharded plans: a collect launch, the exchange, then the merged launch)
+                    st->kernel_ms[JT_K_COLLECT_FLOW] = st->collect_ms;
+                    st->kernel_ms[JT_K_BOTH_FLOW] = st->distribute_ms;
+                } else {
+                    st->kernel_ms[JT_K_COLLECT_FLOW] = st->collect_ms;
+                    st->kernel_ms[JT_K_DISTRIBUTE_FLOW] = st->distribute_ms;
+                }
             } else if (!(hp.flags & JTP_SPLIT_VARIANTS)) {
                 st->kernel_ms[JT_K_COLLECT_LEVEL] = st->collect_ms;
                 st->kernel_ms[JT_K_DISTRIBUTE_LEVEL] = st->distribute_ms;

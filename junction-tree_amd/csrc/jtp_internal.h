@@ -115,7 +115,7 @@ struct JtTask {
     int64_t itab_off;          // offset (ints) of this task's iteration table in the table buffer
     int32_t total;             // loop iterations per workgroup = 2^(nA + nR), 4 .. 64
     int32_t itab_lds;          // byte offset of the iteration table in dynamic LDS
-    int64_t dbg_off;           // JTP_DEBUG & 2: msg-arena offset of 8 time stamps per workgroup (diagnostic builds)
+    int64_t dbg_off;           // JTP_DEBUG & 2: msg-arena offset of the time stamps, 16 per workgroup (builds with -DJT_STAMPS)
     JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing
 };
 
@@ -212,5 +212,6 @@ enum {
     JT_K_REDUCE_LEVEL,                              // reduce tasks of one level (per-level launches only)
     JT_K_MULTI_COLLECT, JT_K_MULTI_DISTRIBUTE,      // multi-set plans: JT_MSETS evidence sets per pass over a table
     JT_K_SINGLE,                                    // one task list, any mix of modes and neighbour counts (read-out)
+    JT_K_BOTH_FLOW,                                 // collect and distribute in ONE dataflow launch (Segment::phase 2)
     JT_K_COUNT
 };

@@ -47,6 +47,13 @@ template <> struct JtVec<double> { using type = double2; };
 // vmcnt themselves (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void jt_dma16(const void *gsrc, uint32_t lds_dst) {
     unsigned keep;
+#ifdef JT_TABLE_NT          // (A/B builds) non-temporal policy on the table stream: rows are read once per phase by one CU
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+    return;
+#endif
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
@@ -63,6 +70,20 @@ __device__ __forceinline__ double jt_shfl_xor(double v, int laneMask) {
     hi = __shfl_xor(hi, laneMask, 64);
     return __hiloint2double(hi, lo);
 }
+
+// Diagnostic time stamps (builds with -DJT_STAMPS only: `python junction-tree_amd/build.py --out stamps.so -DJT_STAMPS`, plans
+// made with JTP_DEBUG=2): lane 0 of a workgroup stores the 100 MHz clock at stage boundaries into its JT_NSTAMP slots of the
+// time-stamp region (JtTask::dbg_off).  In the product build the macro is empty: no registers, no branches, no stores.
+// Slots: 0 entry, 1 first element loads issued, 2 end of the first staging attempt, 3 staged, 4 constants read,
+// 5-8 after loop steps 0-3, 9 loop done, 10 epilogues done (barrier), 11 flush stores issued, 12 flush stores retired,
+// 13 staging attempts (a count, not a time), 14 end of the last wait for a producer (0: never waited).
+#define JT_NSTAMP 16
+#ifdef JT_STAMPS
+#define JT_STAMP_AT(slot, value) do { if ((dbg & 2) && threadIdx.x == 0) stamp_out[slot] = (double)(value); } while (0)
+#else
+#define JT_STAMP_AT(slot, value) do { } while (0)
+#endif
+#define JT_STAMP(slot) JT_STAMP_AT(slot, __builtin_amdgcn_s_memrealtime())
 
 // message-index bit of sub-box index bit b (free_pos[] packed four per word)
 #define JT_FPOS(fp, b) (((fp)[(b) >> 2] >> (8 * ((b) & 3))) & 0xffu)
@@ -118,6 +139,28 @@ __device__ __forceinline__ double jt_msg_settle(const double *p, double v, bool 
     return v;
 }
 
+
+// Where entry i of a workgroup's sub-box of a message lives in the message: the sub-box index is a bit-deposit of i into the
+// message's index (bit b of i lands on message bit free_pos[b]).  The deposit is linear over disjoint bit groups, so it is
+// split once per message into the part of a thread's own low eight index bits (jt_sub_lo: a vector value) and a 32-row table
+// of the bits above them, row j in lane j (jt_sub_hi, read with v_readlane): an entry's address then costs one add, where
+// rounds 1-2 walked up to 13 bits for every single load (the staging code ran to thousands of instructions per thread -
+// 4-6 us per workgroup, on every level, measured with the time stamps of round 3).
+__device__ __forceinline__ uint32_t jt_sub_lo(const uint32_t (&fp)[4], int nfree, int i) {
+    uint32_t g = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+        if (b < nfree) g += (((uint32_t)i >> b) & 1u) << JT_FPOS(fp, b);
+    return g;
+}
+__device__ __forceinline__ uint32_t jt_sub_hi(const uint32_t (&fp)[4], int nfree, int lane) {
+    uint32_t g = 0;
+#pragma unroll
+    for (int b = 8; b < JT_MAX_FREE; ++b)
+        if (b < nfree) g += (((uint32_t)lane >> (b - 8)) & 1u) << JT_FPOS(fp, b);
+    return g;
+}
+
 template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
@@ -136,47 +179,62 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // diagnostic time stamps (JTP_DEBUG=2): 100 MHz wall clock at stage boundaries, lane 0 only
-    uint64_t stamp[6];
-    stamp[0] = FLOW ? t_entry : __builtin_amdgcn_s_memrealtime();
     const uint32_t xF = bk.xF + (uint32_t)tid * VEC;
     const T *psi = psi_arena + tk.psi_off;
     T *bel = bel_arena + (MODE == 1 ? tk.bel_off : 0);   // distribute always stores (virtual cliques: scratch)
     const int total = tk.total;                       // loop iterations of this workgroup (>= U)
     const int dbg = tk.debug;
+#ifdef JT_STAMPS
+    double *stamp_out = msg_arena + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * JT_NSTAMP;
+#endif
+    JT_STAMP_AT(0, FLOW ? t_entry : __builtin_amdgcn_s_memrealtime());
     // What staging needs from the task record, read HERE: the element loads below are issued by inline assembly that the
     // compiler treats as a barrier for memory operations - left where they are used, these scalar loads would be one more
     // dependent round trip between the workgroup's start and its message loads.
-    int64_t sm_off[NIN > 0 ? NIN : 1], sm_ps[NIN > 0 ? NIN : 1];
-    int sm_npart[NIN > 0 ? NIN : 1], sm_nfree[NIN > 0 ? NIN : 1], sm_lds[NIN > 0 ? NIN : 1];
-    bool sm_same[NIN > 0 ? NIN : 1];
-    uint32_t sm_fp[NIN > 0 ? NIN : 1][4];
+    constexpr int NI = NIN > 0 ? NIN : 1, NO = NOUT > 0 ? NOUT : 1;
+    int64_t sm_off[NI], sm_ps[NI];
+    int sm_npart[NI], sm_nfree[NI], sm_lds[NI];
+    bool sm_same[NI];
+    uint32_t sm_glo[NI], sm_hiv[NI];                   // where this thread's sub-box entries lie in the message (jt_sub_lo / jt_sub_hi)
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         const JtMsg &m = tk.msg[k];
         const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+        const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
         sm_off[k] = m.off + bk.gbase[k];
         sm_ps[k] = m.pstride;
         sm_npart[k] = m.npart;
         sm_nfree[k] = m.nfree;
         sm_lds[k] = m.lds_off;
         sm_same[k] = m.same_launch != 0;
-        sm_fp[k][0] = fpw[0], sm_fp[k][1] = fpw[1], sm_fp[k][2] = fpw[2], sm_fp[k][3] = fpw[3];
+        sm_glo[k] = jt_sub_lo(fp, m.nfree, tid);       // (sub-boxes below 256 entries: the entry of thread tid mod 2^nfree)
+        sm_hiv[k] = jt_sub_hi(fp, m.nfree, lane);
     }
-    // ... and, in the collect pass, what the flush needs: read after the loop these are one more dependent round trip on
-    // the hand-over to the parent (config 2: collect 2.52 -> 2.40 ms).  Not in the distribute pass: there the registers
-    // they occupy through the loop cost more (spills) than the round trip, which hides behind the belief stores.
+    // ... and what the flush needs.  Collect pass: kept in registers (read after the loop these are one more dependent round
+    // trip on the hand-over to the parent: config 2 collect 2.52 -> 2.40 ms).  Distribute pass: the registers they would occupy
+    // through the loop cost more (spills) than they save, so lane 0 parks the few words in LDS (flow_ctl) and the flush reads
+    // them back from there - round 2 read the task record again, a dependent trip to memory of 1.0-1.6 us in front of the
+    // stores of every hand-over.
     constexpr bool EARLY_OUT = MODE == 0;
-    int64_t so_at[NOUT > 0 ? NOUT : 1];
-    int so_nfree[NOUT > 0 ? NOUT : 1];
-    uint32_t so_fp[NOUT > 0 ? NOUT : 1][4];
+    int64_t so_at[NO];
+    int so_nfree[NO];
+    uint32_t so_glo[NO], so_hiv[NO];
+    uint32_t *park = flow_ctl != nullptr ? flow_ctl + 28 : nullptr;       // [NOUT][8]: at (2 words), nfree, free_pos (4 words)
 #pragma unroll
-    for (int j = 0; j < (EARLY_OUT ? NOUT : 0); ++j) {
+    for (int j = 0; j < NOUT; ++j) {
         const JtMsg &m = tk.msg[JT_MAX_IN + j];
         const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
-        so_at[j] = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
-        so_nfree[j] = m.nfree;
-        so_fp[j][0] = fpw[0], so_fp[j][1] = fpw[1], so_fp[j][2] = fpw[2], so_fp[j][3] = fpw[3];
+        const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
+        const int64_t at = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+        if constexpr (EARLY_OUT) {
+            so_at[j] = at;
+            so_nfree[j] = m.nfree;
+            so_glo[j] = jt_sub_lo(fp, m.nfree, tid);
+            so_hiv[j] = jt_sub_hi(fp, m.nfree, lane);
+        } else if (park != nullptr && tid == 0) {
+            park[8 * j + 0] = (uint32_t)at, park[8 * j + 1] = (uint32_t)((uint64_t)at >> 32), park[8 * j + 2] = (uint32_t)m.nfree;
+            park[8 * j + 3] = fp[0], park[8 * j + 4] = fp[1], park[8 * j + 5] = fp[2], park[8 * j + 6] = fp[3];
+        }
     }
     // outgoing message j's epilogue follows every 2^run_j iterations (JtTask::out_run)
     int rmask[NOUT > 0 ? NOUT : 1];
@@ -211,154 +269,147 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     const bool chunk_ok = !(bk.flags & JT_BLOCK_INVALID);
     const uint32_t ring_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + (uint32_t)wave * (U * 1024);
     const char *ring = smem + wave * (U * 1024) + lane * 16;
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
     // The workgroup's iteration table (<= 64 rows of JT_NCOL ints, host built) lives in registers,
     // row r in lane r; a step reads "row i, column c" with v_readlane: no memory latency on the
     // critical path of a step except the message entries themselves.
     int trow[JT_NCOL];
-    {
+    // Vector-memory operations return in issue order (s_waitcnt vmcnt counts them together), so whatever is issued BEHIND the
+    // first table rows waits for them - a cold trip to HBM - before it can be used.  With incoming messages the first staging
+    // loads therefore leave FIRST and the table rows right behind them (round 3; rounds 1-2 issued the rows first and the
+    // message loads only came back after them: "first attempt" 4-7 us on every level, time stamps of round 3).
+    auto issue_tables = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
         const int r = lane < total ? lane : total - 1;
         const int4 a = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL);
         const int4 b = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL + 4);
         trow[0] = a.x; trow[1] = a.y; trow[2] = a.z; trow[3] = a.w;
         trow[4] = b.x; trow[5] = b.y; trow[6] = b.z; trow[7] = b.w;
-    }
-    stamp[1] = __builtin_amdgcn_s_memrealtime();
+        JT_STAMP(1);
+    };
+    if constexpr (NIN == 0) issue_tables();
 
     // ---- stage incoming sub-boxes (summing partial copies), zero outgoing sub-boxes -----
-    // (the first element loads are already in flight).  Sub-boxes smaller than the workgroup
+    // (the first element loads leave behind the first round of message loads).  Sub-boxes smaller than the workgroup
     // split their partial copies over 256/n thread groups; the loads of ALL such messages are
     // issued together (one round trip to L2 for the whole staging), group sums are combined
     // through LDS in group order (deterministic).  Larger sub-boxes: one thread per entry.
     double *scratch = reinterpret_cast<double *>(smem + tk.itab_lds - JT_STAGE_SCRATCH * NIN);
     const double *msg_cur = msg_arena + fl.cur_off;
     uint64_t wait_t0 = 0;
-    int n_attempts = 0;
     for (int attempt = 0;; ++attempt) {
-        n_attempts = attempt + 1;
+        JT_STAMP_AT(13, attempt + 1);
         // (only in plans made of latency-bound levels, JtTask::settle: chains gain 6 %; next to streaming
         //  levels the extra loads of waiting workgroups cost 1-2 % - both measured)
         const int settle_attempt = tk.settle ? attempt : 0;
         const double *unready = nullptr;          // (FLOW) an entry this thread found not written yet
         {
-            const double *src[NIN > 0 ? NIN : 1];
-            int idx_t[NIN > 0 ? NIN : 1], gp0[NIN > 0 ? NIN : 1], gp1[NIN > 0 ? NIN : 1];
-            int64_t ps[NIN > 0 ? NIN : 1];
-            bool grouped[NIN > 0 ? NIN : 1], thr_mem[NIN > 0 ? NIN : 1];
-            double psum[NIN > 0 ? NIN : 1];
-            int maxper = 0;
+            // Every thread walks its loads of message k in a fixed order w = 0 .. W_k-1, all messages in lock step, GC loads
+            // per message in flight:
+            //   sub-box of >= 256 entries, or a single copy ("direct"): thread tid owns entries tid + 256 j; w = j * npart + p
+            //     runs over the copies p of entry j, then the next entry; an entry's sum is stored when its last copy is in;
+            //   smaller sub-box with several copies ("grouped"): 256 / n threads share an entry, thread group g sums copies
+            //     [g * per, (g + 1) * per); the group sums meet in LDS below.
+            // Every entry's copies are summed in ascending order from 0.0, group sums in group order: bit-reproducible, and the
+            // same sums as rounds 1-2.
+            constexpr int GC = NIN >= 3 ? 4 : 8;          // loads in flight per message (register budget)
+            const double *base[NI];
+            bool grouped[NI];
+            int W[NI], plog[NI], p0[NI], p1[NI], nent[NI];
+            double acc[NI];
+            int Wmax = 0;
 #pragma unroll
             for (int k = 0; k < NIN; ++k) {
-                const int nfree = sm_nfree[k];
-                const uint32_t fp[4] = {sm_fp[k][0], sm_fp[k][1], sm_fp[k][2], sm_fp[k][3]};
-                src[k] = msg_cur + sm_off[k];
-                ps[k] = sm_ps[k];
-                idx_t[k] = 0;
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (b < nfree) idx_t[k] += ((tid >> b) & 1) << JT_FPOS(fp, b);
-                thr_mem[k] = sm_same[k];
-                grouped[k] = nfree < 8 && sm_npart[k] > 1;
-                psum[k] = 0.0;
-                gp0[k] = gp1[k] = 0;
+                const int nfree = sm_nfree[k], npart = sm_npart[k];
+                base[k] = msg_cur + sm_off[k];
+                nent[k] = 1 << nfree;
+                grouped[k] = nfree < 8 && npart > 1;
+                plog[k] = 31 - __builtin_clz((unsigned)npart);          // (partial-copy counts are powers of two)
+                acc[k] = 0.0;
                 if (grouped[k]) {
                     const int groups = JT_THREADS >> nfree;   // >= 2
-                    const int per = (sm_npart[k] + groups - 1) / groups;
-                    gp0[k] = (tid >> nfree) * per;
-                    gp1[k] = (gp0[k] + per < sm_npart[k]) ? gp0[k] + per : sm_npart[k];
-                    maxper = per > maxper ? per : maxper;
+                    const int per = (npart + groups - 1) / groups;
+                    p0[k] = (tid >> nfree) * per;
+                    p1[k] = (p0[k] + per < npart) ? p0[k] + per : npart;
+                    W[k] = per;
                 } else {
-                    // One thread per entry and round of 256 entries, eight loads in flight per thread: eight entries
-                    // of a single-copy message, else 2^plog copies of 8 >> plog entries (a sub-box of 1024 single-copy
-                    // entries used to cost four dependent round trips, now one).  Every entry's copies are still
-                    // summed in ascending order from 0.0.
-                    double *sub = reinterpret_cast<double *>(smem + sm_lds[k]);
-                    const int n = 1 << nfree;
-                    const int npart = sm_npart[k];
-                    auto entry_at = [&](int it, int pc) {
-                        int idx = idx_t[k];
-#pragma unroll
-                        for (int b = 8; b < JT_MAX_FREE; ++b)
-                            if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
-                        return src[k] + ((int64_t)pc * ps[k] + idx);
-                    };
-                    if (npart == 1) {
-                        for (int it0 = 0; it0 * JT_THREADS < n; it0 += 8) {
-                            double c[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u)
-                                c[u] = (it0 + u) * JT_THREADS + tid < n ? jt_msg_load<FLOW>(entry_at(it0 + u, 0), thr_mem[k]) : 0.0;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                if ((it0 + u) * JT_THREADS + tid >= n) continue;
-                                if (FLOW) c[u] = jt_msg_settle<FLOW>(entry_at(it0 + u, 0), c[u], thr_mem[k], settle_attempt);
-                                if (FLOW && jt_unwritten(c[u])) unready = entry_at(it0 + u, 0);
-                                sub[(it0 + u) * JT_THREADS + tid] = 0.0 + c[u];
-                            }
-                        }
-                    } else {
-                        const int plog = npart >= 8 ? 3 : (npart >= 4 ? 2 : 1);
-                        const int pmask = (1 << plog) - 1, E = 8 >> plog;
-                        for (int it0 = 0; it0 * JT_THREADS < n; it0 += E) {
-                            double sum[4] = {0.0, 0.0, 0.0, 0.0};
-                            for (int p0 = 0; p0 < npart; p0 += 1 << plog) {
-                                double c[8];
-#pragma unroll
-                                for (int u = 0; u < 8; ++u) {
-                                    const int e = u >> plog, pc = p0 + (u & pmask);
-                                    const bool ok = (it0 + e) * JT_THREADS + tid < n && pc < npart;
-                                    c[u] = ok ? jt_msg_load<FLOW>(entry_at(it0 + e, pc), thr_mem[k]) : 0.0;
-                                }
-#pragma unroll
-                                for (int u = 0; u < 8; ++u) {
-                                    const int e = u >> plog, pc = p0 + (u & pmask);
-                                    const bool ok = (it0 + e) * JT_THREADS + tid < n && pc < npart;
-                                    if (FLOW && ok) c[u] = jt_msg_settle<FLOW>(entry_at(it0 + e, pc), c[u], thr_mem[k], settle_attempt);
-                                    if (FLOW && jt_unwritten(c[u])) unready = entry_at(it0 + e, pc);
-                                }
-                                // (plog is uniform: the entry a value belongs to is picked with compile-time indices)
-                                if (plog == 1) {
-#pragma unroll
-                                    for (int u = 0; u < 8; ++u) sum[u >> 1] += c[u];
-                                } else if (plog == 2) {
-#pragma unroll
-                                    for (int u = 0; u < 8; ++u) sum[u >> 2] += c[u];
-                                } else {
-#pragma unroll
-                                    for (int u = 0; u < 8; ++u) sum[0] += c[u];
-                                }
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (e < E && (it0 + e) * JT_THREADS + tid < n) sub[(it0 + e) * JT_THREADS + tid] = sum[e];
-                        }
-                    }
+                    p0[k] = p1[k] = 0;
+                    W[k] = ((nent[k] + JT_THREADS - 1) >> 8) << plog[k];
                 }
+                Wmax = W[k] > Wmax ? W[k] : Wmax;
             }
-            // grouped messages: every thread sums its range of copies of its entry, all messages at once
-            constexpr int GC = NIN >= 3 ? 4 : 8;          // copies in flight per message (register budget)
-            for (int p = 0; p < maxper; p += GC) {
-                double c[NIN > 0 ? NIN : 1][GC];
-#pragma unroll
-                for (int k = 0; k < NIN; ++k)
-#pragma unroll
-                    for (int u = 0; u < GC; ++u)
-                        c[k][u] = (grouped[k] && gp0[k] + p + u < gp1[k]) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]), thr_mem[k]) : 0.0;
-#pragma unroll
-                for (int k = 0; k < NIN; ++k)
+            // address of load w of message k, and whether this thread has such a load (GROUPED is decided per message, outside
+            // the loops over the loads: a branch between two loads would make the compiler wait for the first)
+            auto where = [&](auto k_tag, auto grouped_tag, const int w, bool &ok) -> const double * {
+                constexpr int k = decltype(k_tag)::value;
+                if constexpr (decltype(grouped_tag)::value) {
+                    const int p = p0[k] + w;
+                    ok = p < p1[k];
+                    return base[k] + ((int64_t)p * sm_ps[k] + sm_glo[k]);
+                } else {
+                    const int j = w >> plog[k], p = w & ((1 << plog[k]) - 1);
+                    ok = w < W[k] && (j << 8) + tid < nent[k];
+                    return base[k] + ((int64_t)p * sm_ps[k] + (uint32_t)__builtin_amdgcn_readlane((int)sm_hiv[k], j & 31)) + sm_glo[k];
+                }
+            };
+            for (int w0 = 0; w0 < Wmax; w0 += GC) {
+                double c[NI][GC];
+                auto issue_as = [&](auto k_tag, auto grouped_tag) {
+                    constexpr int k = decltype(k_tag)::value;
 #pragma unroll
                     for (int u = 0; u < GC; ++u) {
-                        if (FLOW && grouped[k] && gp0[k] + p + u < gp1[k])
-                            c[k][u] = jt_msg_settle<FLOW>(src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]), c[k][u], thr_mem[k], settle_attempt);
-                        psum[k] += c[k][u];
-                        if (FLOW && jt_unwritten(c[k][u])) unready = src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]);
+                        bool ok;
+                        const double *ptr = where(k_tag, grouped_tag, w0 + u, ok);
+                        c[k][u] = ok ? jt_msg_load<FLOW>(ptr, sm_same[k]) : 0.0;
                     }
+                };
+                auto issue = [&](auto k_tag) {
+                    if (grouped[decltype(k_tag)::value]) issue_as(k_tag, std::true_type{});
+                    else issue_as(k_tag, std::false_type{});
+                };
+                auto take_as = [&](auto k_tag, auto grouped_tag) {
+                    constexpr int k = decltype(k_tag)::value;
+                    constexpr bool GROUPED = decltype(grouped_tag)::value;
+                    double *sub = reinterpret_cast<double *>(smem + sm_lds[k]);
+#pragma unroll
+                    for (int u = 0; u < GC; ++u) {
+                        const int w = w0 + u;
+                        if constexpr (FLOW) {
+                            // (from the second attempt on, where the task asks for it: an entry still unwritten is loaded again
+                            //  in place for a little while, see jt_msg_settle)
+                            bool ok;
+                            const double *ptr = where(k_tag, grouped_tag, w, ok);
+                            if (ok) c[k][u] = jt_msg_settle<FLOW>(ptr, c[k][u], sm_same[k], settle_attempt);
+                            if (ok && jt_unwritten(c[k][u])) unready = ptr;
+                        }
+                        acc[k] += c[k][u];
+                        if constexpr (!GROUPED) {
+                            if ((w & ((1 << plog[k]) - 1)) == (1 << plog[k]) - 1 && w < W[k]) {     // (uniform) the entry's last copy
+                                const int i = ((w >> plog[k]) << 8) + tid;
+                                if (i < nent[k]) sub[i] = acc[k];
+                                acc[k] = 0.0;
+                            }
+                        }
+                    }
+                };
+                auto take = [&](auto k_tag) {
+                    if (grouped[decltype(k_tag)::value]) take_as(k_tag, std::true_type{});
+                    else take_as(k_tag, std::false_type{});
+                };
+                if constexpr (NIN > 0) issue(std::integral_constant<int, 0>{});
+                if constexpr (NIN > 1) issue(std::integral_constant<int, 1>{});
+                if constexpr (NIN > 2) issue(std::integral_constant<int, 2>{});
+                if constexpr (NIN > 3) issue(std::integral_constant<int, 3>{});
+                if (attempt == 0 && w0 == 0) issue_tables();
+                if constexpr (NIN > 0) take(std::integral_constant<int, 0>{});
+                if constexpr (NIN > 1) take(std::integral_constant<int, 1>{});
+                if constexpr (NIN > 2) take(std::integral_constant<int, 2>{});
+                if constexpr (NIN > 3) take(std::integral_constant<int, 3>{});
             }
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
-                if (grouped[k]) scratch[k * JT_THREADS + tid] = psum[k];
+                if (grouped[k]) scratch[k * JT_THREADS + tid] = acc[k];
         }
         if (attempt == 0) {
 #pragma unroll
@@ -368,6 +419,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 const int n = 1 << m.nfree;
                 for (int s = tid; s < n; s += JT_THREADS) sub[s] = 0.0;
             }
+            JT_STAMP(2);
         }
         if constexpr (!FLOW || NIN == 0) {
             __syncthreads();
@@ -415,6 +467,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                     }
                 }
                 flow_ctl[1] = give_up;
+                JT_STAMP(14);                                         // (the last poll's end: what follows is re-staging)
             }
             __syncthreads();
             if (flow_ctl[1] != 0) {
@@ -435,7 +488,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     }
     __syncthreads();
 
-    stamp[2] = __builtin_amdgcn_s_memrealtime();
+    JT_STAMP(3);
     // ---- per-thread constants ---------------------------------------------------------------
     int thr[NMSG > 0 ? NMSG : 1];
     const double *in_sub[NIN > 0 ? NIN : 1];
@@ -644,7 +697,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         }
     };
 
-    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    JT_STAMP(4);
     // Younger operations when iteration i is consumed: the U-1 later element loads, plus (distribute)
     // one belief store per step already executed since that load was issued: U of them in steady
     // state, k in step k of the first group (its loads were issued in the prologue, before any store).
@@ -652,11 +705,15 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     using std::integral_constant;
     {
         step(integral_constant<int, 0>{}, integral_constant<int, U - 1 + 0 * ST>{}, 0);
+        JT_STAMP(5);
         step(integral_constant<int, 1>{}, integral_constant<int, U - 1 + 1 * ST>{}, 1);
+        JT_STAMP(6);
         if (total > 2) {              // (a workgroup of two iterations - searched splits on latency-bound levels: the
                                       //  other slots hold repeats of its last row)
             step(integral_constant<int, 2>{}, integral_constant<int, U - 1 + 2 * ST>{}, 2);
+            JT_STAMP(7);
             step(integral_constant<int, 3>{}, integral_constant<int, U - 1 + 3 * ST>{}, 3);
+            JT_STAMP(8);
         }
         if constexpr (U == 8) {
             if (total > 4) {          // (a workgroup of four iterations: the other four slots hold repeats of its last row)
@@ -679,8 +736,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             step(integral_constant<int, 7 % U>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 7);
         }
     }
-    if (dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stamp[4] = __builtin_amdgcn_s_memrealtime();
+    JT_STAMP(9);
 
     // ---- flush outgoing sub-boxes as this chunk's partial copy ----------------------------------
     if constexpr (NOUT > 0) {
@@ -689,45 +745,44 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             return;
         }
         __syncthreads();
+        JT_STAMP(10);
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
             if constexpr (!EARLY_OUT) {
-                const JtMsg &m = tk.msg[JT_MAX_IN + j];
-                const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
-                so_at[j] = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
-                so_nfree[j] = m.nfree;
-                so_fp[j][0] = fpw[0], so_fp[j][1] = fpw[1], so_fp[j][2] = fpw[2], so_fp[j][3] = fpw[3];
+                uint32_t fp[4];
+                if (park != nullptr) {                     // parked in LDS at the start (dataflow kernels)
+                    so_at[j] = (int64_t)((uint64_t)park[8 * j + 0] | ((uint64_t)park[8 * j + 1] << 32));
+                    so_nfree[j] = (int)park[8 * j + 2];
+                    fp[0] = park[8 * j + 3], fp[1] = park[8 * j + 4], fp[2] = park[8 * j + 5], fp[3] = park[8 * j + 6];
+                } else {
+                    const JtMsg &m = tk.msg[JT_MAX_IN + j];
+                    const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
+                    so_at[j] = m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+                    so_nfree[j] = m.nfree;
+                    fp[0] = fpw[0], fp[1] = fpw[1], fp[2] = fpw[2], fp[3] = fpw[3];
+                }
+                so_glo[j] = jt_sub_lo(fp, so_nfree[j], tid);
+                so_hiv[j] = jt_sub_hi(fp, so_nfree[j], lane);
             }
             const int64_t at = so_at[j];
             double *dst = msg_arena + fl.cur_off + at + fl.out_shift;
             double *oth = msg_arena + fl.oth_off + at;          // the half the next propagate will use
             const bool mark = fl.oth_off >= 0;
-            const int nfree = so_nfree[j];
-            const int n = 1 << nfree;
-            const uint32_t fp[4] = {so_fp[j][0], so_fp[j][1], so_fp[j][2], so_fp[j][3]};
-            int idx_t = 0;
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-                if (b < nfree) idx_t += ((tid >> b) & 1) << JT_FPOS(fp, b);
+            const int n = 1 << so_nfree[j];
             for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
-                int idx = idx_t;
-#pragma unroll
-                for (int b = 8; b < JT_MAX_FREE; ++b)
-                    if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
+                const uint32_t idx = so_glo[j] + (uint32_t)__builtin_amdgcn_readlane((int)so_hiv[j], it);
                 jt_msg_store<FLOW>(dst + idx, out_sub[j][s]);
                 if (mark) oth[idx] = __longlong_as_double((long long)JT_UNWRITTEN);
             }
         }
     }
+    JT_STAMP(11);
+#ifdef JT_STAMPS
     if (dbg & 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp[5] = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            double *o = msg_arena + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * 8;
-            for (int i = 0; i < 6; ++i) o[i] = (double)stamp[i];
-            o[6] = (double)n_attempts;
-        }
+        JT_STAMP(12);
     }
+#endif
 }
 
 // Reduce task: entry i of the sum = the sum of the partial copies of entry i, JT_REDUCE_ENTRIES entries per
@@ -921,7 +976,7 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_collect_flow(const JtTask *_
                                                               const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                               const T *__restrict__ psi, T *__restrict__ bel,
                                                               double *__restrict__ msg, JtFlow fl) {
-    __shared__ uint32_t flow_ctl[28];
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];        // ticket, wait flags and candidates, parked flush records
     const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
@@ -962,6 +1017,46 @@ __device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict
     }
 }
 
+// Both phases in ONE launch (round 3; plans whose phases follow each other without an exchange in between, and whose
+// messages are small beside their tables - jtp_plan.cpp: finish()): the block list of the distribute phase simply
+// follows that of the collect phase, and the root's distribute workgroups wait for the last upward messages like any
+// other consumer.  Saves the second launch's cold start and the gap between the launches (~10 us of 620 on the width-20
+// tree); every message is then read through to memory (JtMsg::same_launch), also the upward messages the distribute
+// tasks read, because their producers ran in THIS launch.
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 4) void jt_propagate_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                                   const int *__restrict__ itab, const T *__restrict__ psi,
+                                                                   T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];
+    const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
+    const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
+    const JtBlock &bk = blk[ticket];
+    const JtTask &tk = tasks[bk.task];
+    if (tk.kind != 0) {
+        jt_reduce<true>(tk, bk, msg, fl);
+        return;
+    }
+    if (tk.mode == 0) {
+        switch (tk.n_in) {
+            case 0: jt_pass<T, 0, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+            case 1: jt_pass<T, 1, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+            case 2: jt_pass<T, 2, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+            default: jt_pass<T, 3, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        }
+        return;
+    }
+    switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
+        case 0: jt_pass<T, 0, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 1: jt_pass<T, 1, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 3: jt_pass<T, 3, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 4: jt_pass<T, 1, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 5: jt_pass<T, 2, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 6: jt_pass<T, 3, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        default: jt_pass<T, 4, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+    }
+}
+
 // Two builds of the distribute pass.  Compiled for four waves per SIMD (128 registers, a few spills) a CU holds four
 // workgroups instead of three and a third more table rows are in flight: config 4 0.4505 -> 0.4385 ms (A/B on one box).
 // On plans made of latency-bound levels (chains, JtTask::settle) the spills sit on the dependent path - config 2
@@ -971,7 +1066,7 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_distribute_flow(const JtTask
                                                                     const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                     const T *__restrict__ psi, T *__restrict__ bel,
                                                                     double *__restrict__ msg, JtFlow fl) {
-    __shared__ uint32_t flow_ctl[28];
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];        // ticket, wait flags and candidates, parked flush records
     jt_distribute_flow_body<T>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
 }
 
@@ -980,7 +1075,7 @@ __global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_flow_chain(const 
                                                                           const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                           const T *__restrict__ psi, T *__restrict__ bel,
                                                                           double *__restrict__ msg, JtFlow fl) {
-    __shared__ uint32_t flow_ctl[28];
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];        // ticket, wait flags and candidates, parked flush records
     jt_distribute_flow_body<T>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
 }
 
@@ -1021,10 +1116,13 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     const int total = tk.total;
     const int rmask = (1 << tk.nR) - 1;
     const int64_t sstride = fl.set_stride;
+#ifdef JT_STAMPS
+    const int dbg = blockIdx.y == 0 ? tk.debug : (tk.debug & ~2);                             // (time stamps of group 0 only)
+    double *stamp_out = msg0 + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * JT_NSTAMP;      // (as in jt_pass)
+#else
     const int dbg = tk.debug;
-    uint64_t stamp[6];
-    stamp[0] = __builtin_amdgcn_s_memrealtime();      // diagnostic time stamps (JTP_DEBUG=2), as in jt_pass
-    int n_attempts = 0;
+#endif
+    JT_STAMP(0);
 
     const int *gtab = itab + tk.itab_off;
     const T *psi0 = psi_arena + bk.psi_x0 + (uint32_t)tid * VEC;
@@ -1044,7 +1142,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
         trow[4] = b.x; trow[5] = b.y; trow[6] = b.z; trow[7] = b.w;
     }
 
-    stamp[1] = __builtin_amdgcn_s_memrealtime();
+    JT_STAMP(1);
     // evidence of the G sets on this clique, set s in lane s of a register pair (read after the first element
     // loads have left: the table is two dependent loads away; kept in vector registers: sixteen more scalars
     // live across the loop made hipcc spill scalars into it)
@@ -1060,7 +1158,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     const JtMsg &mo = tk.msg[JT_MAX_IN];
     uint64_t wait_t0 = 0;
     for (int attempt = 0;; ++attempt) {
-        n_attempts = attempt + 1;
+        JT_STAMP_AT(13, attempt + 1);
         const double *unready = nullptr;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
@@ -1151,7 +1249,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
         }
     }
 
-    stamp[2] = __builtin_amdgcn_s_memrealtime();
+    JT_STAMP(3);
     // ---- per-thread constants (read before the first store of the kernel, see jt_pass) ---------------
     int thr_in[NIN > 0 ? NIN : 1], in_lds[NIN > 0 ? NIN : 1], in_edep[NIN > 0 ? NIN : 1];
     int in_ew0[NIN > 0 ? NIN : 1], in_ew1[NIN > 0 ? NIN : 1];
@@ -1384,7 +1482,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
         if ((i & rmask) == rmask) epilogue(__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], i));
     };
 
-    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    JT_STAMP(4);
     using std::integral_constant;
     bool any_edep = false;
 #pragma unroll
@@ -1410,7 +1508,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
         else loop(integral_constant<bool, false>{}, integral_constant<bool, false>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the ring's last (repeated) loads land before LDS is given back
-    stamp[4] = __builtin_amdgcn_s_memrealtime();
+    JT_STAMP(9);
 
     // ---- flush every set's outgoing sub-box as this chunk's partial copy --------------------------------
     __syncthreads();
@@ -1430,15 +1528,13 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
             }
         }
     }
+    JT_STAMP(11);
+#ifdef JT_STAMPS
     if (dbg & 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp[5] = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0 && blockIdx.y == 0) {
-            double *o = msg0 + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * 8;
-            for (int i = 0; i < 6; ++i) o[i] = (double)stamp[i];
-            o[6] = (double)n_attempts;
-        }
+        JT_STAMP(12);
     }
+#endif
 }
 
 // Multi-set entry point: grid.y = group of JT_MSETS evidence sets; the block list is that of a whole phase
@@ -1448,7 +1544,7 @@ template <typename T>
 __global__ __launch_bounds__(JT_THREADS, 3) void jt_multi_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                             const int *__restrict__ itab, const T *__restrict__ psi,
                                                             T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
-    __shared__ uint32_t flow_ctl[28];
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];        // ticket, wait flags and candidates, parked flush records
     const uint32_t grp = blockIdx.y;
     fl.sync += (size_t)grp * fl.sync_stride;
     if (fl.ev != nullptr) fl.ev += (size_t)grp * JT_MSETS * fl.ev_stride;
@@ -1583,10 +1679,12 @@ __global__ __launch_bounds__(256) void jt_pack(JtPackDesc d, const S *__restrict
     }
 }
 
+#ifndef JT_INST_TU      // (the kernels that are not templates are defined in ONE translation unit: the engine's)
 // JTP_FAKE_COMM: stand-in for a received message
 __global__ __launch_bounds__(256) void jt_fill_value(double *__restrict__ dst, int64_t n, double v) {
     for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) dst[x] = v;
 }
+#endif
 
 // clique potential = product of factor tables, written in the clique's device layout
 // (CliqueGraph.evaluate for one clique, junctiontree/junctiontree.py:203-226)
@@ -1658,6 +1756,7 @@ __global__ __launch_bounds__(256) void jt_msg_unpack(JtPackDesc d, const double 
     }
 }
 
+#ifndef JT_INST_TU
 // batched marginal read-out: request blockIdx.y, entries strided over blockIdx.x
 __global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restrict__ descs, const double *__restrict__ scratch,
                                                       double *__restrict__ stage) {
@@ -1669,3 +1768,46 @@ __global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restri
         stage[m.dst_off + h] = u;
     }
 }
+#endif
+
+// ------------------------------------------------------------------------------------------
+// Explicit instantiation lists.  The message-passing kernels are compiled in translation units of their own, in parallel
+// (jtp_inst_*.hip: one family and storage type each; build.py), every other translation unit sees them as `extern template`:
+// one translation unit with everything took 3.5 minutes to compile.  X = `extern` or nothing.
+#define JT_KARGS(T) const JtTask *, const JtBlock *, const int *, const T *, T *, double *, JtFlow
+#define JT_INST_FLOW(X, T)                                                   \
+    X template __global__ void jt_collect_flow<T>(JT_KARGS(T));              \
+    X template __global__ void jt_distribute_flow<T>(JT_KARGS(T));           \
+    X template __global__ void jt_distribute_flow_chain<T>(JT_KARGS(T));
+#define JT_INST_LEVEL(X, T)                                                  \
+    X template __global__ void jt_collect_level<T>(JT_KARGS(T));             \
+    X template __global__ void jt_distribute_level<T>(JT_KARGS(T));          \
+    X template __global__ void jt_reduce_level<T>(JT_KARGS(T));              \
+    X template __global__ void jt_single<T>(JT_KARGS(T));
+#define JT_INST_SHAPE(X, T)                                                  \
+    X template __global__ void jt_collect<T, 0>(JT_KARGS(T));                \
+    X template __global__ void jt_collect<T, 1>(JT_KARGS(T));                \
+    X template __global__ void jt_collect<T, 2>(JT_KARGS(T));                \
+    X template __global__ void jt_collect<T, 3>(JT_KARGS(T));                \
+    X template __global__ void jt_distribute<T, 0, 0>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute<T, 0, 1>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute<T, 0, 2>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute<T, 0, 3>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute<T, 1, 0>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute<T, 1, 1>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute<T, 1, 2>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute<T, 1, 3>(JT_KARGS(T));
+#define JT_INST_MULTI(X, T) X template __global__ void jt_multi_flow<T>(JT_KARGS(T));
+#define JT_INST_BOTH(X, T) X template __global__ void jt_propagate_flow<T>(JT_KARGS(T));
+#ifndef JT_INST_TU
+JT_INST_FLOW(extern, float)
+JT_INST_FLOW(extern, double)
+JT_INST_LEVEL(extern, float)
+JT_INST_LEVEL(extern, double)
+JT_INST_SHAPE(extern, float)
+JT_INST_SHAPE(extern, double)
+JT_INST_MULTI(extern, float)
+JT_INST_MULTI(extern, double)
+JT_INST_BOTH(extern, float)
+JT_INST_BOTH(extern, double)
+#endif

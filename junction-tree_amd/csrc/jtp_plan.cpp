@@ -562,6 +562,7 @@ PlanKnobs jtp_read_knobs() {
     k.no_search = geti("JTP_NO_SEARCH", 0);
     k.search_all = geti("JTP_SEARCH_ALL", 1);
     k.roctx = geti("JTP_ROCTX", 0);
+    k.merge_phases = geti("JTP_MERGE_PHASES", -1);
     return k;
 }
 
@@ -1446,10 +1447,32 @@ int PlanBuilder::messages() {
         }
         hp.msg_doubles = (hp.msg_doubles + 1) & ~(int64_t)1;
     }
+    // who writes what each task reads (finish() turns it into JtMsg::same_launch once the launches are known)
+    hp.task_producers.assign(hp.tasks.size(), std::vector<int>());
+    auto up_producer = [&](const PSep &sp) { return sp.up_red_task >= 0 ? sp.up_red_task : hp.pn[sp.child].collect_task; };
+    auto dn_producer = [&](const PSep &sp) {
+        if (sp.dn_red_task >= 0) return sp.dn_red_task;
+        return hp.multiset ? sp.dn_task : hp.pn[sp.parent].distribute_task;
+    };
+    for (const PSep &sp : hp.ps) {
+        if (sp.up_red_task >= 0) hp.task_producers[sp.up_red_task] = {hp.pn[sp.child].collect_task};
+        if (sp.dn_red_task >= 0) hp.task_producers[sp.dn_red_task] = {hp.multiset ? sp.dn_task : hp.pn[sp.parent].distribute_task};
+    }
     for (size_t t = 0; t < hp.tasks.size(); ++t) {
         JtTask &tk = hp.tasks[t];
         if (tk.kind != 0) continue;
         const PNode &p = hp.pn[tk.pnode];
+        {
+            std::vector<int> &prod = hp.task_producers[t];
+            const bool collect_task = (int)t == p.collect_task;
+            size_t skip = p.children.size();                     // multi-set plans: the child a downward-message task serves
+            if (hp.multiset && !collect_task)
+                for (size_t j = 0; j < p.down_tasks.size(); ++j)
+                    if (p.down_tasks[j] == (int)t) skip = j;
+            if (!collect_task && p.psep >= 0) prod.push_back(dn_producer(hp.ps[p.psep]));
+            for (size_t i = 0; i < p.children.size(); ++i)
+                if (i != skip) prod.push_back(up_producer(hp.ps[hp.pn[p.children[i]].psep]));
+        }
         if (hp.multiset && (int)t != p.collect_task) {          // a downward-message task: which child?
             size_t j = 0;
             while (j < p.down_tasks.size() && p.down_tasks[j] != (int)t) ++j;
@@ -1683,10 +1706,56 @@ int PlanBuilder::finish() {
         sg.nblocks += L.nblocks;
         sg.lds_bytes = std::max(sg.lds_bytes, L.lds_bytes);
     }
+    // Both phases in one launch (jt_propagate_flow): where the distribute segment follows the collect segment directly (no
+    // exchange in between) and the messages are small beside the tables - every message of a merged launch is read
+    // through to memory, which costs where staging is a large share of the traffic (config 3) and buys nothing on chains.
+    {
+        const bool merge = hp.knobs.merge_phases == 1 ||
+                           (hp.knobs.merge_phases < 0 && !hp.multiset && !hp.chain_plan && hp.staging_bytes * 8.0 <= hp.table_bytes);
+        if (merge && !hp.multiset) {
+            std::vector<Segment> segs;
+            std::vector<Step> fsteps;
+            for (const Step &st : hp.flow_steps) {
+                if (st.kind == 0 && !fsteps.empty() && fsteps.back().kind == 0 && segs.back().phase == 0 && hp.segments[st.first].phase == 1) {
+                    const Segment &b = hp.segments[st.first];
+                    Segment &a = segs.back();
+                    a.phase = 2;
+                    a.n_launch += b.n_launch;
+                    a.nblocks += b.nblocks;
+                    a.lds_bytes = std::max(a.lds_bytes, b.lds_bytes);
+                    continue;
+                }
+                Step fs = st;
+                if (st.kind == 0) {
+                    fs.first = (int)segs.size();
+                    segs.push_back(hp.segments[st.first]);
+                    segs.back().ticket_idx = JT_SYNC_HDR + (int)segs.size() - 1;
+                }
+                fsteps.push_back(fs);
+            }
+            hp.segments = segs;
+            hp.flow_steps = fsteps;
+        }
+    }
+    // JtMsg::same_launch: the producer of an incoming message runs in the same dataflow launch as its consumer - then the
+    // consumer reads the entries through to memory and waits on their "unwritten" markers; messages finished by an earlier
+    // launch (or received by an exchange) are read with ordinary loads.
+    {
+        std::vector<int> seg_of(hp.tasks.size(), -1);
+        for (size_t g = 0; g < hp.segments.size(); ++g)
+            for (int i = hp.segments[g].first_launch; i < hp.segments[g].first_launch + hp.segments[g].n_launch; ++i)
+                for (int t : hp.launches[i].tasks) seg_of[t] = (int)g;
+        for (size_t t = 0; t < hp.tasks.size(); ++t) {
+            JtTask &tk = hp.tasks[t];
+            const std::vector<int> &prod = hp.task_producers[t];
+            for (int k = 0; k < tk.n_in && k < (int)prod.size(); ++k)
+                tk.msg[k].same_launch = (prod[k] >= 0 && seg_of[t] >= 0 && seg_of[prod[k]] == seg_of[t]) ? 1 : 0;
+        }
+    }
     hp.sync_words = JT_SYNC_HDR + (int)hp.segments.size();
-    if (hp.knobs.debug & 2) {     // time-stamp region, 8 doubles per workgroup
+    if (hp.knobs.debug & 2) {     // time-stamp region, JT_NSTAMP doubles per workgroup (+ one spare set), for -DJT_STAMPS builds
         hp.dbg_base = hp.msg_doubles;
-        hp.msg_doubles += (int64_t)hp.blocks.size() * 8;
+        hp.msg_doubles += ((int64_t)hp.blocks.size() + 1) * 16;
         for (const Launch &L : hp.launches)
             for (int t : L.tasks) hp.tasks[t].dbg_off = hp.dbg_base;
     }

@@ -74,7 +74,7 @@ struct Step {
 // Dataflow schedule: consecutive launches of one phase run as ONE launch whose workgroups take
 // their place in the block list from a ticket counter and wait on message completion counters.
 struct Segment {
-    int phase = 0;
+    int phase = 0;                   // 0 collect, 1 distribute, 2 both (the distribute block list behind the collect one)
     int first_launch = 0, n_launch = 0;
     int64_t blk_off = 0;
     int nblocks = 0;
@@ -105,6 +105,7 @@ struct PlanKnobs {
     int search_all = 1;                                             // JTP_SEARCH_ALL=0: the search only where policy 2 would have been chosen (else policy 3 stays)
     int no_search = 0;                                              // JTP_NO_SEARCH: layout policy 2 where the cost-model search (policy 4) would run
     int roctx = 0;                                                  // JTP_ROCTX: roctx ranges around propagates and read-outs
+    int merge_phases = -1;                                          // JTP_MERGE_PHASES: 1 / 0 = both phases in one dataflow launch / never; -1: where messages are small
 };
 PlanKnobs jtp_read_knobs();
 
@@ -125,6 +126,7 @@ struct HostPlan {
     std::vector<PSep> ps;
     std::vector<int> sep_of_node;    // caller's separator node -> psep (size n_nodes, -1 for cliques)
     std::vector<JtTask> tasks;
+    std::vector<std::vector<int>> task_producers;   // per task and incoming message: the task that writes what the consumer reads (-1: another rank)
     std::vector<int> task_variant;
     std::vector<Launch> launches;
     std::vector<JtBlock> blocks;

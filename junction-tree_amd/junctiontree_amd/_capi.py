@@ -21,7 +21,7 @@ JTP_SHARE_POTENTIALS = 32
 JTP_FLOW_TICKETS = 16
 JTP_MULTISET = 64
 JTP_NO_COMPACT = 128
-N_VARIANTS = 20
+N_VARIANTS = 21
 
 
 class TreeDesc(C.Structure):

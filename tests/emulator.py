@@ -282,7 +282,7 @@ class Emulator:
                 continue
             seg = d["segments"][first]
             launches = d["launches"][seg["first_launch"]:seg["first_launch"] + seg["n_launch"]]
-            assert all(L["phase"] == seg["phase"] for L in launches)
+            assert all(L["phase"] == seg["phase"] for L in launches) or (seg["phase"] == 2 and [L["phase"] for L in launches] == sorted(L["phase"] for L in launches))
             assert seg["blk_off"] == launches[0]["blk_off"] and seg["nblocks"] == sum(L["nblocks"] for L in launches)
             assert seg["lds_bytes"] == max(L["lds_bytes"] for L in launches)
             assert all(d["tasks"][t]["kind"] == (1 if L["variant"] == 16 else 0) for L in launches for t in L["tasks"])

@@ -1,19 +1,17 @@
 """Diagnostic: JTP_DEBUG=2 python tools/stamps_blocks.py [sets] -> the slowest workgroups of the multi-set leaf level."""
-import ctypes as C, os, sys
+import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
-from junctiontree_amd import _capi, engine, synthetic
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _stamps
+from junctiontree_amd import engine, synthetic
 spec = synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0)
 multi = len(sys.argv) > 1
 plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", multiset=multi, n_batch=int(sys.argv[1]) if multi else 1)
 plan.fill_synthetic(1, spec["scales"])
 for _ in range(3):
     plan.propagate()
-d = plan.describe()
-base, nb = d["dbg_base"], d["n_blocks"]
-buf = np.empty(nb * 8)
-_capi.check(plan._lib.jtp_debug_read_msg(plan._handle, 0, base, nb * 8, buf.ctypes.data_as(C.POINTER(C.c_double))))
-st = buf.reshape(nb, 8)[:, :6] * 0.01
+d, full = _stamps.read(plan)
+st = _stamps.coarse(full)
 for L in d["launches"][:4]:
     if L["variant"] == 16:
         continue

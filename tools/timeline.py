@@ -1,9 +1,10 @@
 """Diagnostic: JTP_DEBUG=2 python tools/timeline.py [multi SETS | single] -> what the resident workgroups of a dataflow
 launch are doing over time (10 us bins): staging / waiting for producers, looping, flushing; per phase."""
-import ctypes as C, os, sys
+import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
-from junctiontree_amd import _capi, engine, synthetic
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _stamps
+from junctiontree_amd import engine, synthetic
 multi = len(sys.argv) > 1 and sys.argv[1] == "multi"
 if len(sys.argv) > 1 and sys.argv[1] == "c3":          # BASELINE config 3, shortened: 6 x W lattice, cardinality 8
     import junctiontree_amd as jt
@@ -25,11 +26,8 @@ else:
 plan.fill_synthetic(1, spec["scales"])
 for _ in range(3):
     plan.propagate()
-d = plan.describe()
-base, nb = d["dbg_base"], d["n_blocks"]
-buf = np.empty(nb * 8)
-_capi.check(plan._lib.jtp_debug_read_msg(plan._handle, 0, base, nb * 8, buf.ctypes.data_as(C.POINTER(C.c_double))))
-st = buf.reshape(nb, 8)[:, :6] * 0.01
+d, full = _stamps.read(plan)
+st = _stamps.coarse(full)
 kind = np.array([d["tasks"][b[0]]["kind"] for b in d["blocks"]])
 BIN = float(os.environ.get("TIMELINE_BIN", "10"))
 for ph in (0, 1):
