@@ -47,7 +47,8 @@ template <> struct JtVec<double> { using type = double2; };
 // vmcnt themselves (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void jt_dma16(const void *gsrc, uint32_t lds_dst) {
     unsigned keep;
-#ifdef JT_TABLE_NT          // (A/B builds) non-temporal policy on the table stream: rows are read once per phase by one CU
+#ifndef JT_TABLE_NO_NT       // non-temporal policy on the table stream (rows are read once per phase, by one CU): config 4 0.610 ->
+                            // 0.5975 ms, A/B on one box over three runs each; -DJT_TABLE_NO_NT builds the default-policy loads
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
@@ -141,11 +142,11 @@ __device__ __forceinline__ double jt_msg_settle(const double *p, double v, bool 
 
 
 // Where entry i of a workgroup's sub-box of a message lives in the message: the sub-box index is a bit-deposit of i into the
-// message's index (bit b of i lands on message bit free_pos[b]).  The deposit is linear over disjoint bit groups, so it is
-// split once per message into the part of a thread's own low eight index bits (jt_sub_lo: a vector value) and a 32-row table
-// of the bits above them, row j in lane j (jt_sub_hi, read with v_readlane): an entry's address then costs one add, where
-// rounds 1-2 walked up to 13 bits for every single load (the staging code ran to thousands of instructions per thread -
-// 4-6 us per workgroup, on every level, measured with the time stamps of round 3).
+// message's index (bit b of i lands on message bit free_pos[b]).  The deposit is linear over disjoint bit groups, so the flush
+// splits it once per outgoing message into the part of a thread's own low eight index bits (jt_sub_lo: a vector value) and a
+// 32-row table of the bits above them, row j in lane j (jt_sub_hi, read with v_readlane): an entry's address costs one add.
+// (Round 3 also rebuilt the STAGING loop on this split, every message in lock step: fewer instructions by far, and slower on
+//  every config - 2 % on config 4, 1.5 % on config 3, 12 % on config 2, A/B on one box - so staging keeps the loop of round 2.)
 __device__ __forceinline__ uint32_t jt_sub_lo(const uint32_t (&fp)[4], int nfree, int i) {
     uint32_t g = 0;
 #pragma unroll
@@ -161,7 +162,7 @@ __device__ __forceinline__ uint32_t jt_sub_hi(const uint32_t (&fp)[4], int nfree
     return g;
 }
 
-template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false>
+template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0)>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
                                         double *__restrict__ msg_arena, const JtFlow &fl,
@@ -195,7 +196,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     int64_t sm_off[NI], sm_ps[NI];
     int sm_npart[NI], sm_nfree[NI], sm_lds[NI];
     bool sm_same[NI];
-    uint32_t sm_glo[NI], sm_hiv[NI];                   // where this thread's sub-box entries lie in the message (jt_sub_lo / jt_sub_hi)
+    uint32_t sm_fp[NI][4];
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         const JtMsg &m = tk.msg[k];
@@ -207,18 +208,17 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         sm_nfree[k] = m.nfree;
         sm_lds[k] = m.lds_off;
         sm_same[k] = m.same_launch != 0;
-        sm_glo[k] = jt_sub_lo(fp, m.nfree, tid);       // (sub-boxes below 256 entries: the entry of thread tid mod 2^nfree)
-        sm_hiv[k] = jt_sub_hi(fp, m.nfree, lane);
+        sm_fp[k][0] = fp[0], sm_fp[k][1] = fp[1], sm_fp[k][2] = fp[2], sm_fp[k][3] = fp[3];
     }
     // ... and what the flush needs.  Collect pass: kept in registers (read after the loop these are one more dependent round
     // trip on the hand-over to the parent: config 2 collect 2.52 -> 2.40 ms).  Distribute pass: the registers they would occupy
     // through the loop cost more (spills) than they save, so lane 0 parks the few words in LDS (flow_ctl) and the flush reads
     // them back from there - round 2 read the task record again, a dependent trip to memory of 1.0-1.6 us in front of the
     // stores of every hand-over.
-    constexpr bool EARLY_OUT = MODE == 0;
+    constexpr bool EARLY_OUT = EARLY_FLUSH;      // (the chain build of the distribute pass has the registers too)
     int64_t so_at[NO];
     int so_nfree[NO];
-    uint32_t so_glo[NO], so_hiv[NO];
+    uint32_t so_glo[NO], so_hiv[NO], so_fp[NO][4];
     uint32_t *park = flow_ctl != nullptr ? flow_ctl + 28 : nullptr;       // [NOUT][8]: at (2 words), nfree, free_pos (4 words)
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) {
@@ -229,8 +229,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         if constexpr (EARLY_OUT) {
             so_at[j] = at;
             so_nfree[j] = m.nfree;
-            so_glo[j] = jt_sub_lo(fp, m.nfree, tid);
-            so_hiv[j] = jt_sub_hi(fp, m.nfree, lane);
+            so_fp[j][0] = fp[0], so_fp[j][1] = fp[1], so_fp[j][2] = fp[2], so_fp[j][3] = fp[3];
         } else if (park != nullptr && tid == 0) {
             park[8 * j + 0] = (uint32_t)at, park[8 * j + 1] = (uint32_t)((uint64_t)at >> 32), park[8 * j + 2] = (uint32_t)m.nfree;
             park[8 * j + 3] = fp[0], park[8 * j + 4] = fp[1], park[8 * j + 5] = fp[2], park[8 * j + 6] = fp[3];
@@ -273,10 +272,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // row r in lane r; a step reads "row i, column c" with v_readlane: no memory latency on the
     // critical path of a step except the message entries themselves.
     int trow[JT_NCOL];
-    // Vector-memory operations return in issue order (s_waitcnt vmcnt counts them together), so whatever is issued BEHIND the
-    // first table rows waits for them - a cold trip to HBM - before it can be used.  With incoming messages the first staging
-    // loads therefore leave FIRST and the table rows right behind them (round 3; rounds 1-2 issued the rows first and the
-    // message loads only came back after them: "first attempt" 4-7 us on every level, time stamps of round 3).
+    // (Vector-memory operations return in issue order, so the staging loads issued behind the first table rows only come
+    //  back after them.  Issuing the first round of message loads AHEAD of the rows was tried in round 3: config 4 +-0,
+    //  config 3 - whose staging loads are a quarter of its traffic - 12.5 -> 13.1 ms, A/B on one box: the rows go first.)
     auto issue_tables = [&]() {
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -288,7 +286,16 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         trow[4] = b.x; trow[5] = b.y; trow[6] = b.z; trow[7] = b.w;
         JT_STAMP(1);
     };
-    if constexpr (NIN == 0) issue_tables();
+    issue_tables();
+#ifndef JT_OLD_FLUSH
+    if constexpr (EARLY_OUT) {
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) {
+            so_glo[j] = jt_sub_lo(so_fp[j], so_nfree[j], tid);
+            so_hiv[j] = jt_sub_hi(so_fp[j], so_nfree[j], lane);
+        }
+    }
+#endif
 
     // ---- stage incoming sub-boxes (summing partial copies), zero outgoing sub-boxes -----
     // (the first element loads leave behind the first round of message loads).  Sub-boxes smaller than the workgroup
@@ -305,111 +312,122 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         const int settle_attempt = tk.settle ? attempt : 0;
         const double *unready = nullptr;          // (FLOW) an entry this thread found not written yet
         {
-            // Every thread walks its loads of message k in a fixed order w = 0 .. W_k-1, all messages in lock step, GC loads
-            // per message in flight:
-            //   sub-box of >= 256 entries, or a single copy ("direct"): thread tid owns entries tid + 256 j; w = j * npart + p
-            //     runs over the copies p of entry j, then the next entry; an entry's sum is stored when its last copy is in;
-            //   smaller sub-box with several copies ("grouped"): 256 / n threads share an entry, thread group g sums copies
-            //     [g * per, (g + 1) * per); the group sums meet in LDS below.
-            // Every entry's copies are summed in ascending order from 0.0, group sums in group order: bit-reproducible, and the
-            // same sums as rounds 1-2.
-            constexpr int GC = NIN >= 3 ? 4 : 8;          // loads in flight per message (register budget)
-            const double *base[NI];
-            bool grouped[NI];
-            int W[NI], plog[NI], p0[NI], p1[NI], nent[NI];
-            double acc[NI];
-            int Wmax = 0;
+            const double *src[NIN > 0 ? NIN : 1];
+            int idx_t[NIN > 0 ? NIN : 1], gp0[NIN > 0 ? NIN : 1], gp1[NIN > 0 ? NIN : 1];
+            int64_t ps[NIN > 0 ? NIN : 1];
+            bool grouped[NIN > 0 ? NIN : 1], thr_mem[NIN > 0 ? NIN : 1];
+            double psum[NIN > 0 ? NIN : 1];
+            int maxper = 0;
 #pragma unroll
             for (int k = 0; k < NIN; ++k) {
-                const int nfree = sm_nfree[k], npart = sm_npart[k];
-                base[k] = msg_cur + sm_off[k];
-                nent[k] = 1 << nfree;
-                grouped[k] = nfree < 8 && npart > 1;
-                plog[k] = 31 - __builtin_clz((unsigned)npart);          // (partial-copy counts are powers of two)
-                acc[k] = 0.0;
+                const int nfree = sm_nfree[k];
+                const uint32_t fp[4] = {sm_fp[k][0], sm_fp[k][1], sm_fp[k][2], sm_fp[k][3]};
+                src[k] = msg_cur + sm_off[k];
+                ps[k] = sm_ps[k];
+                idx_t[k] = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (b < nfree) idx_t[k] += ((tid >> b) & 1) << JT_FPOS(fp, b);
+                thr_mem[k] = sm_same[k];
+                grouped[k] = nfree < 8 && sm_npart[k] > 1;
+                psum[k] = 0.0;
+                gp0[k] = gp1[k] = 0;
                 if (grouped[k]) {
                     const int groups = JT_THREADS >> nfree;   // >= 2
-                    const int per = (npart + groups - 1) / groups;
-                    p0[k] = (tid >> nfree) * per;
-                    p1[k] = (p0[k] + per < npart) ? p0[k] + per : npart;
-                    W[k] = per;
+                    const int per = (sm_npart[k] + groups - 1) / groups;
+                    gp0[k] = (tid >> nfree) * per;
+                    gp1[k] = (gp0[k] + per < sm_npart[k]) ? gp0[k] + per : sm_npart[k];
+                    maxper = per > maxper ? per : maxper;
                 } else {
-                    p0[k] = p1[k] = 0;
-                    W[k] = ((nent[k] + JT_THREADS - 1) >> 8) << plog[k];
-                }
-                Wmax = W[k] > Wmax ? W[k] : Wmax;
-            }
-            // address of load w of message k, and whether this thread has such a load (GROUPED is decided per message, outside
-            // the loops over the loads: a branch between two loads would make the compiler wait for the first)
-            auto where = [&](auto k_tag, auto grouped_tag, const int w, bool &ok) -> const double * {
-                constexpr int k = decltype(k_tag)::value;
-                if constexpr (decltype(grouped_tag)::value) {
-                    const int p = p0[k] + w;
-                    ok = p < p1[k];
-                    return base[k] + ((int64_t)p * sm_ps[k] + sm_glo[k]);
-                } else {
-                    const int j = w >> plog[k], p = w & ((1 << plog[k]) - 1);
-                    ok = w < W[k] && (j << 8) + tid < nent[k];
-                    return base[k] + ((int64_t)p * sm_ps[k] + (uint32_t)__builtin_amdgcn_readlane((int)sm_hiv[k], j & 31)) + sm_glo[k];
-                }
-            };
-            for (int w0 = 0; w0 < Wmax; w0 += GC) {
-                double c[NI][GC];
-                auto issue_as = [&](auto k_tag, auto grouped_tag) {
-                    constexpr int k = decltype(k_tag)::value;
-#pragma unroll
-                    for (int u = 0; u < GC; ++u) {
-                        bool ok;
-                        const double *ptr = where(k_tag, grouped_tag, w0 + u, ok);
-                        c[k][u] = ok ? jt_msg_load<FLOW>(ptr, sm_same[k]) : 0.0;
-                    }
-                };
-                auto issue = [&](auto k_tag) {
-                    if (grouped[decltype(k_tag)::value]) issue_as(k_tag, std::true_type{});
-                    else issue_as(k_tag, std::false_type{});
-                };
-                auto take_as = [&](auto k_tag, auto grouped_tag) {
-                    constexpr int k = decltype(k_tag)::value;
-                    constexpr bool GROUPED = decltype(grouped_tag)::value;
+                    // One thread per entry and round of 256 entries, eight loads in flight per thread: eight entries
+                    // of a single-copy message, else 2^plog copies of 8 >> plog entries (a sub-box of 1024 single-copy
+                    // entries used to cost four dependent round trips, now one).  Every entry's copies are still
+                    // summed in ascending order from 0.0.
                     double *sub = reinterpret_cast<double *>(smem + sm_lds[k]);
+                    const int n = 1 << nfree;
+                    const int npart = sm_npart[k];
+                    auto entry_at = [&](int it, int pc) {
+                        int idx = idx_t[k];
 #pragma unroll
-                    for (int u = 0; u < GC; ++u) {
-                        const int w = w0 + u;
-                        if constexpr (FLOW) {
-                            // (from the second attempt on, where the task asks for it: an entry still unwritten is loaded again
-                            //  in place for a little while, see jt_msg_settle)
-                            bool ok;
-                            const double *ptr = where(k_tag, grouped_tag, w, ok);
-                            if (ok) c[k][u] = jt_msg_settle<FLOW>(ptr, c[k][u], sm_same[k], settle_attempt);
-                            if (ok && jt_unwritten(c[k][u])) unready = ptr;
-                        }
-                        acc[k] += c[k][u];
-                        if constexpr (!GROUPED) {
-                            if ((w & ((1 << plog[k]) - 1)) == (1 << plog[k]) - 1 && w < W[k]) {     // (uniform) the entry's last copy
-                                const int i = ((w >> plog[k]) << 8) + tid;
-                                if (i < nent[k]) sub[i] = acc[k];
-                                acc[k] = 0.0;
+                        for (int b = 8; b < JT_MAX_FREE; ++b)
+                            if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
+                        return src[k] + ((int64_t)pc * ps[k] + idx);
+                    };
+                    if (npart == 1) {
+                        for (int it0 = 0; it0 * JT_THREADS < n; it0 += 8) {
+                            double c[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                c[u] = (it0 + u) * JT_THREADS + tid < n ? jt_msg_load<FLOW>(entry_at(it0 + u, 0), thr_mem[k]) : 0.0;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                if ((it0 + u) * JT_THREADS + tid >= n) continue;
+                                if (FLOW) c[u] = jt_msg_settle<FLOW>(entry_at(it0 + u, 0), c[u], thr_mem[k], settle_attempt);
+                                if (FLOW && jt_unwritten(c[u])) unready = entry_at(it0 + u, 0);
+                                sub[(it0 + u) * JT_THREADS + tid] = 0.0 + c[u];
                             }
                         }
+                    } else {
+                        const int plog = npart >= 8 ? 3 : (npart >= 4 ? 2 : 1);
+                        const int pmask = (1 << plog) - 1, E = 8 >> plog;
+                        for (int it0 = 0; it0 * JT_THREADS < n; it0 += E) {
+                            double sum[4] = {0.0, 0.0, 0.0, 0.0};
+                            for (int p0 = 0; p0 < npart; p0 += 1 << plog) {
+                                double c[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int e = u >> plog, pc = p0 + (u & pmask);
+                                    const bool ok = (it0 + e) * JT_THREADS + tid < n && pc < npart;
+                                    c[u] = ok ? jt_msg_load<FLOW>(entry_at(it0 + e, pc), thr_mem[k]) : 0.0;
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int e = u >> plog, pc = p0 + (u & pmask);
+                                    const bool ok = (it0 + e) * JT_THREADS + tid < n && pc < npart;
+                                    if (FLOW && ok) c[u] = jt_msg_settle<FLOW>(entry_at(it0 + e, pc), c[u], thr_mem[k], settle_attempt);
+                                    if (FLOW && jt_unwritten(c[u])) unready = entry_at(it0 + e, pc);
+                                }
+                                // (plog is uniform: the entry a value belongs to is picked with compile-time indices)
+                                if (plog == 1) {
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) sum[u >> 1] += c[u];
+                                } else if (plog == 2) {
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) sum[u >> 2] += c[u];
+                                } else {
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) sum[0] += c[u];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (e < E && (it0 + e) * JT_THREADS + tid < n) sub[(it0 + e) * JT_THREADS + tid] = sum[e];
+                        }
                     }
-                };
-                auto take = [&](auto k_tag) {
-                    if (grouped[decltype(k_tag)::value]) take_as(k_tag, std::true_type{});
-                    else take_as(k_tag, std::false_type{});
-                };
-                if constexpr (NIN > 0) issue(std::integral_constant<int, 0>{});
-                if constexpr (NIN > 1) issue(std::integral_constant<int, 1>{});
-                if constexpr (NIN > 2) issue(std::integral_constant<int, 2>{});
-                if constexpr (NIN > 3) issue(std::integral_constant<int, 3>{});
-                if (attempt == 0 && w0 == 0) issue_tables();
-                if constexpr (NIN > 0) take(std::integral_constant<int, 0>{});
-                if constexpr (NIN > 1) take(std::integral_constant<int, 1>{});
-                if constexpr (NIN > 2) take(std::integral_constant<int, 2>{});
-                if constexpr (NIN > 3) take(std::integral_constant<int, 3>{});
+                }
+            }
+            // grouped messages: every thread sums its range of copies of its entry, all messages at once
+            constexpr int GC = NIN >= 3 ? 4 : 8;          // copies in flight per message (register budget)
+            for (int p = 0; p < maxper; p += GC) {
+                double c[NIN > 0 ? NIN : 1][GC];
+#pragma unroll
+                for (int k = 0; k < NIN; ++k)
+#pragma unroll
+                    for (int u = 0; u < GC; ++u)
+                        c[k][u] = (grouped[k] && gp0[k] + p + u < gp1[k]) ? jt_msg_load<FLOW>(src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]), thr_mem[k]) : 0.0;
+#pragma unroll
+                for (int k = 0; k < NIN; ++k)
+#pragma unroll
+                    for (int u = 0; u < GC; ++u) {
+                        if (FLOW && grouped[k] && gp0[k] + p + u < gp1[k])
+                            c[k][u] = jt_msg_settle<FLOW>(src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]), c[k][u], thr_mem[k], settle_attempt);
+                        psum[k] += c[k][u];
+                        if (FLOW && jt_unwritten(c[k][u])) unready = src[k] + ((int64_t)(gp0[k] + p + u) * ps[k] + idx_t[k]);
+                    }
             }
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
-                if (grouped[k]) scratch[k * JT_THREADS + tid] = acc[k];
+                if (grouped[k]) scratch[k * JT_THREADS + tid] = psum[k];
         }
         if (attempt == 0) {
 #pragma unroll
@@ -750,10 +768,11 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         for (int j = 0; j < NOUT; ++j) {
             if constexpr (!EARLY_OUT) {
                 uint32_t fp[4];
-                if (park != nullptr) {                     // parked in LDS at the start (dataflow kernels)
-                    so_at[j] = (int64_t)((uint64_t)park[8 * j + 0] | ((uint64_t)park[8 * j + 1] << 32));
-                    so_nfree[j] = (int)park[8 * j + 2];
-                    fp[0] = park[8 * j + 3], fp[1] = park[8 * j + 4], fp[2] = park[8 * j + 5], fp[3] = park[8 * j + 6];
+                if (park != nullptr) {                     // parked in LDS at the start (dataflow kernels); uniform: back into scalars
+                    auto word = [&](int i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)park[8 * j + i]); };
+                    so_at[j] = (int64_t)((uint64_t)word(0) | ((uint64_t)word(1) << 32));
+                    so_nfree[j] = (int)word(2);
+                    fp[0] = word(3), fp[1] = word(4), fp[2] = word(5), fp[3] = word(6);
                 } else {
                     const JtMsg &m = tk.msg[JT_MAX_IN + j];
                     const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
@@ -769,6 +788,25 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             double *oth = msg_arena + fl.oth_off + at;          // the half the next propagate will use
             const bool mark = fl.oth_off >= 0;
             const int n = 1 << so_nfree[j];
+#ifdef JT_OLD_FLUSH
+            if constexpr (EARLY_OUT) {
+                const int nfree = so_nfree[j];
+                const uint32_t fp[4] = {so_fp[j][0], so_fp[j][1], so_fp[j][2], so_fp[j][3]};
+                int idx_t = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (b < nfree) idx_t += ((tid >> b) & 1) << JT_FPOS(fp, b);
+                for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
+                    int idx = idx_t;
+#pragma unroll
+                    for (int b = 8; b < JT_MAX_FREE; ++b)
+                        if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
+                    jt_msg_store<FLOW>(dst + idx, out_sub[j][s]);
+                    if (mark) oth[idx] = __longlong_as_double((long long)JT_UNWRITTEN);
+                }
+                continue;
+            }
+#endif
             for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
                 const uint32_t idx = so_glo[j] + (uint32_t)__builtin_amdgcn_readlane((int)so_hiv[j], it);
                 jt_msg_store<FLOW>(dst + idx, out_sub[j][s]);
@@ -993,7 +1031,7 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_collect_flow(const JtTask *_
     }
 }
 
-template <typename T>
+template <typename T, bool EARLY = false>
 __device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                         const int *__restrict__ itab, const T *__restrict__ psi, T *__restrict__ bel,
                                                         double *__restrict__ msg, const JtFlow &fl, uint32_t *flow_ctl) {
@@ -1006,14 +1044,14 @@ __device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict
         return;
     }
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
-        case 0: jt_pass<T, 0, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 1: jt_pass<T, 1, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 2: jt_pass<T, 2, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 3: jt_pass<T, 3, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 4: jt_pass<T, 1, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 5: jt_pass<T, 2, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 6: jt_pass<T, 3, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        default: jt_pass<T, 4, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 0: jt_pass<T, 0, 0, 1, true, EARLY>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 1: jt_pass<T, 1, 1, 1, true, EARLY>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 2, 1, true, EARLY>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 3: jt_pass<T, 3, 3, 1, true, EARLY>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 4: jt_pass<T, 1, 0, 1, true, EARLY>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 5: jt_pass<T, 2, 1, 1, true, EARLY>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 6: jt_pass<T, 3, 2, 1, true, EARLY>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        default: jt_pass<T, 4, 3, 1, true, EARLY>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
     }
 }
 
@@ -1070,13 +1108,20 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_distribute_flow(const JtTask
     jt_distribute_flow_body<T>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
 }
 
+#ifndef JT_CHAIN_WAVES
+#define JT_CHAIN_WAVES 3
+#endif
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_flow_chain(const JtTask *__restrict__ tasks,
+__global__ __launch_bounds__(JT_THREADS, JT_CHAIN_WAVES) void jt_distribute_flow_chain(const JtTask *__restrict__ tasks,
                                                                           const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                           const T *__restrict__ psi, T *__restrict__ bel,
                                                                           double *__restrict__ msg, JtFlow fl) {
     __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];        // ticket, wait flags and candidates, parked flush records
-    jt_distribute_flow_body<T>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
+    #ifdef JT_CHAIN_NO_EARLY
+    jt_distribute_flow_body<T, false>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
+#else
+    jt_distribute_flow_body<T, true>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);   // (flush records kept in registers)
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -133,7 +133,12 @@ def lib():
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
     handle = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
-        fn = getattr(handle, name)
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            if "JTPROP_LIB" in os.environ:      # (A/B against an older build of the library: it may lack newer entry points)
+                continue
+            raise
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = handle

@@ -1,14 +1,15 @@
 #!/bin/bash
-# A/B of two builds of libjtprop.so on one box: tools/ab.sh other.so  (configs 4, 2, 3; alternating)
-ALT=$1
-for i in 1 2 3; do for lib in "" "$ALT"; do
-  export JTPROP_LIB=${lib:-$PWD/junction-tree_amd/junctiontree_amd/lib/libjtprop.so}
-  timeout -k 10 100 python3 bench.py --cpu-sample 0 --steps 100 > /tmp/ab.json 2>/dev/null || exit 1
-  echo "C4 ${lib:+alt} : $(python3 tools/bsum.py /tmp/ab.json | tr '\n' ' ' | tr -s ' ')"
-done; done
-for lib in "" "$ALT"; do
-  export JTPROP_LIB=${lib:-$PWD/junction-tree_amd/junctiontree_amd/lib/libjtprop.so}
-  timeout -k 10 100 python3 bench.py --config c2 --cpu-sample 0 --steps 30 > /tmp/ab.json 2>/dev/null || exit 1
-  echo "C2 ${lib:+alt} : $(python3 tools/bsum.py /tmp/ab.json | tr '\n' ' ' | tr -s ' ')"
-  echo "C3 ${lib:+alt} : $(timeout -k 10 150 python3 tools/c3_time.py)"
+# A/B of library builds on ONE box (boxes of the pool differ by +-2.5 %: never compare across gpurun calls).
+#   bash tools/ab.sh OUTDIR "bench args" lib1 lib2 ...      (libN = a name under junctiontree_amd/lib/: libjtprop_NAME.so, or "cur")
+# Runs every build REPS times (default 2), interleaved, and prints ms/step per run.
+OUT=$1; ARGS=$2; shift 2
+REPS=${REPS:-2}
+mkdir -p $OUT
+L=junction-tree_amd/junctiontree_amd/lib
+for i in $(seq $REPS); do
+  for n in "$@"; do
+    if [ "$n" = cur ]; then env -u JTPROP_LIB python bench.py $ARGS --cpu-sample 0 > $OUT/${n}_$i.json 2>&1
+    else JTPROP_LIB=$L/libjtprop_$n.so python bench.py $ARGS --cpu-sample 0 > $OUT/${n}_$i.json 2>&1; fi
+  done
 done
+python tools/bsum.py $OUT/*.json | grep "ms/step\|unread"

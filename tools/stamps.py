@@ -42,6 +42,7 @@ d, full = _stamps.read(plan)
 st = _stamps.coarse(full)
 attempts = full[:, 13]
 phase_t0, prev_out = {}, {}
+summary = {0: [], 1: []}            # STAMPS_SUMMARY=1: medians over the levels of a phase instead of a line per level
 only_big = len(sys.argv) > 1 and sys.argv[1] == "c3"
 fine_names = ["rec+issue", "1st attempt", "wait+restage", "consts", "step0", "step1", "step2", "step3", "more steps", "epilogues", "flush issue", "flush retire"]
 fine_cols = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
@@ -62,7 +63,15 @@ for L in d["launches"]:
     print("%s level %d (%d blocks, %d tasks): first block in %.1f us, last in %.1f, LAST OUT %.1f (%+.1f after the level before); attempts mean %.2f max %d" % (
         "collect" if L["phase"] == 0 else "distrib", L["level"], L["nblocks"], len(L["tasks"]), s[:, 0].min() - t0p, s[:, 0].max() - t0p, out,
         out - prev_out.get(L["phase"], 0.0), attempts[L["blk_off"]:L["blk_off"] + L["nblocks"]][ok].mean(), attempts[L["blk_off"]:L["blk_off"] + L["nblocks"]][ok].max()))
+    fd0 = np.diff(f[:, fine_cols], axis=1)
+    fd0[f[:, fine_cols][:, 1:] <= 0] = np.nan
+    w8 = f[:, 14] > 0
+    with np.errstate(all="ignore"):
+        summary[L["phase"]].append([out - prev_out.get(L["phase"], 0.0), np.median(f[w8, 3] - f[w8, 14]) if w8.any() else np.nan,
+                                    (s[:, 5].max() - f[w8, 14].max()) if w8.any() else np.nan] + list(np.nanmedian(fd0, axis=0)))
     prev_out[L["phase"]] = out
+    if os.environ.get("STAMPS_SUMMARY"):
+        continue
     dur = np.diff(s, axis=1)
     print("     median stage us: " + "  ".join("%s %.2f" % (n, v) for n, v in zip(
         ["rec+issue", "table+staging", "consts", "loop", "epilogue+flush"], np.median(dur, axis=0))) +
@@ -78,3 +87,14 @@ for L in d["launches"]:
     with np.errstate(all="ignore"):
         print("     fine, median of all  : " + "  ".join("%s %.2f" % (n, v) for n, v in zip(fine_names, np.nanmedian(fd, axis=0))))
         print("     fine, last 5%% to end : " + "  ".join("%s %.2f" % (n, v) for n, v in zip(fine_names, np.nanmedian(fd[last], axis=0))))
+
+if os.environ.get("STAMPS_SUMMARY"):
+    for ph in (0, 1):
+        a = np.array(summary[ph][2:-2] if len(summary[ph]) > 8 else summary[ph])
+        if len(a) == 0:
+            continue
+        with np.errstate(all="ignore"):
+            med = np.nanmedian(a, axis=0)
+        print("%s: %d levels; median over levels: level increment %.2f us, re-stage after the last wait %.2f, last wait -> last block out %.2f" % (
+            "collect" if ph == 0 else "distribute", len(a), med[0], med[1], med[2]))
+        print("     stages: " + "  ".join("%s %.2f" % (n, v) for n, v in zip(fine_names, med[3:])))
