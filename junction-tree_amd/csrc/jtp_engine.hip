@@ -469,7 +469,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     // then idles a whole CU, and staging is a large share of the traffic, which per-level launches read
     // through L2 while a dataflow launch has to read through to memory.  Measured 39.6 vs 46.9 ms.
     if (hp.max_lds > 64 * 1024 && !pl->multiset && !hp.knobs.force_flow) pl->flow = false;
-    for (const JtTask &tk : hp.tasks) pl->chain = pl->chain || tk.settle != 0;
+    pl->chain = hp.chain_plan;
     if (hp.flags & JTP_PLAN_ONLY) {
         *out = pl;
         return JTP_OK;

@@ -563,6 +563,7 @@ PlanKnobs jtp_read_knobs() {
     k.search_all = geti("JTP_SEARCH_ALL", 1);
     k.roctx = geti("JTP_ROCTX", 0);
     k.merge_phases = geti("JTP_MERGE_PHASES", -1);
+    k.settle_level_elems = getd("JTP_SETTLE_LEVEL_ELEMS", 8388608.0);
     return k;
 }
 
@@ -1394,9 +1395,20 @@ int PlanBuilder::make_tasks() {
 }
 
 int PlanBuilder::messages() {
-    // plans whose cliques mostly sit on latency-bound levels - a clique or two - (chains): settle in place
-    if (hp.chain_plan)
-        for (JtTask &tk : hp.tasks) tk.settle = 1;
+    // Settle in place (jt_msg_settle): plans whose cliques mostly sit on latency-bound levels - a clique or two - (chains),
+    // and (round 3) the tasks of any plan's NARROW levels - the top of a tree, a rank's share of one - where the hand-over
+    // between dependent levels is what the level costs (a rank's share of config 4 at 8 ranks: 201.5 -> 195 us, config 4
+    // itself +-0; A/B on one box).  Not on streaming levels: there the re-loads of thousands of waiting workgroups cost more
+    // than the round trips they save (round 2).  Tried on top of it and dropped: a two-stage wait - one lane polls an entry
+    // the PRODUCER waits for, then every thread spins on its own entries - so that a message is taken one load after it
+    // becomes visible: config 2 5.47 -> 5.87 ms, the rank share 195 -> 199 us (the spinning threads of a whole level cost
+    // the producers more than the saved round trip).
+    for (JtTask &tk : hp.tasks) {
+        if (tk.kind != 0) continue;
+        const PNode &p = hp.pn[tk.pnode];
+        const int phase = ((int)(&tk - hp.tasks.data()) == p.collect_task) ? 0 : 1;
+        tk.settle = (hp.chain_plan || lvl_elems[phase][p.owner][p.depth] <= hp.knobs.settle_level_elems) ? 1 : 0;
+    }
     // ---- message arena ----------------------------------------------------------------------
     // A message written as many partial copies costs every consuming workgroup (sub-box x copies)
     // loads before it can start, on the critical path of the small levels near the root.  From
@@ -2006,7 +2018,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             if (t) o << ",";
             o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
-              << ",\"nR\":" << tk.nR << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
+              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
             json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";

@@ -105,6 +105,7 @@ struct PlanKnobs {
     int search_all = 1;                                             // JTP_SEARCH_ALL=0: the search only where policy 2 would have been chosen (else policy 3 stays)
     int no_search = 0;                                              // JTP_NO_SEARCH: layout policy 2 where the cost-model search (policy 4) would run
     int roctx = 0;                                                  // JTP_ROCTX: roctx ranges around propagates and read-outs
+    double settle_level_elems = 8388608.0;                          // JTP_SETTLE_LEVEL_ELEMS: tasks on levels of at most this many table elements settle in place
     int merge_phases = -1;                                          // JTP_MERGE_PHASES: 1 / 0 = both phases in one dataflow launch / never; -1: where messages are small
 };
 PlanKnobs jtp_read_knobs();
