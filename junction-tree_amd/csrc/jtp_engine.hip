@@ -583,7 +583,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     // dynamic LDS beyond 64 KiB has to be allowed per kernel function (raise_lds remembers what each one has)
     auto kfunc = [&](int v) { return hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v); };
     if (pl->multiset) {
-        CREATE_TRY(raise_lds(kfunc(JT_K_MULTI_COLLECT), JT_RING_BYTES + JT_MSETS * JT_SETB_LARGE));
+        CREATE_TRY(raise_lds(kfunc(JT_K_MULTI_COLLECT), JT_RING_BYTES + JT_MSETS * (JT_MSETS > 8 ? JT_SETB_SMALL : JT_SETB_LARGE)));
     } else if (hp.max_lds > 64 * 1024) {
         for (int v = 0; v < JT_K_COUNT; ++v) {
             if (kfunc(v) == nullptr) continue;                 // (the dataflow kernels: below)
@@ -1042,11 +1042,15 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
             fl.ticket_idx = ticket_idx >= 0 ? (uint32_t)ticket_idx : 0xffffffffu;
             fl.ticket_base = ticket_base;
             fl.blk_base = (uint32_t)blk_off;
+            fl.n_groups = (uint32_t)pl->n_groups;
+            fl.n_blocks = (uint32_t)nblocks;
+            // (1-D grid: eight records of group 0, the same eight of group 1, ... - see jt_multi_flow)
+            const unsigned grid = (unsigned)((nblocks + 7) / 8) * 8u * (unsigned)pl->n_groups;
             if (hp.dtype == JTP_F32)
-                hipLaunchKernelGGL(jt_multi_flow<float>, dim3(nblocks, pl->n_groups), dim3(JT_THREADS), lds, s, pl->d_tasks, pl->d_blocks + blk_off,
+                hipLaunchKernelGGL(jt_multi_flow<float>, dim3(grid), dim3(JT_THREADS), lds, s, pl->d_tasks, pl->d_blocks + blk_off,
                                    pl->d_itab, (const float *)b0.psi, (float *)b0.bel, pl->msg_all, fl);
             else
-                hipLaunchKernelGGL(jt_multi_flow<double>, dim3(nblocks, pl->n_groups), dim3(JT_THREADS), lds, s, pl->d_tasks, pl->d_blocks + blk_off,
+                hipLaunchKernelGGL(jt_multi_flow<double>, dim3(grid), dim3(JT_THREADS), lds, s, pl->d_tasks, pl->d_blocks + blk_off,
                                    pl->d_itab, (const double *)b0.psi, (double *)b0.bel, pl->msg_all, fl);
         };
         for (const Step &st : (flow ? hp.flow_steps : hp.steps)) {

@@ -56,7 +56,9 @@
 // JT_MSETS at a time by every workgroup - a table row is loaded once and multiplied into the messages of
 // each set of the group (kernel jt_multi_*).  Per set a workgroup owns an LDS region of JtTask::setb bytes
 // (4 KiB or 16 KiB) holding the set's message sub-boxes.
+#ifndef JT_MSETS
 #define JT_MSETS 8
+#endif
 #define JT_SETB_SMALL 4096
 #define JT_SETB_LARGE 16384
 
@@ -136,6 +138,8 @@ struct JtFlow {
     int64_t set_stride;        // doubles between the message arenas of consecutive sets
     uint32_t ev_stride;        // uint32 between the evidence tables of consecutive sets
     uint32_t sync_stride;      // uint32 between the sync areas of consecutive groups
+    uint32_t n_groups;         // multi-set launches: groups of evidence sets in the launch (the grid is 1-D: jt_multi_flow)
+    uint32_t n_blocks;         // ... and workgroup records per group
     int64_t out_shift;         // added to the address of every outgoing entry (doubles): read-out tasks of multi-set
                                // plans read one set's message arena and write into a scratch buffer elsewhere
 };

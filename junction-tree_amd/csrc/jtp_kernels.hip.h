@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     const int rmask = (1 << tk.nR) - 1;
     const int64_t sstride = fl.set_stride;
 #ifdef JT_STAMPS
-    const int dbg = blockIdx.y == 0 ? tk.debug : (tk.debug & ~2);                             // (time stamps of group 0 only)
+    const int dbg = (fl.dbg & 0x80000000u) ? (tk.debug & ~2) : tk.debug;                      // (time stamps of group 0 only)
     double *stamp_out = msg0 + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * JT_NSTAMP;      // (as in jt_pass)
 #else
     const int dbg = tk.debug;
@@ -1328,13 +1328,13 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     const uint32_t ofp[4] = {ofpw[0], ofpw[1], ofpw[2], ofpw[3]};
     // thread part of the evidence: bit (4 s + e) set = element e of this thread agrees with set s
     constexpr uint32_t TMASK = (1u << TBITS) - 1u;
-    uint32_t tmatch = 0;
+    uint64_t tmatch = 0;
 #pragma unroll
     for (int s = 0; s < G; ++s) {
         const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ev_m, s) & TMASK, v = (uint32_t)__builtin_amdgcn_readlane((int)ev_v, s);
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-            if (((((uint32_t)tid * VEC + e) ^ v) & m) == 0) tmatch |= 1u << (4 * s + e);
+            if (((((uint32_t)tid * VEC + e) ^ v) & m) == 0) tmatch |= 1ull << (4 * s + e);
     }
     // row part (chunk and loop bits): lane s keeps set s's mask and value; one compare + ballot per row
     const uint32_t row_m = ev_m & ~TMASK, row_v = ev_v & ~TMASK;
@@ -1357,7 +1357,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
         for (int s = 0; s < G; ++s) {
 #pragma unroll
             for (int e = 0; e < NACC; ++e)
-                if (!((tmatch >> (4 * s + e)) & 1u)) acc[s][e] = 0.0;
+                if (!((tmatch >> (4 * s + e)) & 1ull)) acc[s][e] = 0.0;
             if constexpr (!ESUM) {
                 if constexpr (VEC == 4) {
                     if (o_rede & 1) {
@@ -1585,16 +1585,28 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
 // Multi-set entry point: grid.y = group of JT_MSETS evidence sets; the block list is that of a whole phase
 // (dataflow launch) or of one tree level.  Workgroups of one group only ever wait for workgroups of the same
 // group earlier in the list.
+#ifndef JT_MULTI_WAVES
+#define JT_MULTI_WAVES 3
+#endif
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS, 3) void jt_multi_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+__global__ __launch_bounds__(JT_THREADS, JT_MULTI_WAVES) void jt_multi_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                             const int *__restrict__ itab, const T *__restrict__ psi,
                                                             T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
     __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];        // ticket, wait flags and candidates, parked flush records
-    const uint32_t grp = blockIdx.y;
+    // 1-D grid, the GROUP index inside the record index: workgroups b .. b+7 of group g, then the same eight records for
+    // group g+1, ...  The groups of evidence sets stream the SAME table rows; dispatched next to each other - and, with the
+    // round-robin placement of consecutive workgroups over the eight XCDs, on the same XCD - the second to last group find
+    // the rows the first one fetched in the L2 / Infinity Cache instead of fetching 1 GiB of tables again per group
+    // (round 2: grid.y = group, every group a sweep of its own over all tables).  Order inside a group is unchanged
+    // (record index ascending with blockIdx), which is all the dataflow waits need.
+    const uint32_t octet = blockIdx.x / (8u * fl.n_groups), within = blockIdx.x % (8u * fl.n_groups);
+    const uint32_t grp = within / 8u, rec = octet * 8u + (within & 7u);
+    if (rec >= fl.n_blocks) return;
+    if (grp != 0) fl.dbg |= 0x80000000u;                     // (diagnostic builds: group 0 writes the time stamps)
     fl.sync += (size_t)grp * fl.sync_stride;
     if (fl.ev != nullptr) fl.ev += (size_t)grp * JT_MSETS * fl.ev_stride;
     double *msg0 = msg + (int64_t)grp * JT_MSETS * fl.set_stride;
-    const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
+    const uint32_t ticket = fl.ticket_idx == 0xffffffffu ? rec : jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
