@@ -133,7 +133,14 @@ struct Range {
 template <typename T>
 struct KernelTable {
     typedef void (*fn)(const JtTask *, const JtBlock *, const int *, const T *, T *, double *, JtFlow);
-    static fn get(int variant) {
+    static fn get(int variant, bool tmix) {
+        if (tmix) {                 // plans with a mixed-radix thread part: one kernel per launch style (they dispatch on the task)
+            if (variant >= JT_K_COLLECT0 && variant <= JT_K_COLLECT3) return jt_collect_level_mix<T>;
+            if (variant >= JT_K_DIST_P0C0 && variant <= JT_K_DIST_P1C3) return jt_distribute_level_mix<T>;
+            if (variant == JT_K_COLLECT_LEVEL) return jt_collect_level_mix<T>;
+            if (variant == JT_K_DISTRIBUTE_LEVEL) return jt_distribute_level_mix<T>;
+            if (variant == JT_K_SINGLE) return jt_single_mix<T>;
+        }
         switch (variant) {
             case JT_K_COLLECT0: return jt_collect<T, 0>;
             case JT_K_COLLECT1: return jt_collect<T, 1>;
@@ -156,7 +163,8 @@ struct KernelTable {
         }
         return nullptr;
     }
-    static fn get_flow(int phase, bool chain) {
+    static fn get_flow(int phase, bool chain, bool tmix) {
+        if (tmix) return phase == 0 ? jt_collect_flow_mix<T> : jt_distribute_flow_mix<T>;      // (never merged: jtp_plan.cpp finish())
         if (phase == 2) return jt_propagate_flow<T>;                    // both phases in one launch
         return phase == 0 ? jt_collect_flow<T> : (chain ? jt_distribute_flow_chain<T> : jt_distribute_flow<T>);
     }
@@ -581,7 +589,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         CREATE_TRY(hipMemcpy(pl->d_itab, hp.itab.data(), hp.itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     // dynamic LDS beyond 64 KiB has to be allowed per kernel function (raise_lds remembers what each one has)
-    auto kfunc = [&](int v) { return hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v); };
+    auto kfunc = [&](int v) { return hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v, hp.tmix) : (const void *)KernelTable<double>::get(v, hp.tmix); };
     if (pl->multiset) {
         CREATE_TRY(raise_lds(kfunc(JT_K_MULTI_COLLECT), JT_RING_BYTES + JT_MSETS * (JT_MSETS > 8 ? JT_SETB_SMALL : JT_SETB_LARGE)));
     } else if (hp.max_lds > 64 * 1024) {
@@ -590,7 +598,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             CREATE_TRY(raise_lds(kfunc(v), hp.max_lds));
         }
         for (int ph = 0; ph < 3; ++ph) {
-            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain) : (const void *)KernelTable<double>::get_flow(ph, pl->chain);
+            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain, hp.tmix) : (const void *)KernelTable<double>::get_flow(ph, pl->chain, hp.tmix);
             CREATE_TRY(raise_lds(f, hp.max_lds));
         }
     }
@@ -837,10 +845,10 @@ int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double 
 static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipStream_t s, const JtTask *tasks,
                           const JtBlock *blocks, const int *itab, void *psi, void *bel, double *msg, const JtFlow &fl) {
     if (pl->hp.dtype == JTP_F32) {
-        auto f = KernelTable<float>::get(variant);
+        auto f = KernelTable<float>::get(variant, pl->hp.tmix);
         hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const float *)psi, (float *)bel, msg, fl);
     } else {
-        auto f = KernelTable<double>::get(variant);
+        auto f = KernelTable<double>::get(variant, pl->hp.tmix);
         hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const double *)psi, (double *)bel, msg, fl);
     }
     return JTP_OK;
@@ -1140,10 +1148,10 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 fl.blk_base = (uint32_t)sg.blk_off;
                 fl.ticket_base = ticket_run * (uint32_t)sg.nblocks;
                 if (hp.dtype == JTP_F32)
-                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase, pl->chain), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase, pl->chain, hp.tmix), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const float *)bb.psi, (float *)bb.bel, bb.msg, fl);
                 else
-                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase, pl->chain), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase, pl->chain, hp.tmix), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const double *)bb.psi, (double *)bb.bel, bb.msg, fl);
             } else if (st.kind == 0) {
                 const Launch &L = hp.launches[st.first];
@@ -1237,7 +1245,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
             one.cur_off = b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));
             one.oth_off = -1;
             one.ev = b.ev;
-            HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE) : (const void *)KernelTable<double>::get(JT_K_SINGLE), bt.lds));
+            HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE, hp.tmix) : (const void *)KernelTable<double>::get(JT_K_SINGLE, hp.tmix), bt.lds));
             launch_variant(pl, JT_K_SINGLE, bt.nblocks, bt.lds, s, bt.d_task, bt.d_blk, bt.d_tab, b.psi, b.bel, b.msg, one);
             HIP_TRY(hipGetLastError());
         }
@@ -1370,6 +1378,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
             rc = jtp_plan_marginal_task(hp, clique, ov, tk, tab, out_bits, npart, blk, err, pl->multiset);
             if (rc) return set_err(rc, "request %d: %s", i, err.c_str());
             tk.itab_off = (int64_t)itab.size();
+            if (tk.tmap_off >= 0) tk.tmap_off += tk.itab_off;      // (the clique's thread map travels behind the task's rows)
             tk.msg[JT_MAX_IN].off = scratch_doubles;
             itab.insert(itab.end(), tab.begin(), tab.end());
             for (JtBlock &bk : blk) {
@@ -1441,7 +1450,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
     }
     {   // the kernel that is actually launched below must be allowed this much dynamic LDS
         const int v = pl->multiset ? JT_K_SINGLE : JT_K_COLLECT0;
-        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v) : (const void *)KernelTable<double>::get(v), mb->lds));
+        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v, hp.tmix) : (const void *)KernelTable<double>::get(v, hp.tmix), mb->lds));
     }
     // marginalise the BELIEF tables: each is the "potential" argument of a childless collect
     JtFlow plain;

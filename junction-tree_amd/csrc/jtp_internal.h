@@ -118,6 +118,9 @@ struct JtTask {
     int32_t total;             // loop iterations per workgroup = 2^(nA + nR), 4 .. 64
     int32_t itab_lds;          // byte offset of the iteration table in dynamic LDS
     int64_t dbg_off;           // JTP_DEBUG & 2: msg-arena offset of the time stamps, 16 per workgroup (builds with -DJT_STAMPS)
+    int64_t tmap_off;          // plans with a mixed-radix thread part (HostPlan::tmix, kernels *_mix): offset (ints) in the table
+                               // buffer of the clique's thread map - 2^TB entries, entry x = element offset inside a row of
+                               // logical thread index x, or -1 where x names no table entry; else -1
     JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing
 };
 
@@ -173,7 +176,8 @@ struct JtPackDesc {
     int32_t dmod[JT_MAX_VARS];    // digits stored along that stride (2^nb where padded, the cardinality where compact)
     int64_t phys_elems;        // elements of the table as stored (zero row not included)
     int32_t low_bits;          // index bits of the thread part (one row = 2^low_bits elements)
-    int32_t pad2;
+    int32_t row_elems;         // > 0: thread part stored at true cardinalities - the digits of variables below low_bits are taken
+                               // of (x mod row_elems), x the element index (a row is row_elems long, not 2^low_bits)
 };
 
 // one request of a batched marginal read-out (jt_marg_unpack): partial copies -> host order

@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t jt_sub_hi(const uint32_t (&fp)[4], int nfree
     return g;
 }
 
-template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0)>
+template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
                                         double *__restrict__ msg_arena, const JtFlow &fl,
@@ -275,10 +275,35 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // (Vector-memory operations return in issue order, so the staging loads issued behind the first table rows only come
     //  back after them.  Issuing the first round of message loads AHEAD of the rows was tried in round 3: config 4 +-0,
     //  config 3 - whose staging loads are a quarter of its traffic - 12.5 -> 13.1 ms, A/B on one box: the rows go first.)
-    auto issue_tables = [&]() {
+    // TMIX (plans with a mixed-radix thread part, HostPlan::tmix): the elements of a thread's logical index tid * VEC + e lie
+    // at tmap[...] inside a row (-1: no such entry).  Rows are then gathered element by element into registers - ordinary
+    // loads the compiler counts itself - instead of the 16-byte LDS-DMA ring; everything downstream (message look-ups,
+    // butterflies, epilogues) works on the logical index and is unchanged.
+    // (Entries that do not exist load the row's first element - every lane then executes every load, no per-element branch -
+    //  and count as zero when the row is consumed; `row0` is a register copy of JtBlock::xF: read through `bk` inside the
+    //  loop it was a scalar load and a wait in front of every element load, the belief stores could alias it.)
+    int tpo[VEC];
+    T tbuf[TMIX ? U : 1][VEC];
+    const uint32_t row0 = bk.xF;
+    auto gather_row = [&](const int slot, const uint32_t xrow, const bool ok) {
+        if constexpr (TMIX) {
+            const T *row = ok ? psi + (row0 + xrow) : psi_arena;             // (uniform; psi_arena: the zero row)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
+            for (int e = 0; e < VEC; ++e) tbuf[slot][e] = row[tpo[e] >= 0 ? tpo[e] : 0];
+        }
+    };
+    auto issue_tables = [&]() {
+        if constexpr (TMIX) {
+            const int *tm = itab + tk.tmap_off + tid * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tpo[e] = tm[e];
+#pragma unroll
+            for (int u = 0; u < U; ++u) gather_row(u, bk.first_x[u], bk.first_x[u] != JT_NO_ROW);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
+        }
         const int r = lane < total ? lane : total - 1;
         const int4 a = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL);
         const int4 b = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL + 4);
@@ -311,7 +336,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         //  levels the extra loads of waiting workgroups cost 1-2 % - both measured)
         const int settle_attempt = tk.settle ? attempt : 0;
         const double *unready = nullptr;          // (FLOW) an entry this thread found not written yet
-        {
+        // (TMIX: a chunk that does not exist - JT_BLOCK_INVALID - stages nothing, waits for nobody and runs no row: it writes
+        //  its all-zero sub-boxes, which the consumers sum and whose entries of the other arena half it re-arms, and ends)
+        if (!TMIX || chunk_ok) {
             const double *src[NIN > 0 ? NIN : 1];
             int idx_t[NIN > 0 ? NIN : 1], gp0[NIN > 0 ? NIN : 1], gp1[NIN > 0 ? NIN : 1];
             int64_t ps[NIN > 0 ? NIN : 1];
@@ -610,9 +637,16 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     auto step = [&](auto slot_tag, auto younger_tag, const int i) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int YOUNGER = decltype(younger_tag)::value;
+        double p[VEC];
+        if constexpr (TMIX) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) p[e] = tpo[e] >= 0 ? (double)tbuf[SLOT][e] : 0.0;
+            const int inext = (i + U < total) ? i + U : total - 1;
+            const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
+            gather_row(SLOT, xnext, xnext != JT_NO_ROW && chunk_ok && i + U < total);
+        } else {
         jt_wait_vmcnt<YOUNGER>();
         const VT v = *reinterpret_cast<const VT *>(ring + SLOT * 1024);
-        double p[VEC];
         p[0] = (double)v.x;
         p[1] = (double)v.y;
         if constexpr (VEC == 4) {
@@ -628,15 +662,20 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             jt_dma16((xnext == JT_NO_ROW || !chunk_ok) ? zero_row : psi + (xF + xnext),
                      __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
         }
+        }
         const int li = i;
         const uint32_t xoff = (uint32_t)__builtin_amdgcn_readlane(trow[0], li);
         const bool row_ok = xoff != JT_NO_ROW && chunk_ok;   // (uniform)
+        // TMIX: the table holds existing rows only; the row's place in the full loop nest and the ends of the outgoing
+        // messages' runs come with it (jtp_plan.cpp, plan_loops)
+        const uint32_t rowinfo = TMIX ? (uint32_t)__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], li) : 0u;
+        const uint32_t inest = TMIX ? (rowinfo >> 16) & 63u : (uint32_t)i;
         if (ev_mask != 0) {                                // (uniform: no vector instruction is spent without evidence)
             // LOGICAL index of this thread's first element (evidence masks are over index bits, element offsets are
             // physical): chunk bits + the row's loop bits + thread part
             uint32_t x0 = bk.lxF + (uint32_t)tid * VEC;
 #pragma unroll
-            for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) x0 += (((uint32_t)i >> t) & 1u) << loop_pos[t];
+            for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) x0 += ((inest >> t) & 1u) << loop_pos[t];
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 if (((x0 + e) & ev_mask) != ev_val) p[e] = 0.0;
@@ -646,6 +685,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         for (int k = 0; k < 4; ++k) ioff[k] = k < NIN ? __builtin_amdgcn_readlane(trow[1 + k], li) : 0;
 #pragma unroll
         for (int j = 0; j < 3; ++j) ooff[j] = j < NOUT ? __builtin_amdgcn_readlane(trow[1 + JT_MAX_IN + j], li) : 0;
+        if constexpr (TMIX && NOUT > 0) ooff[0] &= 0xffff;
         double in[NIN > 0 ? NIN : 1][VEC];
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
@@ -701,16 +741,22 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                     ov[2] = (T)b[2];
                     ov[3] = (T)b[3];
                 }
+                if constexpr (TMIX) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (row_ok && tpo[e] >= 0) __builtin_nontemporal_store(ov[e], bel + (row0 + xoff + (uint32_t)tpo[e]));
+                } else
                 __builtin_nontemporal_store(ov, reinterpret_cast<ext_t *>(row_ok ? bel + (xF + xoff) : junk_row));
             }
         }
         if constexpr (NOUT > 0) {
             if (!(dbg & 1)) {
-                if ((i & rmask[0]) == rmask[0]) epilogue(std::integral_constant<int, 0>{}, ooff[0]);
+                auto run_ends = [&](const int j) { return TMIX ? ((rowinfo >> (24 + j)) & 1u) != 0 : (i & rmask[j]) == rmask[j]; };
+                if (run_ends(0)) epilogue(std::integral_constant<int, 0>{}, ooff[0]);
                 if constexpr (NOUT > 1)
-                    if ((i & rmask[1]) == rmask[1]) epilogue(std::integral_constant<int, 1>{}, ooff[1]);
+                    if (run_ends(1)) epilogue(std::integral_constant<int, 1>{}, ooff[1]);
                 if constexpr (NOUT > 2)
-                    if ((i & rmask[2]) == rmask[2]) epilogue(std::integral_constant<int, 2>{}, ooff[2]);
+                    if (run_ends(2)) epilogue(std::integral_constant<int, 2>{}, ooff[2]);
             }
         }
     };
@@ -721,6 +767,17 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // state, k in step k of the first group (its loads were issued in the prologue, before any store).
     constexpr int ST = (MODE == 1) ? 1 : 0;
     using std::integral_constant;
+    if constexpr (TMIX) {
+        // any number of rows from 1 to 64 (the rows that exist); none at all for a chunk that does not
+        static_assert(U == 4, "the row loop of the mixed-radix kernels is written out for four slots");
+        if (chunk_ok)
+            for (int i0 = 0; i0 < total; i0 += U) {
+                step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, i0);
+                if (i0 + 1 < total) step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, i0 + 1);
+                if (i0 + 2 < total) step(integral_constant<int, 2>{}, integral_constant<int, 0>{}, i0 + 2);
+                if (i0 + 3 < total) step(integral_constant<int, 3>{}, integral_constant<int, 0>{}, i0 + 3);
+            }
+    } else {
     {
         step(integral_constant<int, 0>{}, integral_constant<int, U - 1 + 0 * ST>{}, 0);
         JT_STAMP(5);
@@ -753,6 +810,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             step(integral_constant<int, 6 % U>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 6);
             step(integral_constant<int, 7 % U>{}, integral_constant<int, U - 1 + U * ST>{}, i0 + 7);
         }
+    }
     }
     JT_STAMP(9);
 
@@ -1664,6 +1722,96 @@ __global__ __launch_bounds__(JT_THREADS) void jt_single(const JtTask *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Kernels of plans with a mixed-radix thread part (HostPlan::tmix: some clique stores the variables of its low index
+// bits at their TRUE cardinalities): the same passes with TMIX = true - a thread reaches its elements through the
+// clique's thread map (JtTask::tmap_off) - for every launch style the engine uses with such plans: one launch per
+// phase (dataflow), one per level, and the read-out task lists.
+template <typename T, bool FLOW>
+__device__ __forceinline__ void jt_collect_mix(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
+                                               T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
+                                               uint32_t *flow_ctl, uint64_t t_entry) {
+    switch (tk.n_in) {
+        case 0: jt_pass<T, 0, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 1: jt_pass<T, 1, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 3: jt_pass<T, 3, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        default: jt_pass<T, 4, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+    }
+}
+template <typename T, bool FLOW>
+__device__ __forceinline__ void jt_distribute_mix(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
+                                                  T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
+                                                  uint32_t *flow_ctl, uint64_t t_entry) {
+    if (tk.n_out == 0) {                       // belief only (leaves, and the read-out of multi-neighbour cliques)
+        switch (tk.n_in) {
+            case 0: jt_pass<T, 0, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            case 1: jt_pass<T, 1, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            case 2: jt_pass<T, 2, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            case 3: jt_pass<T, 3, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            default: jt_pass<T, 4, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        }
+        return;
+    }
+    switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
+        case 1: jt_pass<T, 1, 1, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 2, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 3: jt_pass<T, 3, 3, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 5: jt_pass<T, 2, 1, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 6: jt_pass<T, 3, 2, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        default: jt_pass<T, 4, 3, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_collect_level_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                                      const int *__restrict__ itab, const T *__restrict__ psi,
+                                                                      T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    const JtBlock &bk = blk[blockIdx.x];
+    jt_collect_mix<T, false>(tasks[bk.task], bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+}
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_level_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                                         const int *__restrict__ itab, const T *__restrict__ psi,
+                                                                         T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    const JtBlock &bk = blk[blockIdx.x];
+    jt_distribute_mix<T, false>(tasks[bk.task], bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+}
+// (read-out task lists: marginals - mode 0 - and beliefs of multi-neighbour cliques - mode 1)
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_single_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                               const int *__restrict__ itab, const T *__restrict__ psi,
+                                                               T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    const JtBlock &bk = blk[blockIdx.x];
+    const JtTask &tk = tasks[bk.task];
+    if (tk.mode == 0) jt_collect_mix<T, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+    else jt_distribute_mix<T, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+}
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_collect_flow_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                                     const int *__restrict__ itab, const T *__restrict__ psi,
+                                                                     T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];
+    const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
+    const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
+    const JtBlock &bk = blk[ticket];
+    const JtTask &tk = tasks[bk.task];
+    if (tk.kind != 0) jt_reduce<true>(tk, bk, msg, fl);
+    else jt_collect_mix<T, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
+}
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_flow_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                                        const int *__restrict__ itab, const T *__restrict__ psi,
+                                                                        T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];
+    const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
+    const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
+    const JtBlock &bk = blk[ticket];
+    const JtTask &tk = tasks[bk.task];
+    if (tk.kind != 0) jt_reduce<true>(tk, bk, msg, fl);
+    else jt_distribute_mix<T, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
+}
+
 // Per-shape entry points, used when the plan is built with JTP_SPLIT_VARIANTS (profiling aid:
 // one launch per (level, neighbour count), so rocprofv3 attributes time to each shape).
 template <typename T, int NCH>
@@ -1695,6 +1843,8 @@ __device__ __forceinline__ uint64_t jt_splitmix64(uint64_t x) {
 // digit of variable i at device (physical) element index x: a shift where the variable is a bit field
 __device__ __forceinline__ int jt_digit(const JtPackDesc &d, int i, uint32_t x) {
     const uint32_t ds = d.dstride[i];
+    if (d.row_elems > 0 && d.pos[i] < d.low_bits)          // a mixed-radix digit of the row (thread part at true cardinalities)
+        return ds > 0 ? (int)(((x % (uint32_t)d.row_elems) / ds) % (uint32_t)d.dmod[i]) : 0;
     if (ds == (1u << d.pos[i]) && d.dmod[i] == (1 << d.nb[i])) return (int)((x >> d.pos[i]) & ((1u << d.nb[i]) - 1u));
     return ds > 0 ? (int)((x / ds) % (uint32_t)d.dmod[i]) : 0;
 }
@@ -1856,6 +2006,12 @@ __global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restri
     X template __global__ void jt_distribute<T, 1, 3>(JT_KARGS(T));
 #define JT_INST_MULTI(X, T) X template __global__ void jt_multi_flow<T>(JT_KARGS(T));
 #define JT_INST_BOTH(X, T) X template __global__ void jt_propagate_flow<T>(JT_KARGS(T));
+#define JT_INST_MIX(X, T)                                                    \
+    X template __global__ void jt_collect_level_mix<T>(JT_KARGS(T));         \
+    X template __global__ void jt_distribute_level_mix<T>(JT_KARGS(T));      \
+    X template __global__ void jt_single_mix<T>(JT_KARGS(T));                \
+    X template __global__ void jt_collect_flow_mix<T>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute_flow_mix<T>(JT_KARGS(T));
 #ifndef JT_INST_TU
 JT_INST_FLOW(extern, float)
 JT_INST_FLOW(extern, double)
@@ -1867,4 +2023,6 @@ JT_INST_MULTI(extern, float)
 JT_INST_MULTI(extern, double)
 JT_INST_BOTH(extern, float)
 JT_INST_BOTH(extern, double)
+JT_INST_MIX(extern, float)
+JT_INST_MIX(extern, double)
 #endif

@@ -399,6 +399,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         order_a_bits(Ab, om);
     }
     tk.nbits = nbits;
+    tk.tmap_off = hp.tmix ? p.tmap_off : -1;
     tk.real_bits = real_bits;
     tk.debug = hp.knobs.debug;
     tk.nF = (int)Fb.size();
@@ -494,6 +495,33 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         for (int c = 0; c < JT_NCOL; ++c) itab[(size_t)i * JT_NCOL + c] = (int32_t)(uint32_t)row[c];
         if (i < 8) tk.first_x[i] = (uint32_t)row[0];
     }
+    if (hp.tmix) {
+        // Plans with mixed-radix rows (kernels *_mix) loop over the rows that EXIST only: with cardinality 5 in three bits a
+        // loop of two variables is 25 rows, not 64.  Row r of the table is then the r-th existing row, and what the kernels
+        // of the other plans derive from the loop counter travels in the upper half of column 1 + JT_MAX_IN: bits 16-21 the
+        // row's counter value in the full loop nest (its logical index bits: evidence), bit 24 + j "outgoing message j's
+        // run of rows ends here" (JtTask::out_run counts rows of the full nest).
+        std::vector<int> live;
+        for (int i = 0; i < tk.total; ++i)
+            if ((uint32_t)itab[(size_t)i * JT_NCOL] != JT_NO_ROW) live.push_back(i);
+        if (live.empty()) FAIL(JTP_EINVAL, "internal: a loop nest without rows");
+        std::vector<int32_t> packed(live.size() * JT_NCOL);
+        for (size_t r = 0; r < live.size(); ++r) {
+            const int i = live[r];
+            for (int c = 0; c < JT_NCOL; ++c) packed[r * JT_NCOL + c] = itab[(size_t)i * JT_NCOL + c];
+            uint32_t w = (uint32_t)packed[r * JT_NCOL + 1 + JT_MAX_IN];
+            if (w >= (1u << 16)) FAIL(JTP_EINVAL, "internal: sub-box offset %u does not fit 16 bits", w);
+            w |= (uint32_t)i << 16;
+            for (int j = 0; j < tk.n_out; ++j) {
+                const int run = (tk.out_run >> (8 * j)) & 0xff;
+                if (r + 1 == live.size() || (live[r + 1] >> run) != (i >> run)) w |= 1u << (24 + j);
+            }
+            packed[r * JT_NCOL + 1 + JT_MAX_IN] = (int32_t)w;
+        }
+        itab.swap(packed);
+        tk.total = (int)live.size();
+        for (int i = 0; i < 8; ++i) tk.first_x[i] = i < tk.total ? (uint32_t)itab[(size_t)i * JT_NCOL] : JT_NO_ROW;
+    }
     tk.itab_lds = ((lds + 15) & ~15) + JT_STAGE_SCRATCH * tk.n_in;        // sub-boxes, staging scratch per incoming message
     tk.lds_bytes = tk.itab_lds;                           // (the iteration table is register resident)
     if (strict_budget > 0) {
@@ -563,6 +591,8 @@ PlanKnobs jtp_read_knobs() {
     k.search_all = geti("JTP_SEARCH_ALL", 1);
     k.roctx = geti("JTP_ROCTX", 0);
     k.merge_phases = geti("JTP_MERGE_PHASES", -1);
+    k.no_tmix = geti("JTP_NO_TMIX", 0);
+    k.tmix_fill = getd("JTP_TMIX_FILL", 0.6);
     k.settle_level_elems = getd("JTP_SETTLE_LEVEL_ELEMS", 8388608.0);
     return k;
 }
@@ -1171,12 +1201,37 @@ int PlanBuilder::layouts() {
         p.vars = order;
         p.pos.clear();
         p.nb.clear();
+        // Thread part at true cardinalities (round 3): where a variable of the low TB index bits is not a power of two, those
+        // variables become mixed-radix digits of a row of prod(card) elements instead of 2^TB - five variables of cardinality 3
+        // in ten bits stored 4.2 x the table (round 2).  Such a clique keeps every variable wholly below or wholly above bit TB
+        // (bits in between are padding: tpad_mask), and all tasks of the plan reach their elements through PNode::tmap.
+        {
+            // (Which cliques: those whose bit-field thread part would be filled to less than PlanKnobs::tmix_fill, 0.6 -
+            //  cardinality 3: (3/4)^5 = 0.24, 5: 0.24, 6: 0.42.  Fuller ones keep the bit fields: a bit-field thread part may
+            //  hold the low bit of one more variable, so it needs fewer rows - cardinality 7, width 7: fill 0.67, 0.30 ms
+            //  against 0.46 ms with mixed-radix rows for 1.7 x the memory; tools/odd_time.py.)
+            int b = 0;
+            double fill = 1.0;
+            for (int v : p.vars) {
+                if (b + hp.vbits[v] <= hp.TB) fill *= (double)hp.card[v] / (double)(1 << hp.vbits[v]);
+                b += hp.vbits[v];
+            }
+            p.tmix = fill < hp.knobs.tmix_fill && hp.compact && !hp.multiset && !hp.knobs.no_tmix;
+        }
         int bit = 0;
+        p.tpad_mask = 0;
         for (int v : p.vars) {
+            if (p.tmix && bit < hp.TB && bit + hp.vbits[v] > hp.TB) {
+                for (int b = bit; b < hp.TB; ++b) p.tpad_mask |= 1u << b;
+                bit = hp.TB;
+            }
             p.pos.push_back(bit);
             p.nb.push_back(hp.vbits[v]);
             bit += hp.vbits[v];
         }
+        if (p.tmix)
+            for (int b = bit; b < hp.TB; ++b) p.tpad_mask |= 1u << b;
+        hp.tmix = hp.tmix || p.tmix;
         if (bit > JT_MAX_BITS) FAIL(JTP_EUNSUPPORTED, "clique %d needs %d index bits (max %d)", p.real, bit, JT_MAX_BITS);
         p.nbits = std::max(bit, hp.TB + JT_MIN_ITER_LOG2);   // >= 4 loop iterations per workgroup
         if (p.nbits - hp.TB > JT_MAX_HI) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
@@ -1191,6 +1246,31 @@ int PlanBuilder::layouts() {
         p.pad_mask = 0;
         for (int b = 0; b < hp.TB && b < p.nbits; ++b) p.bitw[b] = (int64_t)1 << b;
         int64_t mult = (int64_t)1 << hp.TB;
+        p.trow = 1 << hp.TB;
+        p.tmap.clear();
+        if (p.tmix) {
+            // row = the thread-part variables as mixed-radix digits, first variable fastest
+            std::vector<int64_t> tstride(p.vars.size(), 0);
+            int64_t prod = 1;
+            for (size_t i = 0; i < p.vars.size(); ++i)
+                if (p.pos[i] + p.nb[i] <= hp.TB) tstride[i] = prod, prod *= hp.card[p.vars[i]];
+            p.trow = (int)((prod + hp.VEC - 1) / hp.VEC * hp.VEC);
+            p.tmap.assign((size_t)1 << hp.TB, -1);
+            for (uint32_t x = 0; x < (1u << hp.TB); ++x) {
+                if (x & p.tpad_mask) continue;
+                int64_t off = 0;
+                bool ok = true;
+                for (size_t i = 0; i < p.vars.size() && ok; ++i) {
+                    if (p.pos[i] + p.nb[i] > hp.TB) continue;
+                    const int digit = (int)((x >> p.pos[i]) & ((1u << p.nb[i]) - 1u));
+                    ok = digit < hp.card[p.vars[i]];
+                    off += digit * tstride[i];
+                }
+                if (ok) p.tmap[x] = (int32_t)off;
+            }
+            for (int b = 0; b < hp.TB && b < p.nbits; ++b) p.bitw[b] = 0;      // (inside a row: tmap, not bit weights)
+            mult = p.trow;
+        }
         for (size_t i = 0; i < p.vars.size(); ++i) {
             const int pos = p.pos[i], nb = p.nb[i], card = hp.card[p.vars[i]];
             if (pos + nb <= hp.TB) continue;
@@ -1213,6 +1293,12 @@ int PlanBuilder::layouts() {
         p.phys_elems = mult;
         if (mult > ((int64_t)1 << 31)) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
     }
+    if (hp.tmix)
+        for (PNode &p : hp.pn)
+            if (!p.tmix) {            // bit-field rows: the identity map, so that one kernel family serves every task of the plan
+                p.tmap.resize((size_t)1 << hp.TB);
+                for (uint32_t x = 0; x < (1u << hp.TB); ++x) p.tmap[x] = (int32_t)x;
+            }
     for (size_t s = 0; s < hp.ps.size(); ++s) {
         PSep &sp = hp.ps[s];
         const PNode &ch = hp.pn[sp.child];
@@ -1261,8 +1347,16 @@ int PlanBuilder::arenas() {
             pd.hstride[i] = stride;
             pd.dstride[i] = p.nb[j] > 0 ? (uint32_t)p.bitw[p.pos[j]] : 0u;
             pd.dmod[i] = whole ? hp.card[v] : 1 << p.nb[j];
+            if (p.tmix && p.pos[j] + p.nb[j] <= hp.TB) {          // a mixed-radix digit of the row
+                int64_t ts = 1;
+                for (int jj = 0; jj < j; ++jj)
+                    if (p.pos[jj] + p.nb[jj] <= hp.TB) ts *= hp.card[p.vars[jj]];
+                pd.dstride[i] = p.nb[j] > 0 ? (uint32_t)ts : 0u;
+                pd.dmod[i] = hp.card[v];
+            }
             stride *= hp.card[v];
         }
+        pd.row_elems = p.tmix ? p.trow : 0;
         pd.host_elems = stride;
         return pd;
     };
@@ -1276,6 +1370,10 @@ int PlanBuilder::arenas() {
         for (int v : p.vars) he *= hp.card[v];
         hp.host_table_elems += he;
         if (p.real < 0) hp.virtual_fills.push_back({pack_of(p, p.vars)});     // virtual clique: a resident 0/1 table
+        if (hp.tmix) {
+            p.tmap_off = (int64_t)hp.itab.size();
+            hp.itab.insert(hp.itab.end(), p.tmap.begin(), p.tmap.end());
+        }
     }
     hp.pack.assign(N, JtPackDesc());
     for (int c = 0; c < N; ++c) hp.pack[c] = pack_of(hp.pn[c], hp.node_vars[c]);
@@ -1289,6 +1387,9 @@ int PlanBuilder::level_work() {
     for (int ph = 0; ph < 2; ++ph) lvl_elems[ph].assign(hp.n_ranks + 1, std::vector<double>(maxdepth + 1, 0.0));
     for (int c = 0; c < NP; ++c) {
         double e = (double)hp.pn[c].phys_elems;
+        // (a mixed-radix row holds trow of the 2^TB entries a workgroup step covers: workgroups are sized by steps,
+        //  as if the rows were full - sized by elements they came out at 8 rows of 500 bytes each, 6 x slower)
+        if (hp.pn[c].tmix && hp.pn[c].trow > 0) e *= (double)(1 << hp.TB) / (double)hp.pn[c].trow;
         if (c != hp.root) lvl_elems[0][hp.pn[c].owner][hp.pn[c].depth] += e;
         lvl_elems[1][hp.pn[c].owner][hp.pn[c].depth] += e;
     }
@@ -1358,8 +1459,12 @@ int PlanBuilder::make_tasks() {
             int real_bits = 0;
             for (int nb : p.nb) real_bits += nb;
             std::vector<int32_t> itab;
-            const double share = std::min(1.0, (double)p.phys_elems / std::max(1.0, lvl_elems[phase][p.owner][p.depth]));
-            int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner, p.layout != 4), err,
+            const double steps_scale = p.tmix && p.trow > 0 ? (double)(1 << hp.TB) / (double)p.trow : 1.0;     // (as in level_work)
+            const double share = std::min(1.0, (double)p.phys_elems * steps_scale / std::max(1.0, lvl_elems[phase][p.owner][p.depth]));
+            // (mixed-radix rows are a quarter of a full row or less, and whole variables - 2 or 3 bits - go in or out of the
+            //  loops together: such cliques may always use the 64 rows a workgroup can hold)
+            const int blg = p.tmix ? hp.TB + JT_MAX_ITER_LOG2 : block_log2_for(phase, p.depth, p.owner, p.layout != 4);
+            int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, hp.block_log2 > 0 ? std::max(hp.block_log2, hp.TB) : blg, err,
                                 hp.multiset ? JT_SETB_SMALL : 0, share);
             if (rc != JTP_OK && hp.multiset)
                 rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, block_log2_for(phase, p.depth, p.owner), err, JT_SETB_LARGE);
@@ -1723,8 +1828,8 @@ int PlanBuilder::finish() {
     // through to memory, which costs where staging is a large share of the traffic (config 3) and buys nothing on chains.
     {
         const bool merge = hp.knobs.merge_phases == 1 ||
-                           (hp.knobs.merge_phases < 0 && !hp.multiset && !hp.chain_plan && hp.staging_bytes * 8.0 <= hp.table_bytes);
-        if (merge && !hp.multiset) {
+                           (hp.knobs.merge_phases < 0 && !hp.multiset && !hp.chain_plan && !hp.tmix && hp.staging_bytes * 8.0 <= hp.table_bytes);
+        if (merge && !hp.multiset && !hp.tmix) {
             std::vector<Segment> segs;
             std::vector<Step> fsteps;
             for (const Step &st : hp.flow_steps) {
@@ -1828,6 +1933,10 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int>
     int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
     tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
+    if (hp.tmix) {                               // the task travels with its own table buffer: the clique's thread map behind its rows
+        tk.tmap_off = (int64_t)itab.size();
+        itab.insert(itab.end(), p.tmap.begin(), p.tmap.end());
+    }
     for (size_t k = 0; k < src.size(); ++k) {
         tk.msg[k].off = src[k].first;
         tk.msg[k].npart = src[k].second;
@@ -1857,6 +1966,10 @@ int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<
     int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
     tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
+    if (hp.tmix) {
+        tk.tmap_off = (int64_t)itab.size();
+        itab.insert(itab.end(), p.tmap.begin(), p.tmap.end());
+    }
     for (size_t k = 0; k < src.size(); ++k) {
         tk.msg[k].off = src[k].first;
         tk.msg[k].npart = src[k].second;
@@ -1906,7 +2019,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
       << ",\"root\":" << hp.root << ",\"arena_elems\":" << hp.arena_elems << ",\"msg_doubles\":" << hp.msg_doubles
       << ",\"dbg_base\":" << hp.dbg_base << ",\"max_lds\":" << hp.max_lds << ",\"alg_bytes\":" << (long long)hp.alg_bytes
       << ",\"staging_bytes\":" << (long long)hp.staging_bytes << ",\"table_bytes\":" << (long long)hp.table_bytes
-      << ",\"compact\":" << (hp.compact ? 1 : 0) << ",\"host_table_elems\":" << (long long)hp.host_table_elems
+      << ",\"compact\":" << (hp.compact ? 1 : 0) << ",\"tmix\":" << (hp.tmix ? 1 : 0) << ",\"host_table_elems\":" << (long long)hp.host_table_elems
       << ",\"multiset\":" << (hp.multiset ? 1 : 0) << ",\"alg_table_bytes\":" << (long long)hp.alg_table_bytes
       << ",\"alg_msg_bytes\":" << (long long)hp.alg_msg_bytes
       << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
@@ -1917,8 +2030,13 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         if (i) o << ",";
         o << "{\"real\":" << p.real << ",\"parent\":" << p.parent << ",\"psep\":" << p.psep << ",\"depth\":" << p.depth
           << ",\"owner\":" << p.owner << ",\"nbits\":" << p.nbits << ",\"arena_off\":" << p.arena_off
-          << ",\"phys_elems\":" << p.phys_elems << ",\"pad_mask\":" << p.pad_mask << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"down_tasks\":";
+          << ",\"phys_elems\":" << p.phys_elems << ",\"pad_mask\":" << p.pad_mask << ",\"tmix\":" << (p.tmix ? 1 : 0) << ",\"trow\":" << p.trow
+          << ",\"tpad_mask\":" << p.tpad_mask << ",\"tmap_off\":" << p.tmap_off << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"down_tasks\":";
         json_vec(o, p.down_tasks);
+        if (hp.tmix) {
+            o << ",\"tmap\":";
+            json_vec(o, p.tmap);
+        }
         o << ",\"bitw\":";
         json_vec(o, p.bitw);
         o << ",\"group_mask\":";
@@ -2018,7 +2136,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             if (t) o << ",";
             o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
-              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
+              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"tmap_off\":" << tk.tmap_off << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
             json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";

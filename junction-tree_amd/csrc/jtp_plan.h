@@ -27,6 +27,14 @@ struct PNode {                       // a clique of the (binarised) tree
     std::vector<int> group_pos, group_card;
     uint32_t pad_mask = 0;
     int64_t phys_elems = 0;
+    // thread part stored at TRUE cardinalities (round 3, "tmix"): the variables of the low TB index bits as mixed-radix
+    // digits - tmap[x] = element offset inside a row of logical thread index x, -1 where x names no entry - and rows of
+    // trow elements (the product of their cardinalities, rounded up to the vector width) instead of 2^TB
+    bool tmix = false;
+    int trow = 0;
+    uint32_t tpad_mask = 0;          // index bits below TB that no variable owns (a variable never straddles TB in a tmix clique)
+    std::vector<int32_t> tmap;
+    int64_t tmap_off = -1;           // offset (ints) of tmap in HostPlan::itab
     int collect_task = -1, distribute_task = -1;
     std::vector<int> down_tasks;     // multi-set plans: one task per child (its downward message), child order
 };
@@ -106,6 +114,8 @@ struct PlanKnobs {
     int no_search = 0;                                              // JTP_NO_SEARCH: layout policy 2 where the cost-model search (policy 4) would run
     int roctx = 0;                                                  // JTP_ROCTX: roctx ranges around propagates and read-outs
     double settle_level_elems = 8388608.0;                          // JTP_SETTLE_LEVEL_ELEMS: tasks on levels of at most this many table elements settle in place
+    int no_tmix = 0;                                                // JTP_NO_TMIX: thread parts stay padded bit fields (round-2 layout)
+    double tmix_fill = 0.6;                                         // JTP_TMIX_FILL: mixed-radix rows for cliques whose bit-field thread part would be emptier than this
     int merge_phases = -1;                                          // JTP_MERGE_PHASES: 1 / 0 = both phases in one dataflow launch / never; -1: where messages are small
 };
 PlanKnobs jtp_read_knobs();
@@ -143,6 +153,8 @@ struct HostPlan {
     int64_t arena_elems = 0;         // potential arena == belief arena size (elements), zero row included
     double host_table_elems = 0;     // sum of the true sizes of this rank's clique tables (arena_elems / this = padding factor)
     bool compact = true;             // rows above the thread part stored at true cardinalities (JTP_NO_COMPACT clears it)
+    bool tmix = false;               // some clique stores its thread part at true cardinalities: every task then addresses its
+                                     // elements through a per-clique map (PNode::tmap) and runs the *_mix kernels
     int64_t msg_doubles = 0;
     int64_t dbg_base = -1;           // JTP_DEBUG & 2: time-stamp region inside the message arena
     int max_lds = 0;

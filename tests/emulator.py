@@ -45,12 +45,18 @@ class Emulator:
                     x += dig.astype(np.int64) << pos
                 self.psi[p["arena_off"] + self._phys(p, x)] = 1.0
 
-    @staticmethod
-    def _phys(p, x):
-        """physical element offset of logical index x (offsets are linear in the index bits, jtp_internal.h)"""
+    def _phys(self, p, x):
+        """physical element offset of logical index x: linear in the index bits (jtp_internal.h) - except, in plans with a
+        mixed-radix thread part (`tmix`), inside a row, where the clique's thread map says where logical thread index
+        x mod 2^TB lies (callers only ask for entries that exist)"""
         out = np.zeros_like(x)
         for b, w in enumerate(p["bitw"]):
-            out += ((x >> b) & 1) * w
+            if b >= self.TB or "tmap" not in p:
+                out += ((x >> b) & 1) * w
+        if "tmap" in p:
+            t = np.asarray(p["tmap"], dtype=np.int64)[x & (self.row - 1)]
+            assert np.all(t >= 0), "a table entry whose thread index the map does not know"
+            out += t
         return out
 
     # ---------------------------------------------------------------- layout conversion
@@ -195,11 +201,41 @@ class Emulator:
         for m in ins:
             assert bool(m["e_dep"]) == any(m["e_w"][e] != 0 for e in range(EB))
 
-        itab = np.asarray(tk["itab"], dtype=np.int64).reshape(nA, nR, 8)      # row i = a * nR + r
-        assert tk["total"] == nA * nR and 2 <= tk["total"] <= 64
-        xoff = itab[:, :, 0] & 0xFFFFFFFF
-        for i in range(8):
-            assert tk["first_x"][i] == (xoff.ravel()[i] if i < tk["total"] else 0)
+        if self.d.get("tmix"):
+            # plans with mixed-radix rows: the table holds the rows that exist only, each with its place in the full loop
+            # nest (bits 16-21 of column 1 + JT_MAX_IN) and the "run of outgoing message j ends here" flags (bit 24 + j)
+            rows = np.asarray(tk["itab"], dtype=np.int64).reshape(-1, 8)
+            assert len(rows) == tk["total"] and 1 <= tk["total"] <= nA * nR <= 64
+            info = rows[:, 1 + JT_MAX_IN] & 0xFFFFFFFF
+            nest = (info >> 16) & 63
+            assert np.all(np.diff(nest) > 0) and np.all(info >> (24 + max(n_out, 0)) == 0)
+            for i in range(8):
+                assert tk["first_x"][i] == ((rows[i, 0] & 0xFFFFFFFF) if i < tk["total"] else NO_ROW)
+            for j in range(n_out):
+                run = (tk["out_run"] >> (8 * j)) & 0xFF
+                ends = (info >> (24 + j)) & 1
+                want = np.array([r + 1 == len(nest) or (nest[r + 1] >> run) != (nest[r] >> run) for r in range(len(nest))])
+                assert np.array_equal(ends.astype(bool), want), "run ends of outgoing message %d" % j
+            rows[:, 1 + JT_MAX_IN] = info & 0xFFFF
+            itab = np.zeros((nA * nR, 8), dtype=np.int64)
+            itab[:, 0] = NO_ROW
+            itab[nest] = rows
+            # (offsets of rows that do not exist are not stored: give them their run's, which the checks below compare)
+            for j in range(n_out):
+                run = (tk["out_run"] >> (8 * j)) & 0xFF
+                col = itab[:, 1 + JT_MAX_IN + j].reshape(-1, 1 << run)
+                have = (itab[:, 0] != NO_ROW).reshape(-1, 1 << run)
+                for g in range(len(col)):
+                    if have[g].any():
+                        col[g, :] = col[g, have[g]][0]
+            itab = itab.reshape(nA, nR, 8)
+            xoff = itab[:, :, 0] & 0xFFFFFFFF
+        else:
+            itab = np.asarray(tk["itab"], dtype=np.int64).reshape(nA, nR, 8)      # row i = a * nR + r
+            assert tk["total"] == nA * nR and 2 <= tk["total"] <= 64
+            xoff = itab[:, :, 0] & 0xFFFFFFFF
+            for i in range(8):
+                assert tk["first_x"][i] == (xoff.ravel()[i] if i < tk["total"] else 0)
         # rows that do not exist are marked; the marks must agree with the digits of the row's loop bits
         loopmask = sum(1 << b for b in tk["loop_pos"])
         row_ok = np.ones((nA, nR), dtype=bool)
@@ -219,9 +255,14 @@ class Emulator:
             flat = out_off[j].reshape(-1, 1 << run)
             assert np.all(flat == flat[:, :1])
         # element index of every (a, r, tid, e)
-        x = (xF + xoff[:, :, None, None]
-             + (tid * VEC)[None, None, :, None] + np.arange(VEC)[None, None, None, :]) & 0xFFFFFFFF
-        live = np.broadcast_to(row_ok[:, :, None, None], x.shape)
+        slot = (tid * VEC)[:, None] + np.arange(VEC)[None, :]                  # logical thread index of (tid, e)
+        if "tmap" in pn:        # mixed-radix thread part: the element's place inside the row comes from the clique's map
+            tmap = np.asarray(pn["tmap"], dtype=np.int64)[slot]
+            assert tk["tmap_off"] == pn["tmap_off"] or tk["tmap_off"] >= 0
+        else:
+            tmap = slot
+        x = (xF + xoff[:, :, None, None] + np.maximum(tmap, 0)[None, None, :, :]) & 0xFFFFFFFF
+        live = np.broadcast_to(row_ok[:, :, None, None], x.shape) & np.broadcast_to((tmap >= 0)[None, None, :, :], x.shape)
         assert x[live].max(initial=0) < pn["phys_elems"]
         assert len(np.unique(x[live])) == x[live].size            # every stored element visited at most once
         p = np.where(live, self.psi[tk["psi_off"] + np.where(live, x, 0)], 0.0)      # rows that do not exist read zeros

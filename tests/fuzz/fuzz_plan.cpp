@@ -122,11 +122,19 @@ static bool consistent(const HostPlan &hp, std::string &why) {
             for (int j = 0; j < tk.nF; ++j) fmax += tk.f_x[j];
             for (int i = 0; i < tk.total; ++i) {
                 const uint32_t off = (uint32_t)hp.itab[tk.itab_off + (int64_t)i * JT_NCOL];
-                if (off != JT_NO_ROW && (int64_t)off + ((int64_t)1 << hp.TB) > phys) return why = "row outside the table", false;
+                // (a row is 2^TB elements, or - thread part at true cardinalities - PNode::trow)
+                if (off != JT_NO_ROW && (int64_t)off + hp.pn[tk.pnode].trow > phys) return why = "row outside the table", false;
             }
             (void)fmax;
         }
         if (tk.itab_off < 0 || tk.itab_off + (int64_t)tk.total * JT_NCOL > (int64_t)hp.itab.size()) return why = "iteration table outside the buffer", false;
+        if (hp.tmix) {          // every entry of the clique's thread map: -1 or an offset inside a row
+            if (tk.tmap_off < 0 || tk.tmap_off + ((int64_t)1 << hp.TB) > (int64_t)hp.itab.size()) return why = "thread map outside the buffer", false;
+            for (int64_t x = 0; x < ((int64_t)1 << hp.TB); ++x) {
+                const int32_t po = hp.itab[tk.tmap_off + x];
+                if (po < -1 || po >= hp.pn[tk.pnode].trow) return why = "thread map entry outside the row", false;
+            }
+        } else if (tk.tmap_off != -1) return why = "thread map in a plan without one", false;
         for (int k = 0; k < tk.n_in + tk.n_out; ++k) {
             const JtMsg &m = tk.msg[k < tk.n_in ? k : JT_MAX_IN + (k - tk.n_in)];
             if (m.off < 0 || m.off + (int64_t)m.npart * m.pstride > hp.msg_doubles) return why = "message outside the arena", false;

@@ -838,15 +838,17 @@ def test_propagate_restages_only_cliques_whose_factors_changed(golden):
 
 @pytest.mark.parametrize("card,width,sep", [(3, 8, 4), (5, 6, 3), (6, 5, 2), (7, 5, 3), (3, 9, 5)])
 def test_wide_cliques_of_odd_cardinalities(card, width, sep):
-    """Tables whose variables above the thread part are stored at their true cardinality (mixed-radix rows, rows that
-    do not exist read the zero row): beliefs, Z and marginals vs the oracle in float64 and float32, dataflow and
+    """Tables stored at their true cardinalities - above the thread part (mixed-radix rows, rows that do not exist read
+    the zero row: round 2) and inside it (round 3: the thread part's variables are mixed-radix digits of a row, arena
+    <= 1.25 x the host tables for cardinality 3 width 8/9 and cardinality 5 width 6): beliefs, Z and marginals vs the oracle in float64 and float32, dataflow and
     per-level launches, the padded round-1 layout for comparison (bit-identical results are not expected: the
     summation order differs), hard evidence (its masks are over the LOGICAL index) and multi-set plans."""
     spec = synthetic.wide_binary_tree(n_cliques=7, width=width, sep=sep, card=card, seed=card)
     pots = synthetic.potentials_for(spec, seed=11)
     want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
     arenas = {}
-    for opts in ({}, {"level_launches": True}, {"no_compact": True}, {"block_log2": 10}):
+    host_elems = sum(card ** width for _ in range(spec["n_cliques"]))
+    for opts in ({}, {"level_launches": True}, {"no_compact": True}, {"block_log2": 10}, {"split_variants": True}, {"flow_tickets": True}):
         for dtype in ("f64", "f32"):
             cast = [p.astype(np.float32) for p in pots] if dtype == "f32" else pots
             ref = oracle.beliefs_exact(spec["tree"], cast, spec["node_vars"]) if dtype == "f32" else want
@@ -854,6 +856,13 @@ def test_wide_cliques_of_odd_cardinalities(card, width, sep):
             d = plan.describe()
             arenas[bool(opts.get("no_compact"))] = d["arena_elems"]
             assert d["compact"] == (0 if opts.get("no_compact") else 1)
+            # round 3: the thread part too is stored at true cardinalities (mixed-radix rows reached through a per-clique
+            # thread map, kernels *_mix): the arena is the host tables plus alignment, not (4/3)^5 = 4.2 x them
+            # (cliques whose bit-field thread part would be at least 0.6 full keep it: cardinality 7, (7/8)^3)
+            assert d["tmix"] == (0 if opts.get("no_compact") or card == 7 else 1)
+            if not opts.get("no_compact") and (card, width) in ((3, 8), (3, 9), (5, 6)):
+                assert d["arena_elems"] <= 1.25 * host_elems, (d["arena_elems"], host_elems)
+                assert all(p["trow"] < 2 ** d["TB"] for p in d["pnodes"] if p["tmix"])
             for c in range(spec["n_cliques"]):
                 plan.set_potential(c, cast[c])
             plan.propagate()
