@@ -15,9 +15,10 @@ MRF of cardinality 8, junction tree by this repo's own builder) in the same form
 
 Prints ONE JSON line on rank 0.  `value` = algorithmic clique-potential GB/s of the whole
 job (SURVEY.md 8d definition of algorithmic bytes), `messages_per_sec` beside it.
-`roofline` is for the dominant kernel (jt_distribute_flow: the whole distribute phase in one
-launch), timed with hipEvents on the plan's own stream during the timed steps: one event before
-and one after the launch in every propagate.  `cpu_baseline` times the numpy restatement of the
+`roofline` is for the dominant kernel (config 4: jt_propagate_flow, both phases of the propagate
+in one dataflow launch; configs 2 and 3: jt_distribute_flow[_chain], the whole distribute phase in
+one launch), timed with hipEvents on the plan's own stream during the timed steps: one event
+before and one after the launch in every propagate.  `cpu_baseline` times the numpy restatement of the
 reference's einsum sequence (oracle/jt_oracle.py: beliefs_refshaped) on one host core over a
 bounded sample of the same workload; it is a checker/baseline, never the measured path.
 
@@ -455,6 +456,11 @@ def main():
                                   for kn, kv in stats["kernels"].items()},
                 "collect_ms": stats["collect_ms"], "distribute_ms": stats["distribute_ms"],
             }
+            if any(kn.startswith("jt_propagate_flow") for kn in stats["kernels"]):
+                # both phases ran inside ONE launch (plans whose messages are small beside their tables): there is no
+                # boundary between the phases to put an event on
+                out["roofline"]["collect_ms"] = out["roofline"]["distribute_ms"] = None
+                out["roofline"]["phases_in_one_launch"] = True
         cpu_n = args.cpu_sample if args.cpu_sample >= 0 else {"c4": n, "c2": 100, "c3": 60}[args.config]
         if cpu_n > 0 and world == 1:
             if args.config == "c4":

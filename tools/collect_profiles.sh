@@ -1,35 +1,57 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): bench lines, rocprofv3 kernel trace + stats, PMC passes for HBM traffic
 # (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, never combined with a trace domain).  Everything lands under
-# gpurun_out/prof/; tools/summarize_profiles.py turns it into the files committed under profiles/.
+# gpurun_out/prof/; tools/summarize_profiles.py turns it into gpurun_out/prof/summary/, whose files are committed
+# under profiles/ as r03_*.  Every text file starts with the id of the library build it was measured on (the JSON
+# bench lines carry it in config.library; hbm_traffic*.json in "source_id"): bench.py quotes roofline.traffic only
+# when that id is the running library's.
+#   bash tools/collect_profiles.sh            (needs lib/libjtprop_stamps.so = build.py --out ... -DJT_STAMPS of the same sources)
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 B="python3 bench.py"
+L=junction-tree_amd/junctiontree_amd/lib
+ID="# library build: $(cat $L/BUILD_ID 2>/dev/null | tr '\n' ' ')"
+hdr() { echo "$ID" > $1; }          # start a text file with the build id
 timeout 300 $B --cpu-all-cores > $OUT/bench.json 2> $OUT/bench.err
-timeout 300 $B --steps 30 --warmup 3 --cpu-sample 0 --level-launches --per-launch > $OUT/bench_level.json 2> $OUT/per_launch.txt
+hdr $OUT/per_launch.txt
+timeout 300 $B --steps 30 --warmup 3 --cpu-sample 0 --level-launches --per-launch > $OUT/bench_level.json 2>> $OUT/per_launch.txt
 timeout 300 $B --steps 20 --warmup 2 --cpu-sample 0 --no-profile --batch 4 > $OUT/bench_batch4.json 2>/dev/null
 timeout 300 $B --steps 10 --warmup 2 --cpu-sample 0 --batch 16 --share > $OUT/bench_c5_share16.json 2>/dev/null
 for n in 8 16 64; do timeout 300 $B --steps 10 --warmup 2 --cpu-sample 0 --batch $n --multiset > $OUT/bench_c5_multiset$n.json 2>/dev/null; done
 timeout 600 $B --steps 20 --warmup 3 --config c2 > $OUT/bench_c2.json 2>/dev/null
-timeout 600 python3 tools/run_c3.py > $OUT/c3.txt 2>&1
-JTP_DEBUG=2 timeout 300 python3 tools/stamps.py > $OUT/stage_times.txt 2>&1
-JTP_DEBUG=2 timeout 300 python3 tools/stamps.py multi 8 > $OUT/stage_times_multiset8.txt 2>&1
-timeout 300 python3 tools/rank_time.py 8 20 > $OUT/rank_time_8.txt 2>&1
+timeout 900 $B --steps 10 --warmup 3 --config c3 > $OUT/bench_c3.json 2>/dev/null
+# a second, idle plan on the device (round 2: ticket order for everybody, +10 %; round 3: tickets only while
+# another plan's propagate is in flight)
+for k in 0 1 0 1; do timeout 300 $B --steps 40 --warmup 10 --cpu-sample 0 --idle-plans $k >> $OUT/idle_plans_ab.jsonl 2>/dev/null; done
+hdr $OUT/rank_time_8.txt; timeout 300 python3 tools/rank_time.py 8 30 >> $OUT/rank_time_8.txt 2>&1
+hdr $OUT/odd_cardinalities.txt
+for a in "3 13 6 63 f32" "3 12 6 63 f64" "5 9 4 63 f32" "6 8 4 63 f32" "7 7 3 63 f32"; do timeout 300 python3 tools/odd_time.py $a >> $OUT/odd_cardinalities.txt 2>&1; done
+if [ -f $L/libjtprop_stamps.so ]; then
+  export JTPROP_LIB=$L/libjtprop_stamps.so JTP_DEBUG=2
+  hdr $OUT/stage_times.txt; timeout 300 python3 tools/stamps.py >> $OUT/stage_times.txt 2>&1
+  hdr $OUT/stage_times_c2.txt; STAMPS_SUMMARY=1 timeout 300 python3 tools/stamps.py c2 1000 >> $OUT/stage_times_c2.txt 2>&1
+  hdr $OUT/stage_times_c3.txt; STAMPS_SUMMARY=1 timeout 600 python3 tools/stamps.py c3 167 >> $OUT/stage_times_c3.txt 2>&1
+  hdr $OUT/stage_times_multiset8.txt; timeout 300 python3 tools/stamps.py multi 8 >> $OUT/stage_times_multiset8.txt 2>&1
+  hdr $OUT/stage_times_rank0_of_8.txt; STAMPS_SUMMARY=1 timeout 300 python3 tools/stamps.py ranks 8 0 >> $OUT/stage_times_rank0_of_8.txt 2>&1
+  hdr $OUT/timeline_c3.txt; timeout 600 python3 tools/timeline.py c3 167 2>&1 | awk 'NR % 50 == 1 || /phase/' >> $OUT/timeline_c3.txt
+  unset JTPROP_LIB JTP_DEBUG
+fi
 echo "benches done" > $OUT/progress.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 > $OUT/kt_bench.json 2> $OUT/kt.err
 echo "kernel trace done" >> $OUT/progress.txt
 # HBM traffic: case name -> bench arguments
 pmc() {   # $1 = case, rest = bench arguments
   local c=$1; shift
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$c -o p -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-profile "$@" > /dev/null 2> $OUT/fetch_$c.err
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$c -o p -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-profile "$@" > /dev/null 2> $OUT/write_$c.err
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$c -o p -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-profile "$@" > /dev/null 2> $OUT/fetch_$c.err
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$c -o p -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-profile "$@" > /dev/null 2> $OUT/write_$c.err
   echo "pmc $c done" >> $OUT/progress.txt
 }
 pmc single
-pmc share16 --batch 16 --share
 pmc multiset16 --batch 16 --multiset
 pmc multiset64 --batch 64 --multiset
+pmc c2 --config c2
+pmc c3 --config c3
 timeout 600 rocprofv3 --pmc VALUBusy --output-format csv -d $OUT/valu_multiset16 -o p -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-profile --batch 16 --multiset > /dev/null 2> $OUT/valu.err
 # keep what travels back small: the per-dispatch traces are reduced here
 python3 tools/summarize_profiles.py $OUT

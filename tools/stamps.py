@@ -47,7 +47,7 @@ only_big = len(sys.argv) > 1 and sys.argv[1] == "c3"
 fine_names = ["rec+issue", "1st attempt", "wait+restage", "consts", "step0", "step1", "step2", "step3", "more steps", "epilogues", "flush issue", "flush retire"]
 fine_cols = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
 for L in d["launches"]:
-    if only_big and L["nblocks"] < 4096:
+    if only_big and L["nblocks"] < 1000:
         continue
     if L["variant"] == 16:          # reduce tasks carry no time stamps
         continue

@@ -9,6 +9,16 @@ src = sys.argv[1]
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 
+# the library build everything here was measured on: bench.py quotes `roofline.traffic` from hbm_traffic.json only when
+# this id is the running library's (junction-tree_amd/build.py writes lib/BUILD_ID: "<source id> <git head at build time>")
+try:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd", "junctiontree_amd", "lib", "BUILD_ID")) as fh:
+        build = fh.read().split()
+except OSError:
+    build = []
+source_id = build[0] if build else "unknown"
+git_head = build[-1] if len(build) > 1 else "unknown"
+
 
 def rows(pattern):
     for path in glob.glob(os.path.join(src, pattern), recursive=True):
@@ -21,6 +31,7 @@ def rows(pattern):
 stats = [r for r in rows("kt/**/*kernel_stats.csv") if "jt_" in r.get("Name", "")]
 if stats:
     with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as fh:
+        fh.write("# library build: %s git %s (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --cpu-sample 0)\n" % (source_id, git_head))
         w = csv.DictWriter(fh, fieldnames=list(stats[0].keys()))
         w.writeheader()
         w.writerows(stats)
@@ -56,15 +67,15 @@ note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over
         "[case arguments]`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); averages "
         "over all launches of the kernel (one launch per phase)")
 traffic = all_traffic.get("single", {})
-json.dump({"note": note, "kernels": traffic}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-json.dump({"note": note + "; cases: single = the default bench (one evidence set); share16 = 16 sets, one copy of the tables, "
-           "one pass per set (round 1); multiset16/64 = 16/64 sets, one pass per group of eight sets", "cases": all_traffic},
+json.dump({"source_id": source_id, "git_head_at_build": git_head, "note": note, "kernels": traffic}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+json.dump({"source_id": source_id, "git_head_at_build": git_head, "note": note + "; cases: single = the default bench (one evidence set); share16 = 16 sets, one copy of the tables, "
+           "one pass per set (round 1); multiset16/64 = 16/64 sets, one pass per group of eight sets; c2 / c3 = bench.py --config c2 / c3", "cases": all_traffic},
           open(os.path.join(dst, "hbm_traffic_cases.json"), "w"), indent=1)
 valu = defaultdict(list)
 for r in rows("valu_*/**/*counter_collection.csv"):
     if "jt_" in r.get("Kernel_Name", ""):
         valu[r["Kernel_Name"].split("(")[0] + " " + r["Counter_Name"]].append(float(r["Counter_Value"]))
-json.dump({k: sum(v) / len(v) for k, v in valu.items()}, open(os.path.join(dst, "valu_multiset16.json"), "w"), indent=1)
-json.dump(trace, open(os.path.join(dst, "kernel_trace_summary.json"), "w"), indent=1)
+json.dump(dict({k: sum(v) / len(v) for k, v in valu.items()}, source_id=source_id), open(os.path.join(dst, "valu_multiset16.json"), "w"), indent=1)
+json.dump(dict(trace, source_id=source_id), open(os.path.join(dst, "kernel_trace_summary.json"), "w"), indent=1)
 print(json.dumps(trace, indent=1))
 print(json.dumps(all_traffic, indent=1))
