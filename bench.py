@@ -385,8 +385,20 @@ def main():
 
     stats = plan.stats()
     z = plan.z() if plan.owns(plan.root) else None
+    belief_dev = None
     if world > 1:                                    # the rank holding the root clique knows Z: share it
         z = rdzv.allreduce_max(z if z is not None else -1.0e300)
+        # ... and every rank checks the DISTRIBUTE side of the sharded run on cliques of its own (Z only proves the
+        # collect side): a clique belief sums to Z whatever the clique.  First, middle and last clique a rank owns, one
+        # single-variable marginal each (formed on the device); the worst relative deviation over all ranks goes
+        # into the line.
+        mine = [c for c in range(n) if plan.owns(c)]
+        picks = sorted({mine[0], mine[len(mine) // 2], mine[-1]}) if mine else []
+        dev = 0.0
+        if picks:
+            for m in plan.marginals([(c, [spec["node_vars"][c][0]]) for c in picks]):
+                dev = max(dev, abs(float(m.sum()) - z) / abs(z))
+        belief_dev = rdzv.allreduce_max(dev)
     if args.per_launch and not args.no_profile and rank == 0:
         for L in plan.launch_ms():
             print("# %s level %d: %4d tasks %5d blocks %8.4f ms %7.0f GB/s" % (
@@ -484,6 +496,7 @@ def main():
             out["config"]["Z_expected"] = Z_DEFAULT_C4
             out["config"]["Z_rel_err"] = abs(z - Z_DEFAULT_C4) / Z_DEFAULT_C4
         if world > 1:
+            out["config"]["sharded_belief_sums_rel_err"] = belief_dev      # (three cliques per rank: sum of the belief vs Z)
             out["config"]["multi_gpu_note"] = ("transport: %s" % os.environ["JTP_RCCL_LIB"] if os.environ.get("JTP_RCCL_LIB")
                                                else "transport: RCCL (librccl.so.1), ncclSend/ncclRecv grouped per cut level")
         if args.share or args.multiset:

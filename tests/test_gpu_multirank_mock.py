@@ -159,6 +159,8 @@ def test_bench_starts_its_own_ranks(gpus):
     out = json.loads(lines[0])
     assert out["n_gpus"] == gpus and out["steps"] == 5 and out["scaling"] == "strong"
     assert out["config"]["Z_rel_err"] <= 1e-6, out["config"]
+    # (the distribute side of the sharded run: three clique beliefs per rank sum to Z)
+    assert out["config"]["sharded_belief_sums_rel_err"] <= 1e-6, out["config"]
     assert out["config"]["launch_mode"] == "flow_tickets"          # ranks share the GPU here
     assert out["value"] > 0 and out["ms_per_step"] > 0
 

@@ -1,7 +1,8 @@
 """Diagnostic: JTPROP_LIB=<build with -DJT_STAMPS> JTP_DEBUG=2 python tools/stamps.py [c2 N | c3 W | multi SETS | ranks WORLD RANK]
 -> per-level stage timings of one propagate, and how long after the previous level's last workgroup each level's last one ends."""
-import os, sys
+import os, sys, warnings
 import numpy as np
+warnings.filterwarnings("ignore", category=RuntimeWarning)      # medians over stage slots a short loop never reaches
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _stamps
 from junctiontree_amd import engine, partition, synthetic
