@@ -604,6 +604,7 @@ PlanKnobs jtp_read_knobs() {
     k.tmix_fill = getd("JTP_TMIX_FILL", 0.6);
     k.settle_level_elems = getd("JTP_SETTLE_LEVEL_ELEMS", 8388608.0);
     k.top_min_loop = geti("JTP_TOP_MIN_LOOP", 3);
+    k.longest_first = geti("JTP_LONGEST_FIRST", 1);
     k.top_share = getd("JTP_TOP_SHARE", 0.12);
     return k;
 }
@@ -1703,6 +1704,14 @@ int PlanBuilder::schedule() {
             L.level = level;
             L.variant = g.first;
             L.tasks = g.second;
+            if (hp.knobs.longest_first) {
+                // Longest workgroups first: a level is over when its LAST workgroup is, and the workgroups of one task all
+                // take about as long as each other.  Multi-set plans: the tasks that cannot sum a vector's four elements
+                // before the message product (JtTask::esum == 0, 8 % of them on the width-20 tree) run 4-5 x longer per
+                // row - sixteen such workgroups, started two thirds into their level, ended 140 us after everybody else.
+                auto weight = [&](int t) { return (long)hp.tasks[t].total * (hp.multiset && !hp.tasks[t].esum ? 4 : 1); };
+                std::stable_sort(L.tasks.begin(), L.tasks.end(), [&](int a, int b) { return weight(a) > weight(b); });
+            }
             L.blk_off = (int64_t)hp.blocks.size();
             for (int t : L.tasks) {
                 const JtTask &tk = hp.tasks[t];

@@ -113,6 +113,7 @@ struct PlanKnobs {
     int search_all = 1;                                             // JTP_SEARCH_ALL=0: the search only where policy 2 would have been chosen (else policy 3 stays)
     int no_search = 0;                                              // JTP_NO_SEARCH: layout policy 2 where the cost-model search (policy 4) would run
     int roctx = 0;                                                  // JTP_ROCTX: roctx ranges around propagates and read-outs
+    int longest_first = 1;                                          // JTP_LONGEST_FIRST: within a level, tasks with the longest workgroups go first in the block list
     int top_min_loop = 3;                                           // JTP_TOP_MIN_LOOP: log2 of the fewest rows per workgroup on levels of a few cliques (searched splits)
     double top_share = 0.12;                                        // JTP_TOP_SHARE: ... a clique holding at least this share of its level's elements
     double settle_level_elems = 8388608.0;                          // JTP_SETTLE_LEVEL_ELEMS: tasks on levels of at most this many table elements settle in place
