@@ -9,7 +9,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 cases = [("c4", synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card=2, seed=0), "f32", reps),
          ("mid", synthetic.wide_binary_tree(n_cliques=63, width=16, sep=8, card=2, seed=3), "f64", reps),
          ("random", synthetic.random_tree(n_cliques=40, width=14, sep=6, card=2, seed=5), "f32", reps),
-         ("chain", synthetic.chain_tree(n_cliques=60, card=16, width=3), "f64", reps)]
+         ("chain", synthetic.chain_tree(n_cliques=60, card=16, width=3), "f64", reps),
+         ("odd", synthetic.wide_binary_tree(n_cliques=15, width=10, sep=5, card=3, seed=2), "f32", reps)]     # mixed-radix rows (kernels *_mix)
 for name, spec, dt, n in cases:
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dt)
     plan.fill_synthetic(1, spec["scales"])
