@@ -590,6 +590,7 @@ PlanKnobs jtp_read_knobs() {
     k.target_blocks_c = getd("JTP_TARGET_BLOCKS", 1024.0);
     k.target_blocks_d = getd("JTP_TARGET_BLOCKS_D", k.target_blocks_c);
     k.min_block_log2 = geti("JTP_MIN_BLOCK_LOG2", 13);
+    k.multi_min_block_log2 = geti("JTP_MULTI_MIN_BLOCK_LOG2", 16);
     k.max_block_log2 = geti("JTP_MAX_BLOCK_LOG2", 16);
     k.max_block_log2_d = geti("JTP_MAX_BLOCK_LOG2_D", std::min(k.max_block_log2, 15));
     k.tiny_level_elems = getd("JTP_TINY_LEVEL_ELEMS", 2097152.0);
@@ -664,7 +665,13 @@ int PlanBuilder::block_log2_for(int phase, int level, int owner, bool tiny_rule)
         // (the distribute pass - read + write - streams best in workgroups of at most 32 rows: config 4 0.4345 -> 0.4300 ms,
         //  the collect pass in up to 64: 0.2055 against 0.2084 ms; multi-set plans - whose second phase is marginalisations,
         //  not a read + write pass - keep 64: 1.058 against 1.074 ms)
-        const int lgmin = hp.knobs.min_block_log2, lgmax = phase == 1 && !hp.multiset ? hp.knobs.max_block_log2_d : hp.knobs.max_block_log2;
+        // (multi-set plans: always the 64 rows a workgroup can hold - a step serves eight evidence sets, so a workgroup's fixed
+        //  cost, eight sets' sub-boxes staged through 8-byte loads, weighs more against its loop than in single-set plans:
+        //  64 evidence sets 6.73 -> 6.11 ms, env sweep on one box; 512 / 256 / 128 workgroups per level as the target:
+        //  6.33 / 6.16 / 6.11;
+        //  one group of eight sets alone is too few workgroups for that: 1.03 -> 1.13 ms; 16 sets 1.82 -> 1.80)
+        const int lgmin = hp.multiset && hp.n_batch > JT_MSETS ? hp.knobs.multi_min_block_log2 : hp.knobs.min_block_log2;
+        const int lgmax = phase == 1 && !hp.multiset ? hp.knobs.max_block_log2_d : hp.knobs.max_block_log2;
         // levels of a clique or two are latency bound: 4 iterations per workgroup, so that every element
         // load is already in flight while the workgroup waits for its messages
         const double tiny = hp.knobs.tiny_level_elems;

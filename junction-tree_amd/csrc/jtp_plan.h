@@ -104,6 +104,7 @@ struct PlanKnobs {
     int reduce_min = -1;             // JTP_REDUCE_MIN: partial copies from which a reduce task sums them (-1: default)
     double target_blocks_c = 1024.0, target_blocks_d = 1024.0;     // JTP_TARGET_BLOCKS(_D): workgroups per tree level
     int min_block_log2 = 13, max_block_log2 = 16;                   // JTP_MIN/MAX_BLOCK_LOG2
+    int multi_min_block_log2 = 16;                                  // JTP_MULTI_MIN_BLOCK_LOG2: ... of multi-set plans
     int max_block_log2_d = 15;                                      // JTP_MAX_BLOCK_LOG2_D: the cap for the distribute pass
     double tiny_level_elems = 2097152.0;                            // JTP_TINY_LEVEL_ELEMS
     int force_level_launches = 0, force_flow = 0, fake_comm = 0;   // JTP_FORCE_LEVEL_LAUNCHES / JTP_FORCE_FLOW / JTP_FAKE_COMM
