@@ -64,7 +64,12 @@ def compute_beliefs(tree, potentials, clique_vars, dl=sum_product):
     """Consistent beliefs for every node of the junction tree (cliques and separators)."""
     from . import engine
 
-    if not isinstance(dl, HipSumProduct):
+    # The reference's own call form - `compute_beliefs(tree, potentials, clique_vars, SumProduct(numpy.einsum))`,
+    # `tests/test_computation.py:46-48` - names exactly the law the device implements, so it is accepted and runs on
+    # the GPU like the default; any OTHER callable could be a different semiring and is refused (no host path here).
+    plain_numpy = (type(dl).__name__ == "SumProduct" and getattr(dl, "func", None) is np.einsum
+                   and not getattr(dl, "args", ()) and not getattr(dl, "kwargs", {}))
+    if not isinstance(dl, HipSumProduct) and not plain_numpy:
         raise TypeError(
             "this build runs the sum-product law on the GPU only; pass "
             "junctiontree_amd.computation.sum_product (got %r).  A custom einsum callable "

@@ -10,6 +10,7 @@ import junctiontree_amd as jt
 from conftest import as_tree
 from junctiontree_amd import computation as comp
 from junctiontree_amd import engine, synthetic
+from junctiontree_amd.sum_product import SumProduct
 
 pytestmark = pytest.mark.gpu
 
@@ -319,12 +320,27 @@ def test_sum_product_einsum_on_device_and_evidence_shrinking():
     close(comp.sum_product.einsum(A, ["x", "y", "z"], ["y", "x"]), A.sum(axis=2).T)
 
 
+def test_the_reference_call_form_with_numpy_einsum_runs_on_the_device():
+    """`compute_beliefs(tree, potentials, clique_vars, SumProduct(numpy.einsum))` - how the reference's own tests call it
+    (tests/test_computation.py:46-48) - names the law the device implements: same result as the default."""
+    rng = np.random.default_rng(5)
+    tree = [0, (3, [1]), (4, [2])]
+    node_vars = [["a", "b"], ["b", "c"], ["a", "d"], ["b"], ["a"]]
+    pots = [rng.random((2, 3)), rng.random((3, 4)), rng.random((2, 5)), np.ones(3), np.ones(2)]
+    got = comp.compute_beliefs(tree, pots, node_vars, SumProduct(np.einsum))
+    want = oracle.beliefs_exact(tree, pots, node_vars)
+    for g, w in zip(got, want):
+        close(g, w, rtol=RTOL64)
+
+
 def test_errors():
     with pytest.raises(ValueError):
         comp.compute_beliefs([0, (2, [1])], [np.ones((2, 3)), np.ones((4, 2)), np.ones(3)],
                              [[1, 2], [2, 3], [2]])                 # 3 vs 4 along variable 2
     with pytest.raises(TypeError):
         comp.compute_beliefs([0], [np.ones(2)], [[1]], dl=object())
+    with pytest.raises(TypeError):              # another callable could be another semiring: refused, there is no host path
+        comp.compute_beliefs([0], [np.ones(2)], [[1]], dl=SumProduct(lambda *a, **k: np.einsum(*a, **k)))
     plan = engine.Plan([0], [[1, 2]], {1: 2, 2: 3})
     with pytest.raises(ValueError):
         plan.set_potential(0, np.ones((2, 2)))
