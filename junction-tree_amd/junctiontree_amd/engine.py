@@ -73,6 +73,17 @@ class Plan:
         self.parent = parent
         self.root = order[0]
 
+        # More than 32 variables on a node (the C ABI's limit; the reference, through numpy.einsum, takes 52 labels): a
+        # table is at most 2^31 entries, so all but 31 of them have cardinality 1 - such variables own no index bit and
+        # are kept on the host only: the device sees the nodes without them, arrays lose / regain the length-1 axes by
+        # a reshape.  (Only then: trees within the limit are passed on as they are.)
+        try:
+            wide = any(len(node_vars[n]) > _capi.MAX_VARS for n in self.node_ids)
+            self._trivial = {lab for n in self.node_ids for lab in node_vars[n] if int(sizes[lab]) == 1} if wide else set()
+        except KeyError as exc:                           # the reference raises KeyError too
+            raise KeyError(exc.args[0])
+        full_vars = node_vars
+        node_vars = {n: [lab for lab in full_vars[n] if lab not in self._trivial] for n in self.node_ids}
         labels = {}
         for n in self.node_ids:
             for lab in node_vars[n]:
@@ -81,10 +92,10 @@ class Plan:
         self.var_labels = list(labels)
         try:
             self.card = [int(sizes[lab]) for lab in self.var_labels]
-        except KeyError as exc:                           # the reference raises KeyError too
+        except KeyError as exc:
             raise KeyError(exc.args[0])
-        self.node_vars = {n: list(node_vars[n]) for n in self.node_ids}
-        self.node_shape = {n: tuple(int(sizes[lab]) for lab in node_vars[n]) for n in self.node_ids}
+        self.node_vars = {n: list(full_vars[n]) for n in self.node_ids}
+        self.node_shape = {n: tuple(int(sizes[lab]) for lab in full_vars[n]) for n in self.node_ids}
         self.dtype = {"f32": _capi.JTP_F32, "f64": _capi.JTP_F64, np.float32: _capi.JTP_F32,
                       np.float64: _capi.JTP_F64}[dtype]
         self.n_batch = n_batch
@@ -144,6 +155,13 @@ class Plan:
         """This rank holds the clique: it is the owner, or the clique is replicated (owner == n_ranks)."""
         return self.owner[self.abi_of[clique]] in (self.rank, self.n_ranks) or self.n_ranks == 1
 
+    def _drop_trivial(self, arr, labels):
+        """`arr` without the axes of the host-only (one-state) variables; such an axis has length 1, so this is a reshape."""
+        for ax, lab in enumerate(labels):
+            if lab in self._trivial and arr.shape[ax] != 1:
+                raise ValueError("axis %d belongs to variable %r of cardinality 1 but has length %d" % (ax, lab, arr.shape[ax]))
+        return arr.reshape([arr.shape[ax] for ax, lab in enumerate(labels) if lab not in self._trivial])
+
     # ------------------------------------------------------------------ data in
     def set_potential(self, node, array, batch=0):
         """Upload the potential of clique `node` (caller's index).  The array must have one
@@ -157,6 +175,8 @@ class Plan:
         if arr.ndim != len(full):
             raise ValueError("potential of node %r has %d axes, its variable list has %d"
                              % (node, arr.ndim, len(full)))
+        if self._trivial:
+            arr = self._drop_trivial(arr, self.node_vars[node])
         shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
         host_dtype = _capi.JTP_F32 if arr.dtype == np.float32 else _capi.JTP_F64
         _capi.check(self._lib.jtp_set_potential(self._handle, batch, self.abi_of[node],
@@ -181,6 +201,9 @@ class Plan:
             a = np.ascontiguousarray(a).reshape(a.shape)
             if a.ndim != len(labels):
                 raise ValueError("factor %d has %d axes but %d variables" % (i, a.ndim, len(labels)))
+            if self._trivial:
+                a = self._drop_trivial(a, labels)
+                labels = [lab for lab in labels if lab not in self._trivial]
             ids = _int_array([self.var_id[lab] for lab in labels])
             shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
             keep += [a, ids, shape]
@@ -195,6 +218,11 @@ class Plan:
         """Hard evidence of evidence set `batch`: `observed` maps variable label -> observed state; it
         replaces the set's previous evidence ({} clears it) and applies from the next propagate."""
         labels = list(observed)
+        if self._trivial:
+            for lab in labels:
+                if lab in self._trivial and int(observed[lab]) != 0:
+                    raise ValueError("variable %r has one state: observed state %r" % (lab, observed[lab]))
+            labels = [lab for lab in labels if lab not in self._trivial]
         ids = _int_array([self.var_id[lab] for lab in labels])
         states = _int_array([int(observed[lab]) for lab in labels])
         _capi.check(self._lib.jtp_set_evidence(self._handle, batch, len(labels), C.cast(ids, C.POINTER(C.c_int32)),
@@ -237,8 +265,9 @@ class Plan:
 
     def marginal(self, clique, labels, batch=0):
         """Marginal of the clique belief onto `labels` (in that axis order), float64."""
+        shape = tuple(1 if lab in self._trivial else self.card[self.var_id[lab]] for lab in labels)
+        labels = [lab for lab in labels if lab not in self._trivial]
         ids = _int_array([self.var_id[lab] for lab in labels])
-        shape = tuple(self.card[self.var_id[lab]] for lab in labels)
         out = np.empty(shape, dtype=np.float64)
         _capi.check(self._lib.jtp_get_marginal(self._handle, batch, self.abi_of[clique],
                                                C.cast(ids, C.POINTER(C.c_int32)), len(labels),
@@ -254,10 +283,10 @@ class Plan:
         cliques = _int_array([self.abi_of[c] for c, _ in requests])
         var_off, var_ids, out_off, shapes = [0], [], [0], []
         for _, labels in requests:
-            ids = [self.var_id[lab] for lab in labels]
+            ids = [self.var_id[lab] for lab in labels if lab not in self._trivial]
             var_ids += ids
             var_off.append(len(var_ids))
-            shape = tuple(self.card[i] for i in ids)
+            shape = tuple(1 if lab in self._trivial else self.card[self.var_id[lab]] for lab in labels)
             shapes.append(shape)
             out_off.append(out_off[-1] + int(np.prod(shape, dtype=np.int64)) if shape else out_off[-1] + 1)
         flat = np.empty(out_off[-1], dtype=np.float64)

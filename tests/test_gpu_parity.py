@@ -333,6 +333,32 @@ def test_the_reference_call_form_with_numpy_einsum_runs_on_the_device():
         close(g, w, rtol=RTOL64)
 
 
+def test_more_than_32_variables_on_a_node_when_the_rest_have_one_state():
+    """tests/test_planner_emulated.py, same case, through the device: beliefs, marginals over labels that include one-state
+    variables, evidence on a one-state variable."""
+    from test_planner_emulated import wide_node_case
+    tree, node_vars, sizes, pots = wide_node_case()
+    want = oracle.beliefs_exact(tree, pots, node_vars)
+    got = comp.compute_beliefs(tree, pots, node_vars)
+    for n in range(5):
+        assert got[n].shape == want[n].shape
+        close(got[n], want[n])
+    plan = engine.Plan(tree, node_vars, sizes)
+    for c in range(3):
+        plan.set_potential(c, pots[c])
+    plan.set_evidence({"u3": 0})
+    plan.propagate()
+    m = plan.marginal(0, ["u1", "b", "u25", "a"])
+    assert m.shape == (1, 3, 1, 2)
+    close(m, want[0].sum(axis=node_vars[0].index("c")).reshape(-1).reshape(2, 3).T.reshape(1, 3, 1, 2))
+    ms = plan.marginals([(1, ["d", "u0"]), (0, ["u29"])])
+    assert ms[0].shape == (4, 1) and ms[1].shape == (1,)
+    close(ms[1], np.array([want[0].sum()]))
+    with pytest.raises(ValueError):
+        plan.set_evidence({"u3": 1})
+    plan.close()
+
+
 def test_errors():
     with pytest.raises(ValueError):
         comp.compute_beliefs([0, (2, [1])], [np.ones((2, 3)), np.ones((4, 2)), np.ones(3)],

@@ -366,3 +366,33 @@ def test_rows_above_the_thread_part_are_stored_at_true_cardinalities(card, width
         assert sizes[True] < sizes[False]
         print("card %d width %d: host %d, compact arena %d (%.2fx), padded arena %d (%.2fx)" % (
             card, width, host, sizes[True], sizes[True] / host, sizes[False], sizes[False] / host))
+
+
+def wide_node_case():
+    """A 3-clique tree whose root clique lists 33 variables, 30 of them with one state."""
+    rng = np.random.default_rng(3)
+    ones = ["u%d" % i for i in range(30)]
+    sizes = dict({lab: 1 for lab in ones}, a=2, b=3, c=2, d=4, e=2)
+    node_vars = [ones[:20] + ["a", "b", "c"] + ones[20:], ["b", "c", "d"] + ones[:5], ["c", "e"], ["b", "c"] + ones[3:5], ["c"]]
+    tree = [0, (3, [1]), (4, [2])]
+    pots = [rng.random([sizes[lab] for lab in node_vars[n]]) for n in range(3)] + [np.ones([sizes[lab] for lab in node_vars[n]]) for n in (3, 4)]
+    return tree, node_vars, sizes, pots
+
+
+def test_more_than_32_variables_on_a_node_when_the_rest_have_one_state():
+    """The reference takes up to 52 labels per einsum (sum_product.py:34-41); a dense table is at most 2^31 entries,
+    so beyond 31 variables the rest have cardinality 1.  engine.Plan keeps such variables on the host: the device
+    plan is that of the tree without them (the GPU side: test_gpu_parity.py, same case)."""
+    tree, node_vars, sizes, pots = wide_node_case()
+    assert len(node_vars[0]) == 33
+    plan = engine.Plan(tree, node_vars, sizes, plan_only=True)
+    d = plan.describe()
+    assert sorted(plan.var_id) == ["a", "b", "c", "d", "e"] and len(plan._trivial) == 30
+    assert plan.node_shape[0] == tuple(sizes[lab] for lab in node_vars[0])
+    assert plan._drop_trivial(pots[0], node_vars[0]).shape == (2, 3, 2)
+    with pytest.raises(ValueError):
+        plan._drop_trivial(np.ones((2,) + pots[0].shape[1:]), node_vars[0])      # a one-state variable's axis must have length 1
+    plan.close()
+    # the same tree with the one-state variables given two states is beyond the C ABI's limit, and says so
+    with pytest.raises(Exception, match="variables"):
+        engine.Plan(tree, node_vars, {lab: max(2, k) for lab, k in sizes.items()}, plan_only=True)
