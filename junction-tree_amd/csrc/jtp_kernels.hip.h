@@ -312,7 +312,6 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         JT_STAMP(1);
     };
     issue_tables();
-#ifndef JT_OLD_FLUSH
     if constexpr (EARLY_OUT) {
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
@@ -320,7 +319,6 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             so_hiv[j] = jt_sub_hi(so_fp[j], so_nfree[j], lane);
         }
     }
-#endif
 
     // ---- stage incoming sub-boxes (summing partial copies), zero outgoing sub-boxes -----
     // (the first element loads leave behind the first round of message loads).  Sub-boxes smaller than the workgroup
@@ -769,13 +767,18 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     using std::integral_constant;
     if constexpr (TMIX) {
         // any number of rows from 1 to 64 (the rows that exist); none at all for a chunk that does not
-        static_assert(U == 4, "the row loop of the mixed-radix kernels is written out for four slots");
         if (chunk_ok)
             for (int i0 = 0; i0 < total; i0 += U) {
                 step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, i0);
                 if (i0 + 1 < total) step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, i0 + 1);
                 if (i0 + 2 < total) step(integral_constant<int, 2>{}, integral_constant<int, 0>{}, i0 + 2);
                 if (i0 + 3 < total) step(integral_constant<int, 3>{}, integral_constant<int, 0>{}, i0 + 3);
+                if constexpr (U == 8) {       // (builds with -DJT_U=8 -DJT_RING_BYTES=32768: an experiment)
+                    if (i0 + 4 < total) step(integral_constant<int, 4 % U>{}, integral_constant<int, 0>{}, i0 + 4);
+                    if (i0 + 5 < total) step(integral_constant<int, 5 % U>{}, integral_constant<int, 0>{}, i0 + 5);
+                    if (i0 + 6 < total) step(integral_constant<int, 6 % U>{}, integral_constant<int, 0>{}, i0 + 6);
+                    if (i0 + 7 < total) step(integral_constant<int, 7 % U>{}, integral_constant<int, 0>{}, i0 + 7);
+                }
             }
     } else {
     {
@@ -846,25 +849,6 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             double *oth = msg_arena + fl.oth_off + at;          // the half the next propagate will use
             const bool mark = fl.oth_off >= 0;
             const int n = 1 << so_nfree[j];
-#ifdef JT_OLD_FLUSH
-            if constexpr (EARLY_OUT) {
-                const int nfree = so_nfree[j];
-                const uint32_t fp[4] = {so_fp[j][0], so_fp[j][1], so_fp[j][2], so_fp[j][3]};
-                int idx_t = 0;
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (b < nfree) idx_t += ((tid >> b) & 1) << JT_FPOS(fp, b);
-                for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
-                    int idx = idx_t;
-#pragma unroll
-                    for (int b = 8; b < JT_MAX_FREE; ++b)
-                        if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
-                    jt_msg_store<FLOW>(dst + idx, out_sub[j][s]);
-                    if (mark) oth[idx] = __longlong_as_double((long long)JT_UNWRITTEN);
-                }
-                continue;
-            }
-#endif
             for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
                 const uint32_t idx = so_glo[j] + (uint32_t)__builtin_amdgcn_readlane((int)so_hiv[j], it);
                 jt_msg_store<FLOW>(dst + idx, out_sub[j][s]);
