@@ -1,0 +1,39 @@
+"""One-off: N random factor graphs through the public API (jt.create_junction_tree + tree.propagate) against the brute-force joint.
+    python tools/gpu_fuzz_api.py [N] [first seed]"""
+import os, sys, time, string
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "junction-tree_amd"))
+import numpy as np
+import junctiontree_amd as jt
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+t0 = time.time()
+for seed in range(first, first + n):
+    rng = np.random.default_rng(seed)
+    nv = int(rng.integers(2, 11))
+    names = ["v%d" % i for i in range(nv)] if seed % 2 else list(range(nv))
+    sizes = {v: int(rng.integers(1, 5)) for v in names}
+    nf = int(rng.integers(1, 2 * nv))
+    factors = []
+    for _ in range(nf):
+        k = int(rng.integers(1, min(4, nv) + 1))
+        factors.append([names[i] for i in rng.choice(nv, size=k, replace=False)])
+    used = {v for f in factors for v in f}
+    f32 = seed % 3 == 0
+    values = [rng.uniform(0.2, 1.0, [sizes[v] for v in f]).astype(np.float32 if f32 else np.float64) for f in factors]
+    tree = jt.create_junction_tree(factors, sizes)
+    got = tree.propagate(values)
+    # brute force: the joint over the variables that occur, then every factor's marginal
+    order = sorted(used, key=str)
+    ax = {v: i for i, v in enumerate(order)}
+    ops = []
+    for f, val in zip(factors, values):
+        ops += [np.asarray(val, dtype=np.float64), [ax[v] for v in f]]
+    joint = np.einsum(*ops, list(range(len(order))), optimize=True)
+    for f, g in zip(factors, got):
+        want = np.einsum(joint, list(range(len(order))), [ax[v] for v in f])
+        assert g.shape == want.shape, (seed, f)
+        np.testing.assert_allclose(g, want, rtol=2e-6 if f32 else 1e-11, atol=1e-30, err_msg="seed %d factor %r" % (seed, f))
+    if (seed - first) % 50 == 49:
+        print("seed %d ok (%.0f s)" % (seed, time.time() - t0), flush=True)
+print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint (%.0f s)" % (n, time.time() - t0))
