@@ -7,7 +7,7 @@ import numpy as np
 import junctiontree_amd as jt
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-t0 = time.time()
+t0, n_sets = time.time(), 0
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
     nv = int(rng.integers(2, 11))
@@ -34,6 +34,20 @@ for seed in range(first, first + n):
         want = np.einsum(joint, list(range(len(order))), [ax[v] for v in f])
         assert g.shape == want.shape, (seed, f)
         np.testing.assert_allclose(g, want, rtol=2e-6 if f32 else 1e-11, atol=1e-30, err_msg="seed %d factor %r" % (seed, f))
+    if seed % 4 == 0:          # hard-evidence sets over the same values: every factor of set e against joint x indicators
+        sets = [{}] + [{order[i]: int(rng.integers(0, sizes[order[i]])) for i in rng.choice(len(order), size=int(rng.integers(1, min(3, len(order)) + 1)), replace=False)}
+                       for _ in range(int(rng.integers(1, 10)))]
+        res = tree.propagate_evidence_sets(values, sets)
+        for obs, got_e in zip(sets, res):
+            je = joint.copy()
+            for v, st in obs.items():
+                ind = np.zeros(sizes[v]); ind[st] = 1.0
+                shape = [1] * je.ndim; shape[ax[v]] = sizes[v]
+                je = je * ind.reshape(shape)
+            for f, g in zip(factors, got_e):
+                want = np.einsum(je, list(range(len(order))), [ax[v] for v in f])
+                np.testing.assert_allclose(g, want, rtol=2e-6 if f32 else 1e-11, atol=1e-30, err_msg="seed %d evidence %r factor %r" % (seed, obs, f))
+        n_sets += len(sets)
     if (seed - first) % 50 == 49:
         print("seed %d ok (%.0f s)" % (seed, time.time() - t0), flush=True)
-print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint (%.0f s)" % (n, time.time() - t0))
+print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint; %d evidence sets through propagate_evidence_sets too (%.0f s)" % (n, n_sets, time.time() - t0))
