@@ -202,6 +202,7 @@ struct JtEvalFactor {
     // host: the kernel indexes these with its loop counter only)
     uint32_t vds[JT_MAX_VARS];   // device element stride of the digit
     int32_t vmod[JT_MAX_VARS];   // digits stored along it
+    uint8_t vrow[JT_MAX_VARS];   // 1: a mixed-radix digit INSIDE a row (JtPackDesc::row_elems): taken of (x mod row_elems)
 };
 struct JtEvalDesc {
     JtPackDesc clique;

@@ -1896,7 +1896,10 @@ __global__ __launch_bounds__(256) void jt_eval_product(const JtEvalDesc *__restr
                 int64_t idx = 0;
                 for (int j = 0; j < ff.nv; ++j) {
                     const uint32_t ds = ff.vds[j];
-                    const int digit = ds > 0 ? (int)(((uint32_t)x / ds) % (uint32_t)ff.vmod[j]) : 0;
+                    // (a digit of the thread part stored at true cardinalities is a digit of the place INSIDE the row, as in
+                    //  jt_digit: taken of x itself it was wrong from the second row on - found by the round-3 API check below)
+                    const uint32_t xr = ff.vrow[j] ? (uint32_t)x % (uint32_t)c.row_elems : (uint32_t)x;
+                    const int digit = ds > 0 ? (int)((xr / ds) % (uint32_t)ff.vmod[j]) : 0;
                     idx += (int64_t)digit * ff.stride[j];
                 }
                 v *= ff.is_f64 ? reinterpret_cast<const double *>(stage)[ff.off + idx]
