@@ -341,14 +341,16 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         if (ch.us < 1e30) F = himask & ~ch.L, searched = true;
     }
     // 1. LDS must fit: fix the high bit that shrinks the staged sub-boxes most.
+    bool down_to_four = strict_budget > 0;
     while (!searched && (lds_of(F) > budget || max_free(F) > JT_MAX_FREE)) {
         int best = -1;
         long best_lds = 0;
         int best_part = 0;
         for (int b = TB; b < nbits; ++b) {      // (fitting LDS never goes below 8 iterations: staging a big
-                                                //  sub-box for 4 would cost more than it saves; multi-set plans: 4)
+                                                //  sub-box for 4 would cost more than it saves; multi-set plans: 4 - and 4
+                                                //  for anybody whose sub-boxes do not fit at all otherwise, see below)
             if (F >> b & 1) continue;
-            if (nbits - popc(F | unit(b)) < TB + (strict_budget > 0 ? 2 : 3)) continue;
+            if (nbits - popc(F | unit(b)) < TB + (down_to_four ? 2 : 3)) continue;
             long l = lds_of(F | unit(b));
             int pl = part_log2(F | unit(b));
             if (best < 0 || l < best_lds || (l == best_lds && pl < best_part)) {
@@ -358,6 +360,12 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         if (best < 0 || best_lds >= lds_of(F)) {
             if (strict_budget > 0) FAIL(JTP_EUNSUPPORTED, "message sub-boxes of one evidence set need %ld bytes of LDS (limit %d)", lds_of(F), strict_budget);
             if (lds_of(F) <= 150 * 1024 && max_free(F) <= JT_MAX_FREE) break;   // cannot shrink further
+            // (a marginal onto nearly all variables of a clique of few rows - a factor as wide as its clique, 3^8 entries:
+            //  four rows per workgroup before giving up)
+            if (!down_to_four) {
+                down_to_four = true;
+                continue;
+            }
             FAIL(JTP_EUNSUPPORTED, "message sub-boxes do not fit in LDS (%ld bytes)", lds_of(F));
         }
         F |= unit(best);
