@@ -10,13 +10,17 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t0, n_sets = time.time(), 0
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
-    nv = int(rng.integers(2, 11))
+    wide = os.environ.get("FUZZ_WIDE")        # wider factors (up to 6 variables of up to 5 states) over up to 12 variables
+    nv = int(rng.integers(2, 13 if wide else 11))
     names = ["v%d" % i for i in range(nv)] if seed % 2 else list(range(nv))
-    sizes = {v: int(rng.integers(1, 5)) for v in names}
+    while True:
+        sizes = {v: int(rng.integers(1, 6 if wide else 5)) for v in names}
+        if np.prod([float(k) for k in sizes.values()]) <= 4e6:
+            break
     nf = int(rng.integers(1, 2 * nv))
     factors = []
     for _ in range(nf):
-        k = int(rng.integers(1, min(4, nv) + 1))
+        k = int(rng.integers(1, min(6 if wide else 4, nv) + 1))
         factors.append([names[i] for i in rng.choice(nv, size=k, replace=False)])
     used = {v for f in factors for v in f}
     f32 = seed % 3 == 0
