@@ -7,7 +7,7 @@ import numpy as np
 import junctiontree_amd as jt
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-t0, n_sets = time.time(), 0
+t0, n_sets, n_again, failed = time.time(), 0, 0, []
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
     wide = os.environ.get("FUZZ_WIDE")        # wider factors (up to 6 variables of up to 5 states) over up to 12 variables
@@ -26,7 +26,12 @@ for seed in range(first, first + n):
     f32 = seed % 3 == 0
     values = [rng.uniform(0.2, 1.0, [sizes[v] for v in f]).astype(np.float32 if f32 else np.float64) for f in factors]
     tree = jt.create_junction_tree(factors, sizes)
-    got = tree.propagate(values)
+    try:
+        got = tree.propagate(values)
+    except Exception as exc:
+        print("seed %d: %s: %s" % (seed, type(exc).__name__, exc), flush=True)
+        failed.append(seed)
+        continue
     # brute force: the joint over the variables that occur, then every factor's marginal
     order = sorted(used, key=str)
     ax = {v: i for i, v in enumerate(order)}
@@ -38,6 +43,19 @@ for seed in range(first, first + n):
         want = np.einsum(joint, list(range(len(order))), [ax[v] for v in f])
         assert g.shape == want.shape, (seed, f)
         np.testing.assert_allclose(g, want, rtol=2e-6 if f32 else 1e-11, atol=1e-30, err_msg="seed %d factor %r" % (seed, f))
+    if seed % 3 == 1:          # some factors get new values: only their cliques are staged again (content digests), same answer as from scratch
+        for rnd in range(2):
+            for i in rng.choice(len(factors), size=int(rng.integers(1, len(factors) + 1)), replace=False):
+                values[i] = rng.uniform(0.2, 1.0, values[i].shape).astype(values[i].dtype)
+            got = tree.propagate(values)
+            ops = []
+            for f, val in zip(factors, values):
+                ops += [np.asarray(val, dtype=np.float64), [ax[v] for v in f]]
+            joint = np.einsum(*ops, list(range(len(order))), optimize=True)
+            for f, g in zip(factors, got):
+                want = np.einsum(joint, list(range(len(order))), [ax[v] for v in f])
+                np.testing.assert_allclose(g, want, rtol=2e-6 if f32 else 1e-11, atol=1e-30, err_msg="seed %d round %d factor %r" % (seed, rnd, f))
+        n_again += 2
     if seed % 4 == 0:          # hard-evidence sets over the same values: every factor of set e against joint x indicators
         sets = [{}] + [{order[i]: int(rng.integers(0, sizes[order[i]])) for i in rng.choice(len(order), size=int(rng.integers(1, min(3, len(order)) + 1)), replace=False)}
                        for _ in range(int(rng.integers(1, 10)))]
@@ -54,4 +72,4 @@ for seed in range(first, first + n):
         n_sets += len(sets)
     if (seed - first) % 50 == 49:
         print("seed %d ok (%.0f s)" % (seed, time.time() - t0), flush=True)
-print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint; %d evidence sets through propagate_evidence_sets too (%.0f s)" % (n, n_sets, time.time() - t0))
+print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint; %d evidence sets through propagate_evidence_sets and %d propagates with some factors changed too (%.0f s); raised: %r" % (n, n_sets, n_again, time.time() - t0, failed))
