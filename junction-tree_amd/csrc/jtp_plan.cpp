@@ -362,7 +362,8 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
             // cannot shrink further: accepted while the whole workgroup - ring, sub-boxes, staging scratch and the kernels'
             // static words - stays inside the CU's 160 KiB (150 KiB of sub-boxes alone, the bound of rounds 1-2, did not:
             // hipFuncSetAttribute refused 170 KiB on a random factor graph, tools/gpu_fuzz_api.py)
-            if (lds_of(F) + JT_RING_BYTES + JT_STAGE_SCRATCH * (long)ins.size() + 1024 <= 160 * 1024 && max_free(F) <= JT_MAX_FREE) break;
+            // (4 KiB for the static words: the reduce path's 2 KiB of partial sums and the dataflow control words are in the same kernels)
+            if (lds_of(F) + JT_RING_BYTES + JT_STAGE_SCRATCH * (long)ins.size() + 4096 <= 160 * 1024 && max_free(F) <= JT_MAX_FREE) break;
             // (a marginal onto nearly all variables of a clique of few rows - a factor as wide as its clique, 3^8 entries:
             //  four rows per workgroup before giving up)
             if (!down_to_four) {

@@ -35,7 +35,14 @@ def run_plan(spec, pots, dtype, **opts):
 t0 = time.time()
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
-    spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 40)), max_width=width)
+    if os.environ.get("FUZZ_BIG"):          # fewer, much larger cliques of cardinalities 2..7 (tables of up to 2^22 entries, many rows)
+        while True:
+            spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 12)), max_width=width, cards=(2, 3, 3, 4, 5, 6, 7))
+            big = max(p.size for p in pots)
+            if 1 << 14 <= big <= 1 << 22 and sum(p.size for p in pots) <= 1 << 24:
+                break
+    else:
+        spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 40)), max_width=width)
     want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
     opts = opts_all[int(os.environ["FUZZ_OPTS"]) if "FUZZ_OPTS" in os.environ else seed % len(opts_all)]
     for dtype in ("f64", "f32"):
@@ -44,8 +51,8 @@ for seed in range(first, first + n):
         engine._cache.clear()
         try:
             out, zz = run_plan(spec, cast, dtype, **opts)
-        except ValueError as exc:                    # a structure the planner refuses (JTP_EUNSUPPORTED): reported, not a mismatch
-            print("seed %d %s %r: refused: %s" % (seed, dtype, opts, exc), flush=True)
+        except Exception as exc:                     # a structure the planner refuses (JTP_EUNSUPPORTED) or any other error: reported, not a mismatch
+            print("seed %d %s %r: %s: %s" % (seed, dtype, opts, type(exc).__name__, exc), flush=True)
             refused.append(seed)
             zz = z
             continue
