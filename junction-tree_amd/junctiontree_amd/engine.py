@@ -436,7 +436,15 @@ def plan_for(tree, node_vars, sizes, dtype, **kwargs):
         return plan
     _cache_stats["misses"] += 1
     try:
-        plan = Plan(tree, node_vars, sizes, dtype=dtype, **kwargs)
+        try:
+            plan = Plan(tree, node_vars, sizes, dtype=dtype, **kwargs)
+        except ValueError as exc:
+            # float32 storage means 1024-element rows: a clique of few rows with four or more neighbours whose separators are
+            # nearly the whole clique then needs more LDS than a CU has (limits).  The same tree in float64
+            # storage (512-element rows) plans; it stays on the device, the tables are converted on upload.
+            if dtype not in ("f32", np.float32) or "do not fit in LDS" not in str(exc):
+                raise
+            plan = Plan(tree, node_vars, sizes, dtype="f64", **kwargs)
     except MemoryError:
         # the device is full: let go of every cached plan (those nobody else holds are destroyed now) and try once more
         import gc

@@ -360,6 +360,26 @@ def test_factor_products_formed_on_the_device_in_mixed_radix_tables(nv, card, dt
         close(g, np.einsum(joint, list(range(nv)), [ax[v] for v in f]), rtol=RTOL32 if dt == np.float32 else RTOL64, what=str(f))
 
 
+def test_float32_trees_the_planner_refuses_run_in_float64_storage():
+    """A clique of few rows with four or more neighbours whose separators are nearly the whole clique cannot be planned with
+    1024-element (float32) rows - every message needs the whole thread part in LDS (found by tools/gpu_fuzz.py, FUZZ_BIG, seed
+    92488).  An explicit float32 plan says so; `compute_beliefs` / `propagate` (engine.plan_for) store such a tree as float64 on
+    the device instead."""
+    from test_planner_emulated import random_junction_tree
+    rng = np.random.default_rng(92488)
+    while True:
+        spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 12)), max_width=9, cards=(2, 3, 3, 4, 5, 6, 7))
+        if 1 << 14 <= max(p.size for p in pots) <= 1 << 22 and sum(p.size for p in pots) <= 1 << 24:
+            break
+    cast = [p.astype(np.float32) for p in pots]
+    with pytest.raises(ValueError, match="do not fit in LDS"):
+        engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
+    want = oracle.beliefs_exact(spec["tree"], cast, spec["node_vars"])
+    got = comp.compute_beliefs(spec["tree"], cast, spec["node_vars"])
+    for g, w in zip(got, want):
+        close(g, w, rtol=RTOL64)
+
+
 def test_more_than_32_variables_on_a_node_when_the_rest_have_one_state():
     """tests/test_planner_emulated.py, same case, through the device: beliefs, marginals over labels that include one-state
     variables, evidence on a one-state variable."""
