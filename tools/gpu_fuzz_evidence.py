@@ -15,7 +15,13 @@ width = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 t0, refused, done = time.time(), [], {}
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
-    spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 25)), max_width=width)
+    if os.environ.get("FUZZ_BIG"):          # fewer, larger cliques of cardinalities 2..7 (tables of up to 2^20 entries, many rows)
+        while True:
+            spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 10)), max_width=width, cards=(2, 3, 3, 4, 5, 6, 7))
+            if 1 << 13 <= max(p.size for p in pots) <= 1 << 20 and sum(p.size for p in pots) <= 1 << 22:
+                break
+    else:
+        spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 25)), max_width=width)
     nc, nb = spec["n_cliques"], int(rng.integers(3, 12))
     share = [False, True, "multiset"][seed % 3]
     dtype = ("f64", "f32")[(seed // 3) % 2]
