@@ -28,6 +28,20 @@ def run_plan(spec, pots, dtype, **opts):
     modes[key] = modes.get(key, 0) + 1
     out = [plan.belief(n) for n in range(len(spec["node_vars"]))]
     z = plan.z()
+    # marginals onto random subsets of random cliques' variables (their own planner tasks and kernels): against the belief summed on the host
+    mrng = np.random.default_rng(len(pots) + int(pots[0].size))
+    reqs = []
+    for _ in range(4):
+        c = int(mrng.integers(0, spec["n_cliques"]))
+        vs = list(spec["node_vars"][c])
+        k = int(mrng.integers(0, len(vs) + 1))
+        reqs.append((c, [vs[i] for i in mrng.permutation(len(vs))[:k]]))
+    got = plan.marginals(reqs) + [plan.marginal(*reqs[0])]
+    for (c, labs), g in zip(reqs + [reqs[0]], got):
+        vs = list(spec["node_vars"][c])
+        want = np.einsum(out[c], list(range(len(vs))), [vs.index(v) for v in labs])
+        tol = 1e-5 if dtype == "f32" else 1e-10
+        assert g.shape == want.shape and np.all(np.abs(g - want) <= tol * max(np.max(np.abs(want)), 1e-300)), ("marginal", c, labs, float(np.max(np.abs(g - want))), float(np.max(np.abs(want))))
     plan.close()
     return out, z
 
