@@ -42,6 +42,18 @@ def run_plan(spec, pots, dtype, **opts):
         want = np.einsum(out[c], list(range(len(vs))), [vs.index(v) for v in labs])
         tol = 1e-5 if dtype == "f32" else 1e-10
         assert g.shape == want.shape and np.all(np.abs(g - want) <= tol * max(np.max(np.abs(want)), 1e-300)), ("marginal", c, labs, float(np.max(np.abs(g - want))), float(np.max(np.abs(want))))
+    # the same plan again with new tables on some cliques (both halves of the message arena, markers re-armed by the producers)
+    cur = [np.array(p0, copy=True) for p0 in pots]
+    for rnd in range(3):
+        for c in mrng.permutation(spec["n_cliques"])[:int(mrng.integers(1, spec["n_cliques"] + 1))]:
+            cur[c] = (cur[c] * mrng.uniform(0.5, 1.5, cur[c].shape)).astype(cur[c].dtype)
+            plan.set_potential(int(c), cur[c])
+        plan.propagate(sync=bool(rnd % 2))
+        want2, z2 = oracle.beliefs_exact(spec["tree"], cur, spec["node_vars"], return_z=True)
+        for node in mrng.permutation(len(spec["node_vars"]))[:3]:
+            close(plan.belief(int(node)), want2[int(node)], rtol=RTOL32 if dtype == "f32" else RTOL64, what="round %d node %d" % (rnd, node))
+        assert abs(plan.z() - z2) <= 1e-5 * abs(z2)
+    assert plan.stats()["flow_fallbacks"] == 0
     plan.close()
     return out, z
 
