@@ -91,6 +91,11 @@ def _worker(rank, world, port_file, recipe, kwargs, opts, env, queue):
     (3, "random_tree", {"n_cliques": 26, "width": 11, "sep": 5, "card": 2, "seed": 8, "renumber": 2}, {}, {}),
     (4, "wide_binary_tree", {"n_cliques": 31, "width": 13, "sep": 6, "card": 2, "seed": 5, "replicate_top": True}, {}, {}),
     (3, "random_tree", {"n_cliques": 28, "width": 11, "sep": 5, "card": 2, "seed": 6, "renumber": 4, "replicate_top": True}, {"level_launches": True}, {}),
+    # (round 3) cardinalities that are not powers of two: tables with mixed-radix rows (kernels *_mix) and rows stored at true
+    # cardinalities on every rank, messages across the cuts as padded bit fields
+    (2, "wide_binary_tree", {"n_cliques": 15, "width": 8, "sep": 4, "card": 3, "seed": 7}, {}, {}),
+    (3, "random_tree", {"n_cliques": 20, "width": 6, "sep": 3, "card": 5, "seed": 9, "renumber": 3, "replicate_top": True}, {}, {}),
+    (4, "random_tree", {"n_cliques": 24, "width": 7, "sep": 3, "card": 3, "seed": 11}, {"level_launches": True}, {}),
 ])
 def test_ranks_sharing_one_gpu_through_mock_transport(world, recipe, kwargs, opts, env, tmp_path):
     import multiprocessing as mp
