@@ -325,6 +325,8 @@ static void bitfield_desc(JtPackDesc &d) {
     }
     d.phys_elems = (int64_t)1 << d.nbits;
     d.low_bits = d.nbits;
+    d.row_elems = 0;
+    d.split_var = -1;
 }
 
 template <typename T, typename S>
@@ -788,7 +790,7 @@ int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32
                 e.cvar[j] = (uint8_t)pos;
                 e.vds[j] = d.clique.dstride[pos];
                 e.vmod[j] = d.clique.dmod[pos];
-                e.vrow[j] = d.clique.row_elems > 0 && d.clique.pos[pos] < d.clique.low_bits ? 1 : 0;
+                e.vrow[j] = d.clique.row_elems > 0 && d.clique.pos[pos] < d.clique.low_bits ? (pos == d.clique.split_var ? 2 : 1) : 0;
                 const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
                 e.stride[j] = (len == 1) ? 0 : (int32_t)stride;
                 stride *= len;

@@ -178,6 +178,12 @@ struct JtPackDesc {
     int32_t low_bits;          // index bits of the thread part (one row = 2^low_bits elements)
     int32_t row_elems;         // > 0: thread part stored at true cardinalities - the digits of variables below low_bits are taken
                                // of (x mod row_elems), x the element index (a row is row_elems long, not 2^low_bits)
+    // ... with ONE variable across bit low_bits (PNode::tsplit; -1: none): its digit is low + (high << split_lb), low a
+    // radix-2^split_lb digit of the row (dstride / dmod of that variable), high a digit of split_mod2 values along split_ds2
+    int32_t split_var;         // index into this record's variables
+    int32_t split_lb;
+    uint32_t split_ds2;
+    int32_t split_mod2;
 };
 
 // one request of a batched marginal read-out (jt_marg_unpack): partial copies -> host order
@@ -202,7 +208,8 @@ struct JtEvalFactor {
     // host: the kernel indexes these with its loop counter only)
     uint32_t vds[JT_MAX_VARS];   // device element stride of the digit
     int32_t vmod[JT_MAX_VARS];   // digits stored along it
-    uint8_t vrow[JT_MAX_VARS];   // 1: a mixed-radix digit INSIDE a row (JtPackDesc::row_elems): taken of (x mod row_elems)
+    uint8_t vrow[JT_MAX_VARS];   // 1: a mixed-radix digit INSIDE a row (JtPackDesc::row_elems): taken of (x mod row_elems);
+                                 // 2: the clique's variable across the thread part's top bit (JtPackDesc::split_*)
 };
 struct JtEvalDesc {
     JtPackDesc clique;

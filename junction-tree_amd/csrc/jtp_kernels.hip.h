@@ -1827,6 +1827,8 @@ __device__ __forceinline__ uint64_t jt_splitmix64(uint64_t x) {
 // digit of variable i at device (physical) element index x: a shift where the variable is a bit field
 __device__ __forceinline__ int jt_digit(const JtPackDesc &d, int i, uint32_t x) {
     const uint32_t ds = d.dstride[i];
+    if (d.row_elems > 0 && i == d.split_var)               // the variable across the thread part's top bit: low digit of the row, high digit above
+        return (int)(((x % (uint32_t)d.row_elems) / ds) % (uint32_t)d.dmod[i]) + ((int)((x / d.split_ds2) % (uint32_t)d.split_mod2) << d.split_lb);
     if (d.row_elems > 0 && d.pos[i] < d.low_bits)          // a mixed-radix digit of the row (thread part at true cardinalities)
         return ds > 0 ? (int)(((x % (uint32_t)d.row_elems) / ds) % (uint32_t)d.dmod[i]) : 0;
     if (ds == (1u << d.pos[i]) && d.dmod[i] == (1 << d.nb[i])) return (int)((x >> d.pos[i]) & ((1u << d.nb[i]) - 1u));
@@ -1841,6 +1843,9 @@ __device__ __forceinline__ bool jt_dev_to_host(const JtPackDesc &d, uint32_t x, 
         const int digit = jt_digit(d, i, x);
         valid = valid && (digit < d.card[i]);
         h += (int64_t)digit * d.hstride[i];
+        if (d.row_elems > 0 && i == d.split_var)
+            back += (int64_t)(digit & ((1 << d.split_lb) - 1)) * d.dstride[i] + (int64_t)(digit >> d.split_lb) * d.split_ds2;
+        else
         back += (int64_t)digit * d.dstride[i];
     }
     if (back != (int64_t)x) valid = false;              // index bits no variable owns must be clear
@@ -1899,7 +1904,8 @@ __global__ __launch_bounds__(256) void jt_eval_product(const JtEvalDesc *__restr
                     // (a digit of the thread part stored at true cardinalities is a digit of the place INSIDE the row, as in
                     //  jt_digit: taken of x itself it was wrong from the second row on - found by the round-3 API check below)
                     const uint32_t xr = ff.vrow[j] ? (uint32_t)x % (uint32_t)c.row_elems : (uint32_t)x;
-                    const int digit = ds > 0 ? (int)((xr / ds) % (uint32_t)ff.vmod[j]) : 0;
+                    int digit = ds > 0 ? (int)((xr / ds) % (uint32_t)ff.vmod[j]) : 0;
+                    if (ff.vrow[j] == 2) digit += (int)(((uint32_t)x / c.split_ds2) % (uint32_t)c.split_mod2) << c.split_lb;
                     idx += (int64_t)digit * ff.stride[j];
                 }
                 v *= ff.is_f64 ? reinterpret_cast<const double *>(stage)[ff.off + idx]
@@ -1919,6 +1925,9 @@ __device__ __forceinline__ uint32_t jt_host_to_dev(const JtPackDesc &d, int64_t 
         const int c = d.card[i];
         const int digit = (int)(h % c);
         h /= c;
+        if (d.row_elems > 0 && i == d.split_var)
+            x += (uint32_t)(digit & ((1 << d.split_lb) - 1)) * d.dstride[i] + (uint32_t)(digit >> d.split_lb) * d.split_ds2;
+        else
         x += (uint32_t)digit * d.dstride[i];
     }
     return x;

@@ -618,6 +618,7 @@ PlanKnobs jtp_read_knobs() {
     k.merge_phases = geti("JTP_MERGE_PHASES", -1);
     k.no_tmix = geti("JTP_NO_TMIX", 0);
     k.tmix_fill = getd("JTP_TMIX_FILL", 0.6);
+    k.no_tsplit = geti("JTP_NO_TSPLIT", 0);
     k.settle_level_elems = getd("JTP_SETTLE_LEVEL_ELEMS", 8388608.0);
     k.top_min_loop = geti("JTP_TOP_MIN_LOOP", 3);
     k.longest_first = geti("JTP_LONGEST_FIRST", 1);
@@ -1254,10 +1255,20 @@ int PlanBuilder::layouts() {
         }
         int bit = 0;
         p.tpad_mask = 0;
+        p.tsplit = -1, p.tsplit_lb = 0;
         for (int v : p.vars) {
             if (p.tmix && bit < hp.TB && bit + hp.vbits[v] > hp.TB) {
-                for (int b = bit; b < hp.TB; ++b) p.tpad_mask |= 1u << b;
-                bit = hp.TB;
+                // A variable across bit TB: its low bits become a radix-2^lb digit of the row and its high bits a digit of the rows
+                // above with ceil(card / 2^lb) values - the rows of a bit-field thread part, a third to a half fewer than with the
+                // variable moved up whole - where the entries this stores for values >= card (zeros) cost at most a quarter;
+                // else the variable moves above bit TB and the bits below it are padding.
+                const int lb = hp.TB - bit, card = hp.card[v], hi = (card + (1 << lb) - 1) >> lb;
+                if (!hp.knobs.no_tsplit && (double)(hi << lb) <= 1.25 * card) {
+                    p.tsplit = (int)p.pos.size(), p.tsplit_lb = lb;
+                } else {
+                    for (int b = bit; b < hp.TB; ++b) p.tpad_mask |= 1u << b;
+                    bit = hp.TB;
+                }
             }
             p.pos.push_back(bit);
             p.nb.push_back(hp.vbits[v]);
@@ -1286,8 +1297,10 @@ int PlanBuilder::layouts() {
             // row = the thread-part variables as mixed-radix digits, first variable fastest
             std::vector<int64_t> tstride(p.vars.size(), 0);
             int64_t prod = 1;
-            for (size_t i = 0; i < p.vars.size(); ++i)
+            for (size_t i = 0; i < p.vars.size(); ++i) {
                 if (p.pos[i] + p.nb[i] <= hp.TB) tstride[i] = prod, prod *= hp.card[p.vars[i]];
+                else if ((int)i == p.tsplit) tstride[i] = prod, prod <<= p.tsplit_lb;          // the low bits of the variable across TB
+            }
             p.trow = (int)((prod + hp.VEC - 1) / hp.VEC * hp.VEC);
             p.tmap.assign((size_t)1 << hp.TB, -1);
             for (uint32_t x = 0; x < (1u << hp.TB); ++x) {
@@ -1295,6 +1308,10 @@ int PlanBuilder::layouts() {
                 int64_t off = 0;
                 bool ok = true;
                 for (size_t i = 0; i < p.vars.size() && ok; ++i) {
+                    if ((int)i == p.tsplit) {
+                        off += (int64_t)((x >> p.pos[i]) & ((1u << p.tsplit_lb) - 1u)) * tstride[i];       // (every low value has a place)
+                        continue;
+                    }
                     if (p.pos[i] + p.nb[i] > hp.TB) continue;
                     const int digit = (int)((x >> p.pos[i]) & ((1u << p.nb[i]) - 1u));
                     ok = digit < hp.card[p.vars[i]];
@@ -1309,15 +1326,23 @@ int PlanBuilder::layouts() {
             const int pos = p.pos[i], nb = p.nb[i], card = hp.card[p.vars[i]];
             if (pos + nb <= hp.TB) continue;
             const bool whole = pos >= hp.TB && hp.compact && (card & (card - 1)) != 0;
+            // (the variable across TB of a mixed-radix clique: its high bits are a digit of ceil(card / 2^lb) values)
+            const int hi = (int)i == p.tsplit ? (card + (1 << p.tsplit_lb) - 1) >> p.tsplit_lb : 0;
+            const bool split_group = hi > 0 && (hi & (hi - 1)) != 0;
             for (int k = std::max(0, hp.TB - pos); k < nb; ++k) {
-                p.bitw[pos + k] = whole ? mult << k : mult;
-                if (!whole) mult <<= 1;
+                p.bitw[pos + k] = whole ? mult << k : (split_group ? mult << (k - (hp.TB - pos)) : mult);
+                if (!whole && !split_group) mult <<= 1;
             }
             if (whole) {
                 p.group_mask.push_back(((1u << nb) - 1u) << pos);
                 p.group_pos.push_back(pos);
                 p.group_card.push_back(card);
                 mult *= card;
+            } else if (split_group) {
+                p.group_mask.push_back(((1u << (nb - (hp.TB - pos))) - 1u) << hp.TB);
+                p.group_pos.push_back(hp.TB);
+                p.group_card.push_back(hi);
+                mult *= hi;
             }
         }
         for (int b = std::max(bit, hp.TB); b < p.nbits; ++b) {
@@ -1392,6 +1417,22 @@ int PlanBuilder::arenas() {
         }
         pd.row_elems = p.tmix ? p.trow : 0;
         pd.host_elems = stride;
+        pd.split_var = -1;
+        if (p.tmix && p.tsplit >= 0) {
+            const int j = p.tsplit, card = hp.card[p.vars[j]];
+            for (int i = 0; i < pd.nvars; ++i)
+                if (host_vars[i] == p.vars[j]) pd.split_var = i;
+            if (pd.split_var >= 0) {
+                int64_t ts = 1;
+                for (int jj = 0; jj < j; ++jj)
+                    if (p.pos[jj] + p.nb[jj] <= hp.TB) ts *= hp.card[p.vars[jj]];
+                pd.split_lb = p.tsplit_lb;
+                pd.dstride[pd.split_var] = (uint32_t)ts;
+                pd.dmod[pd.split_var] = 1 << p.tsplit_lb;
+                pd.split_ds2 = (uint32_t)p.bitw[hp.TB];
+                pd.split_mod2 = (card + (1 << p.tsplit_lb) - 1) >> p.tsplit_lb;
+            }
+        }
         return pd;
     };
     for (int c = 0; c < NP; ++c) {
@@ -2073,7 +2114,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         o << "{\"real\":" << p.real << ",\"parent\":" << p.parent << ",\"psep\":" << p.psep << ",\"depth\":" << p.depth
           << ",\"owner\":" << p.owner << ",\"nbits\":" << p.nbits << ",\"arena_off\":" << p.arena_off
           << ",\"phys_elems\":" << p.phys_elems << ",\"pad_mask\":" << p.pad_mask << ",\"tmix\":" << (p.tmix ? 1 : 0) << ",\"trow\":" << p.trow
-          << ",\"tpad_mask\":" << p.tpad_mask << ",\"tmap_off\":" << p.tmap_off << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"down_tasks\":";
+          << ",\"tpad_mask\":" << p.tpad_mask << ",\"tsplit\":" << p.tsplit << ",\"tsplit_lb\":" << p.tsplit_lb << ",\"tmap_off\":" << p.tmap_off << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"down_tasks\":";
         json_vec(o, p.down_tasks);
         if (hp.tmix) {
             o << ",\"tmap\":";
@@ -2117,6 +2158,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         json_list(o, pd.dstride, pd.dstride + pd.nvars);
         o << ",\"dmod\":";
         json_list(o, pd.dmod, pd.dmod + pd.nvars);
+        o << ",\"split_var\":" << pd.split_var << ",\"split_lb\":" << pd.split_lb << ",\"split_ds2\":" << pd.split_ds2 << ",\"split_mod2\":" << pd.split_mod2;
         o << ",\"phys_elems\":" << pd.phys_elems << "}";
     }
     o << "],\"pseps\":[";

@@ -32,7 +32,10 @@ struct PNode {                       // a clique of the (binarised) tree
     // trow elements (the product of their cardinalities, rounded up to the vector width) instead of 2^TB
     bool tmix = false;
     int trow = 0;
-    uint32_t tpad_mask = 0;          // index bits below TB that no variable owns (a variable never straddles TB in a tmix clique)
+    uint32_t tpad_mask = 0;          // index bits below TB that no variable owns
+    int tsplit = -1, tsplit_lb = 0;  // (tmix) the variable that straddles bit TB (index into vars; -1: none) and how many of its bits lie
+                                     // below TB: those are a radix-2^lb digit of the row, the bits above a digit of ceil(card / 2^lb) values of the
+                                     // rows above - taken when that wastes at most a quarter (entries with low + (high << lb) >= card are stored as zeros)
     std::vector<int32_t> tmap;
     int64_t tmap_off = -1;           // offset (ints) of tmap in HostPlan::itab
     int collect_task = -1, distribute_task = -1;
@@ -119,6 +122,7 @@ struct PlanKnobs {
     double top_share = 0.12;                                        // JTP_TOP_SHARE: ... a clique holding at least this share of its level's elements
     double settle_level_elems = 8388608.0;                          // JTP_SETTLE_LEVEL_ELEMS: tasks on levels of at most this many table elements settle in place
     int no_tmix = 0;                                                // JTP_NO_TMIX: thread parts stay padded bit fields (round-2 layout)
+    int no_tsplit = 0;                                              // JTP_NO_TSPLIT: no variable across bit TB in a clique with mixed-radix rows (the first form of round 3)
     double tmix_fill = 0.6;                                         // JTP_TMIX_FILL: mixed-radix rows for cliques whose bit-field thread part would be emptier than this
     int merge_phases = -1;                                          // JTP_MERGE_PHASES: 1 / 0 = both phases in one dataflow launch / never; -1: where messages are small
 };

@@ -952,6 +952,9 @@ def test_wide_cliques_of_odd_cardinalities(card, width, sep):
             if not opts.get("no_compact") and (card, width) in ((3, 8), (3, 9), (5, 6)):
                 assert d["arena_elems"] <= 1.25 * host_elems, (d["arena_elems"], host_elems)
                 assert all(p["trow"] < 2 ** d["TB"] for p in d["pnodes"] if p["tmix"])
+                # (cardinality 5 in float32: one bit of a fourth variable lies below bit TB - the rows of a bit-field thread
+                #  part at 6/5 of the true size; cardinality 3 would cost 4/3 that way and moves the variable up whole)
+                assert {p["tsplit"] >= 0 for p in d["pnodes"] if p["tmix"] and p["nbits"] > d["TB"] + 2} <= {card == 5 and dtype == "f32"}
             for c in range(spec["n_cliques"]):
                 plan.set_potential(c, cast[c])
             plan.propagate()
