@@ -7,7 +7,7 @@ import numpy as np
 import junctiontree_amd as jt
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-t0, n_sets, n_again, failed = time.time(), 0, 0, []
+t0, n_sets, n_again, n_cond, failed = time.time(), 0, 0, 0, []
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
     wide = os.environ.get("FUZZ_WIDE")        # wider factors (up to 6 variables of up to 5 states) over up to 12 variables
@@ -25,7 +25,7 @@ for seed in range(first, first + n):
     used = {v for f in factors for v in f}
     f32 = seed % 3 == 0
     values = [rng.uniform(0.2, 1.0, [sizes[v] for v in f]).astype(np.float32 if f32 else np.float64) for f in factors]
-    tree = jt.create_junction_tree(factors, sizes)
+    tree = jt.create_junction_tree(factors, dict(sizes))          # (the tree keeps the dict it is given: conditioning below changes it)
     try:
         got = tree.propagate(values)
     except Exception as exc:
@@ -56,6 +56,32 @@ for seed in range(first, first + n):
                 want = np.einsum(joint, list(range(len(order))), [ax[v] for v in f])
                 np.testing.assert_allclose(g, want, rtol=2e-6 if f32 else 1e-11, atol=1e-30, err_msg="seed %d round %d factor %r" % (seed, rnd, f))
         n_again += 2
+    if seed % 5 == 2:          # the reference's way of conditioning (tests/test_junctiontree.py:393-411): set a variable's size to 1 and slice the factors
+        cond = [np.array(v, copy=True) for v in values]
+        csizes = dict(sizes)
+        for v in [order[i] for i in rng.permutation(len(order))[:int(rng.integers(1, min(3, len(order)) + 1))]]:
+            st = int(rng.integers(0, sizes[v]))
+            tree.clique_tree.factor_graph.sizes[v] = 1
+            csizes[v] = 1
+            for i, f in enumerate(factors):
+                if v in f:
+                    cond[i] = np.take(cond[i], [st], axis=f.index(v))
+            try:
+                got_c = tree.propagate(cond)
+            except Exception as exc:
+                print("seed %d conditioning on %r (state %d): %s; sizes %r; factors %r; shapes %r" % (seed, v, st, exc, dict(tree.clique_tree.factor_graph.sizes), factors, [c.shape for c in cond]), flush=True)
+                raise
+            ops = []
+            for f, val in zip(factors, cond):
+                ops += [np.asarray(val, dtype=np.float64), [ax[u] for u in f]]
+            jc = np.einsum(*ops, list(range(len(order))), optimize=True)
+            for f, g in zip(factors, got_c):
+                want = np.einsum(jc, list(range(len(order))), [ax[u] for u in f])
+                assert g.shape == want.shape, (seed, f, g.shape, want.shape)
+                np.testing.assert_allclose(g, want, rtol=2e-6 if f32 else 1e-11, atol=1e-30, err_msg="seed %d conditioned on %r factor %r" % (seed, v, f))
+        for v in order:
+            tree.clique_tree.factor_graph.sizes[v] = sizes[v]
+        n_cond += 1
     if seed % 4 == 0:          # hard-evidence sets over the same values: every factor of set e against joint x indicators
         sets = [{}] + [{order[i]: int(rng.integers(0, sizes[order[i]])) for i in rng.choice(len(order), size=int(rng.integers(1, min(3, len(order)) + 1)), replace=False)}
                        for _ in range(int(rng.integers(1, 10)))]
@@ -72,4 +98,4 @@ for seed in range(first, first + n):
         n_sets += len(sets)
     if (seed - first) % 50 == 49:
         print("seed %d ok (%.0f s)" % (seed, time.time() - t0), flush=True)
-print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint; %d evidence sets through propagate_evidence_sets and %d propagates with some factors changed too (%.0f s); raised: %r" % (n, n_sets, n_again, time.time() - t0, failed))
+print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint; %d evidence sets through propagate_evidence_sets and %d propagates with some factors changed too; %d graphs conditioned the reference's way (sizes set to 1, factors sliced) (%.0f s); raised: %r" % (n, n_sets, n_again, n_cond, time.time() - t0, failed))
