@@ -50,4 +50,31 @@ plan.sync()
 print("batch6  %5d x 6 propagates  %.1f s  mismatching checks %d  fallbacks %d" % (reps, time.perf_counter() - t0, bad, plan.stats()["flow_fallbacks"]))
 assert bad == 0 and plan.stats()["flow_fallbacks"] == 0
 plan.close()
+# two PLANS whose propagates are in flight together, each on its own stream: the second one to start takes its workgroups in
+# ticket order (jtp_propagate: another plan's dataflow propagate is in flight), the kernels share the GPU
+specs = [synthetic.wide_binary_tree(n_cliques=63, width=17, sep=8, card=2, seed=11), synthetic.chain_tree(n_cliques=40, card=16, width=3),
+         synthetic.wide_binary_tree(n_cliques=15, width=10, sep=5, card=3, seed=12)]
+plans = [engine.Plan(sp["tree"], sp["node_vars"], sp["sizes"], dtype=dt) for sp, dt in zip(specs, ("f32", "f64", "f32"))]
+for pl, sp in zip(plans, specs):
+    pl.fill_synthetic(21, sp["scales"])
+    pl.propagate()
+z0 = [pl.z() for pl in plans]
+m0 = [pl.marginal(0, list(sp["node_vars"][0])[:2]) for pl, sp in zip(plans, specs)]
+t0 = time.perf_counter()
+bad = 0
+for i in range(reps):
+    for pl in plans:
+        pl.propagate(sync=False)
+    if i % 100 == 99:
+        for k, (pl, sp) in enumerate(zip(plans, specs)):
+            pl.sync()
+            bad += pl.z() != z0[k] or not np.array_equal(pl.marginal(0, list(sp["node_vars"][0])[:2]), m0[k])
+for pl in plans:
+    pl.sync()
+st = [pl.stats() for pl in plans]
+print("3plans  %5d x 3 propagates  %.1f s  mismatching checks %d  fallbacks %d  propagates in ticket order %r" % (
+    reps, time.perf_counter() - t0, bad, sum(x["flow_fallbacks"] for x in st), [x["tickets_used"] for x in st]))
+assert bad == 0 and all(x["flow_fallbacks"] == 0 for x in st)
+for pl in plans:
+    pl.close()
 print("soak ok")
