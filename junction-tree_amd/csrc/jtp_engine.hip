@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -220,12 +221,19 @@ struct MargBatch {
 static std::atomic<int> g_inflight[64];
 
 // dynamic LDS above 64 KiB must be allowed per kernel function: remember what each function was raised to
-static std::map<const void *, int> g_lds_raised;
+// (per device: the attribute belongs to the function on the CURRENT device; under a lock: plans may be created from
+//  several host threads)
+static std::map<std::pair<int, const void *>, int> g_lds_raised;
+static std::mutex g_lds_mutex;
 static hipError_t raise_lds(const void *func, int bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
-    int &have = g_lds_raised[func];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_lds_mutex);
+    int &have = g_lds_raised[std::make_pair(dev, func)];
     if (have >= bytes) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) have = bytes;
     return e;
 }

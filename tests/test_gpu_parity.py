@@ -360,6 +360,39 @@ def test_factor_products_formed_on_the_device_in_mixed_radix_tables(nv, card, dt
         close(g, np.einsum(joint, list(range(nv)), [ax[v] for v in f]), rtol=RTOL32 if dt == np.float32 else RTOL64, what=str(f))
 
 
+def test_plans_created_and_run_from_two_host_threads():
+    """a plan is not thread safe, distinct plans are independent - created, run and destroyed from two host
+    threads at once (ctypes releases the GIL): each thread's results equal the oracle's every time."""
+    import threading
+    specs = [synthetic.wide_binary_tree(n_cliques=15, width=14, sep=7, card=2, seed=21), synthetic.random_tree(n_cliques=12, width=6, sep=3, card=3, seed=22)]
+    errors = []
+
+    def worker(spec, dtype):
+        try:
+            pots = synthetic.potentials_for(spec, seed=5, dtype=np.float32 if dtype == "f32" else np.float64)
+            want, z = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+            for rep in range(6):
+                plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, lds_budget=(96 * 1024 if rep % 2 else 0))
+                for c in range(spec["n_cliques"]):
+                    plan.set_potential(c, pots[c])
+                for _ in range(20):
+                    plan.propagate(sync=False)
+                plan.sync()
+                for node in (0, spec["n_cliques"] - 1, len(spec["node_vars"]) - 1):
+                    close(plan.belief(node), want[node], rtol=RTOL32 if dtype == "f32" else RTOL64)
+                assert abs(plan.z() - z) <= (1e-6 if dtype == "f32" else 1e-11) * abs(z) and plan.stats()["flow_fallbacks"] == 0
+                plan.close()
+        except Exception as exc:            # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(sp, dt)) for sp, dt in zip(specs, ("f32", "f64"))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_float32_trees_the_planner_refuses_run_in_float64_storage():
     """A clique of few rows with four or more neighbours whose separators are nearly the whole clique cannot be planned with
     1024-element (float32) rows - every message needs the whole thread part in LDS (found by tools/gpu_fuzz.py, FUZZ_BIG, seed
