@@ -113,6 +113,9 @@ def _worker(rank, world, port, recipe, kwargs, queue):
     ("random_tree", {"n_cliques": 24, "width": 10, "sep": 4, "card": 2, "seed": 7, "renumber": 5}),
     ("wide_binary_tree", {"n_cliques": 31, "width": 11, "sep": 5, "card": 2, "seed": 2, "replicate_top": True}),
     ("random_tree", {"n_cliques": 30, "width": 10, "sep": 4, "card": 2, "seed": 9, "renumber": 3, "replicate_top": True}),
+    # (round 3) cardinalities that are not powers of two: mixed-radix rows on both ranks, padded bit-field messages across the cut
+    ("wide_binary_tree", {"n_cliques": 15, "width": 7, "sep": 3, "card": 3, "seed": 5}),
+    ("random_tree", {"n_cliques": 18, "width": 5, "sep": 2, "card": 5, "seed": 6, "renumber": 2, "replicate_top": True}),
 ])
 def test_two_rank_exchange_schedule(recipe, kwargs, monkeypatch):
     import multiprocessing as mp
