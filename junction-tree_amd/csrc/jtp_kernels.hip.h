@@ -45,8 +45,18 @@ template <> struct JtVec<double> { using type = double2; };
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS at `lds_dst` + lane * 16
 // (wave-uniform byte address).  Not tracked by the compiler's s_waitcnt insertion: callers count
 // vmcnt themselves (cdna_hip_programming.md section 5.7).
-__device__ __forceinline__ void jt_dma16(const void *gsrc, uint32_t lds_dst) {
+// `reused` (uniform): the row will be read again soon by workgroups of the same XCD - multi-set plans of several groups of
+// evidence sets, whose grid puts the groups' workgroups for one record next to each other on one XCD: default cache policy
+// there (16 sets 1.78 -> 1.73 ms, 64 sets 6.09 -> 6.04 ms, 8 sets = one group unchanged; A/B on one box); everywhere else a row is read once per pass: non-temporal.
+__device__ __forceinline__ void jt_dma16(const void *gsrc, uint32_t lds_dst, bool reused = false) {
     unsigned keep;
+    if (reused) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
+        return;
+    }
 #ifndef JT_TABLE_NO_NT       // non-temporal policy on the table stream (rows are read once per phase, by one CU): config 4 0.610 ->
                             // 0.5975 ms, A/B on one box over three runs each; -DJT_TABLE_NO_NT builds the default-policy loads
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
@@ -1219,7 +1229,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     const bool chunk_ok = !(bk.flags & JT_BLOCK_INVALID);
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
+        jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024), fl.n_groups > 1);
     int trow[JT_NCOL];
     {
         const int r = lane < total ? lane : total - 1;
@@ -1480,7 +1490,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
             const int inext = (i + U < total) ? i + U : total - 1;
             const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
             jt_dma16((xnext == JT_NO_ROW || !chunk_ok) ? zero_row : psi + (xF + xnext),
-                     __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
+                     __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024), fl.n_groups > 1);
         }
         uint32_t rowok = 0xffffffffu;                       // bit s: the row agrees with set s
         if constexpr (ROWEV) {
