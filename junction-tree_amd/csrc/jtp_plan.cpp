@@ -461,6 +461,16 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         for (int b = 0; b < nbits; ++b)
             if ((mv.mask >> b & 1) && !(F >> b & 1)) fr.push_back({mv.dst[b], b});
         std::sort(fr.begin(), fr.end());
+        // Sub-box slot order: the index bits that are LANE bits of the clique's thread part come first, the others follow in
+        // message order.  The lanes of a half-wave then read one contiguous run of the sub-box (ds_read_b64: 32 lanes x 8 bytes
+        // over 64 banks - conflict-free inside 256 bytes), whatever place those variables have in the message; in message order
+        // a lane bit of weight >= 32 entries put two lanes on one bank (SQ_LDS_BANK_CONFLICT: a third of all LDS cycles of
+        // jt_multi_flow).  64 evidence sets 6.04 -> 5.32 ms, 8 sets 1.02 -> 0.89, config 3 11.78 -> 11.56, configs 2 and 4
+        // unchanged (A/B on one box).  Staging and flush follow free_pos[] as before: their global accesses are less contiguous
+        // now, which the loop's gain outweighs (slot orders that kept the lowest message bits low measured slower: 5.58 ms).
+        // Mixed-radix thread parts have no lane bits: message order.  JTP_LANE_LOW=0: message order, 1: incoming sub-boxes only.
+        if (hp.knobs.lane_low > (is_out ? 1 : 0) && !hp.tmix)
+            std::stable_partition(fr.begin(), fr.end(), [&](const std::pair<int, int> &x) { return x.second >= hp.EB && x.second < hp.EB + 5; });
         jm.nfree = (int)fr.size();
         for (size_t r = 0; r < fr.size(); ++r) {
             jm.free_pos[r] = (uint8_t)fr[r].first;
@@ -621,6 +631,7 @@ PlanKnobs jtp_read_knobs() {
     k.no_tsplit = geti("JTP_NO_TSPLIT", 0);
     k.settle_level_elems = getd("JTP_SETTLE_LEVEL_ELEMS", 8388608.0);
     k.top_min_loop = geti("JTP_TOP_MIN_LOOP", 3);
+    k.lane_low = geti("JTP_LANE_LOW", 2);
     k.longest_first = geti("JTP_LONGEST_FIRST", 1);
     k.top_share = getd("JTP_TOP_SHARE", 0.12);
     return k;

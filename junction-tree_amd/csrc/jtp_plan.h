@@ -118,6 +118,7 @@ struct PlanKnobs {
     int no_search = 0;                                              // JTP_NO_SEARCH: layout policy 2 where the cost-model search (policy 4) would run
     int roctx = 0;                                                  // JTP_ROCTX: roctx ranges around propagates and read-outs
     int longest_first = 1;                                          // JTP_LONGEST_FIRST: within a level, tasks with the longest workgroups go first in the block list
+    int lane_low = 2;                                               // JTP_LANE_LOW: a sub-box's index bits that are lane bits come first (0 = message order, 1 = incoming sub-boxes only, 2 = all)
     int top_min_loop = 3;                                           // JTP_TOP_MIN_LOOP: log2 of the fewest rows per workgroup on levels of a few cliques (searched splits)
     double top_share = 0.12;                                        // JTP_TOP_SHARE: ... a clique holding at least this share of its level's elements
     double settle_level_elems = 8388608.0;                          // JTP_SETTLE_LEVEL_ELEMS: tasks on levels of at most this many table elements settle in place
