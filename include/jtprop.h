@@ -214,6 +214,9 @@ int jtp_get_z(jtp_plan *plan, int32_t batch, double *z);
  * per propagate. */
 int jtp_set_profiling(jtp_plan *plan, int32_t keep);
 int jtp_set_profiling_granularity(jtp_plan *plan, int32_t per_launch);
+/* Time only every `stride`-th propagate (the first one after this call included): an event costs 2-3 us of idle GPU, which a
+ * benchmark of 0.6 ms propagates sees (1.3 % with every propagate timed).  Default 1. */
+int jtp_set_profiling_stride(jtp_plan *plan, int32_t stride);
 int jtp_get_stats(jtp_plan *plan, jtp_stats *stats);
 /* Mean device time (ms) of each of the plan's launches, in schedule order; `n` = capacity of
  * `ms`.  Returns the number of launches (or a negative error).  Needs jtp_set_profiling. */

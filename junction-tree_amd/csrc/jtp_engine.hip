@@ -278,6 +278,8 @@ struct jtp_plan {
     int prof_steps = 0;             // 0: off; else ring of this many event sets
     std::vector<hipEvent_t> ev;     // prof_steps x (2 per launch)
     int prof_cursor = 0;            // propagates recorded since profiling was switched on
+    int prof_stride = 1;            // every how many propagates one is timed (jtp_set_profiling_stride)
+    unsigned prof_calls = 0;        // propagates since profiling was switched on, timed or not
     bool prof_per_launch = false;   // event pair per launch instead of three per propagate
     bool flow = true;               // dataflow launches (one per phase) instead of one per level
     bool chain = false;             // the plan is made of latency-bound levels (JtTask::settle): distribute runs the build without spills
@@ -1023,7 +1025,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
             return set_err(JTP_EINVAL, "a multi-set plan propagates all its evidence sets together: pass [0, %d)", hp.n_batch);
         if (pl->prof_per_launch) return set_err(JTP_EINVAL, "per-launch profiling is not available for multi-set plans");
         hipStream_t s = pl->streams[0];
-        const bool prof = pl->prof_steps > 0;
+        const bool prof = pl->prof_steps > 0 && (pl->prof_calls++ % (unsigned)pl->prof_stride) == 0;
         if (prof) while (pl->ev.size() < 3 * (size_t)pl->prof_steps) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
@@ -1097,7 +1099,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         HIP_TRY(hipGetLastError());
         return JTP_OK;
     }
-    const bool prof = pl->prof_steps > 0;
+    const bool prof = pl->prof_steps > 0 && (pl->prof_calls++ % (unsigned)pl->prof_stride) == 0;
     const size_t ev_per_step = pl->prof_per_launch ? 2 * hp.launches.size() : 3;
     if (prof) {
         size_t need = ev_per_step * (size_t)pl->prof_steps;
@@ -1508,6 +1510,16 @@ int jtp_get_z(jtp_plan *pl, int32_t batch, double *z) {
 int jtp_set_profiling(jtp_plan *pl, int32_t on) {
     if (!pl) return set_err(JTP_EINVAL, "null plan");
     pl->prof_steps = on > 0 ? std::min(on, 256) : 0;     // `on` = number of propagates to keep
+    pl->prof_cursor = 0;
+    pl->prof_calls = 0;
+    return JTP_OK;
+}
+
+int jtp_set_profiling_stride(jtp_plan *pl, int32_t stride) {
+    if (!pl) return set_err(JTP_EINVAL, "null plan");
+    if (stride < 1) return set_err(JTP_EINVAL, "stride must be at least 1");
+    pl->prof_stride = stride;
+    pl->prof_calls = 0;
     pl->prof_cursor = 0;
     return JTP_OK;
 }

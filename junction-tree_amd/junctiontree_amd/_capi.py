@@ -105,6 +105,7 @@ SYMBOLS = {
     "jtp_get_z": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "jtp_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "jtp_set_profiling_granularity": (C.c_int, [C.c_void_p, C.c_int32]),
+    "jtp_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int32]),
     "jtp_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "jtp_get_launch_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "jtp_debug_read_msg": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),

@@ -303,10 +303,12 @@ class Plan:
         return val.value
 
     # ------------------------------------------------------------------ instrumentation
-    def set_profiling(self, keep=1, per_launch=False):
+    def set_profiling(self, keep=1, per_launch=False, stride=1):
         """Time the next `keep` propagates with hipEvents on the plan's stream: three events per
-        propagate (phase times), or with `per_launch` a pair around every launch."""
+        propagate (phase times), or with `per_launch` a pair around every launch; `stride` > 1 times only
+        every stride-th propagate (the events cost 2-3 us of GPU time each)."""
         _capi.check(self._lib.jtp_set_profiling_granularity(self._handle, 1 if per_launch else 0))
+        _capi.check(self._lib.jtp_set_profiling_stride(self._handle, int(stride)))
         _capi.check(self._lib.jtp_set_profiling(self._handle, int(keep)))
 
     def debug_set(self, knob, value):

@@ -632,6 +632,30 @@ def test_repeated_propagates_with_new_potentials_and_mixed_launch_modes():
         plan.close()
 
 
+def test_event_timing_of_every_nth_propagate():
+    """jtp_set_profiling_stride: with a stride only every n-th propagate carries events; the reported device time is the
+    mean over those and stays a plausible time of ONE propagate, the results are unaffected."""
+    spec = synthetic.wide_binary_tree(n_cliques=15, width=14, sep=7, card=2, seed=2)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
+    plan.fill_synthetic(1, spec["scales"])
+    plan.propagate()
+    z0 = plan.z()
+    times = {}
+    for stride in (1, 4):
+        plan.set_profiling(12, stride=stride)
+        for _ in range(12):
+            plan.propagate(sync=False)
+        plan.sync()
+        st = plan.stats()
+        times[stride] = sum(k["ms"] for k in st["kernels"].values())
+        assert times[stride] > 0 and plan.z() == z0
+    assert 0.4 < times[4] / times[1] < 2.5, times
+    with pytest.raises(ValueError):
+        plan.set_profiling(4, stride=0)
+    plan.set_profiling(0)
+    plan.close()
+
+
 def test_pinned_host_arrays_in_and_out():
     """Potentials handed over from page-locked arrays (jtp_host_alloc) and beliefs read into them."""
     spec = synthetic.wide_binary_tree(n_cliques=7, width=12, sep=6, card=2, seed=3)
