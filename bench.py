@@ -17,8 +17,12 @@ Prints ONE JSON line on rank 0.  `value` = algorithmic clique-potential GB/s of 
 job (SURVEY.md 8d definition of algorithmic bytes), `messages_per_sec` beside it.
 `roofline` is for the dominant kernel (config 4: jt_propagate_flow, both phases of the propagate
 in one dataflow launch; configs 2 and 3: jt_distribute_flow[_chain], the whole distribute phase in
-one launch), timed with hipEvents on the plan's own stream during the timed steps: one event
-before and one after the launch of every fourth propagate (`steps_timed_with_events`; an event costs 2-3 us of GPU time).  `cpu_baseline` times the numpy restatement of the
+one launch), timed with hipEvents on the plan's own stream: ONE event before the first timed step and
+ONE after the last (no event between the steps: an event costs 2-3 us of idle GPU), divided by the
+steps; where a step is two launches, the kernel's share of it comes from a few propagates timed after
+the timed region.  With the default workload on one GPU the line also carries `configs`: one measured
+sub-result per other BASELINE config (c2, c3, c3_api_end_to_end, c5_multiset64), each with
+`ms_per_step`, algorithmic bytes, roofline fraction and a parity flag.  `cpu_baseline` times the numpy restatement of the
 reference's einsum sequence (oracle/jt_oracle.py: beliefs_refshaped) on one host core over a
 bounded sample of the same workload; it is a checker/baseline, never the measured path.
 
@@ -151,6 +155,212 @@ def cpu_baseline_all_cores(width, sep, card, n_sample=16):
     }
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The other BASELINE configs, measured in the same process after the headline workload (`configs` in the JSON line).
+
+def _timed(plan, steps, warmup=3):
+    """(wall ms per step, device ms per step) of `steps` propagates: one hipEvent pair around the region."""
+    for _ in range(warmup):
+        plan.propagate(sync=False)
+    plan.sync()
+    t0 = time.perf_counter()
+    plan.region_begin()
+    for _ in range(steps):
+        plan.propagate(sync=False)
+    dev_ms = plan.region_end()
+    plan.sync()
+    return (time.perf_counter() - t0) / steps * 1e3, dev_ms / steps
+
+
+def _sub_result(workload, alg_bytes, messages, wall_ms, dev_ms, steps, parity, **more):
+    out = {"workload": workload, "ms_per_step": wall_ms, "device_ms_per_step": dev_ms, "steps": steps,
+           "algorithmic_bytes_per_step": alg_bytes, "value": alg_bytes / (wall_ms * 1e-3) / 1e9, "unit": "GB/s",
+           "messages_per_sec": messages / (wall_ms * 1e-3), "frac": alg_bytes / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "bound": "hbm", "parity": parity}
+    out.update(more)
+    return out
+
+
+def sub_c2(device, steps=20):
+    """configs[1]: chain of 1000 cliques of 64^3 doubles.  Parity: calibration - the separator marginal of two adjacent
+    cliques agrees wherever it is taken, every belief sums to Z (five places along the chain)."""
+    import numpy as np
+    from junctiontree_amd import engine, synthetic
+    spec = synthetic.chain_tree(n_cliques=1000, card=64, width=3)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", device=device)
+    try:
+        plan.fill_synthetic(1, spec["scales"])
+        wall, dev = _timed(plan, steps)
+        alg = synthetic.algorithmic_bytes(spec, 8)
+        z = plan.z()
+        worst = 0.0
+        for c in (0, 250, 499, 750, 998):
+            a, b = plan.marginals([(c, [c + 1, c + 2]), (c + 1, [c + 1, c + 2])])
+            worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(a))), abs(float(a.sum()) - z) / abs(z))
+        return _sub_result("BASELINE.json configs[1]: chain of 1000 cliques, width 3, cardinality 64, float64", alg["total"], alg["messages"],
+                           wall, dev, steps, {"kind": "calibration", "rel_err": worst, "tolerance": 1e-9, "ok": bool(worst <= 1e-9)},
+                           dtype="f64", Z=z, launches_per_step=plan.stats()["n_launches"])
+    finally:
+        plan.close()
+
+
+def sub_c3(device, steps=10, api_calls=5, lattice_w=167):
+    """configs[2] as restated in SURVEY.md 8d (6 x 167 lattice MRF, cardinality 8, float32), twice: the hot path
+    (collect + distribute with the clique potentials resident) and the whole API call tree.propagate(values) with every
+    factor table new (H2D of the factor tables, evaluate, collect + distribute, factor marginals, D2H)."""
+    import numpy as np
+    import junctiontree_amd as jt
+    from junctiontree_amd import engine, synthetic
+    factors, sizes, values = synthetic.lattice_mrf(6, lattice_w, 8)
+    t0 = time.perf_counter()
+    tree = jt.create_junction_tree(factors, sizes)
+    t_build = time.perf_counter() - t0
+    ct = tree.clique_tree
+    engine.clear_plan_cache()
+    t0 = time.perf_counter()
+    out = tree.propagate(values)
+    t_first = time.perf_counter() - t0
+    plan = tree.plan("f32")
+    try:
+        n = len(ct.maxcliques)
+        tables = sum(int(np.prod([sizes[v] for v in c])) for c in ct.maxcliques) * 4
+        seps = sum(int(np.prod([sizes[v] for v in sp])) if len(sp) else 1 for sp in tree.separators) * 8
+        root_table = int(np.prod([sizes[v] for v in ct.maxcliques[plan.root]])) * 4
+        alg = 3 * tables - root_table + 5 * seps
+        wall, dev = _timed(plan, steps)
+        z = plan.z()
+        api = []
+        for r in range(api_calls):
+            vals = [v * np.float32(1.0 + 1e-3 * (r + 1)) for v in values]
+            plan.sync()
+            t0 = time.perf_counter()
+            out = tree.propagate(vals)
+            api.append((time.perf_counter() - t0) * 1e3)
+        staged = plan.staged_cliques
+        out = tree.propagate(values)
+        z = plan.z()
+        sums = np.array([m.sum() for m in out])
+        seen, worst = {}, 0.0
+        for f, o in zip(factors, out):
+            for ax, v in enumerate(f):
+                m = o.sum(axis=1 - ax)
+                if v in seen:
+                    worst = max(worst, float(np.max(np.abs(m - seen[v]) / seen[v])))
+                else:
+                    seen[v] = m
+        sum_err = float(np.max(np.abs(sums - z)) / z)
+        parity = {"kind": "calibration", "factor_marginals_sum_to_Z_rel_err": sum_err, "calibration_rel_err": worst,
+                  "tolerance": 5e-6, "ok": bool(sum_err <= 5e-6 and worst < 5e-6)}
+        wl = ("BASELINE.json configs[2] as restated in SURVEY.md 8d: 6 x %d lattice MRF, %d pairwise factors, cardinality 8, float32; "
+              "junction tree by this repo's builder: %d cliques, max width %d" % (lattice_w, len(factors), n, max(len(c) for c in ct.maxcliques)))
+        hot = _sub_result(wl, alg, 2 * (n - 1), wall, dev, steps, parity, dtype="f32", Z=z, junction_tree_build_s=t_build,
+                          first_call_s=t_first, launches_per_step=plan.stats()["n_launches"])
+        api_ms = min(api)
+        # the API call moves, beyond the hot path's bytes: the tables of the cliques that hold factors written once more
+        # (evaluate; the others stay all ones) and their beliefs read once more (marginalize: the requests on one clique
+        # share the pass); the factor tables in and the factor marginals out are under 2 MB
+        held = sorted(set(ct.factor_to_maxclique))
+        factor_tables = sum(int(np.prod([sizes[v] for v in ct.maxcliques[c]])) for c in held) * 4
+        api_alg = alg + 2 * factor_tables
+        e2e = {"workload": wl + "; tree.propagate(values) with all %d factor tables new: H2D, evaluate (%d cliques formed), collect + "
+                                 "distribute, %d factor marginals, D2H" % (len(factors), staged, len(factors)),
+               "ms_per_step": api_ms, "ms_per_step_median": sorted(api)[len(api) // 2], "steps": api_calls,
+               "algorithmic_bytes_per_step": api_alg, "value": api_alg / (api_ms * 1e-3) / 1e9, "unit": "GB/s",
+               "frac": api_alg / (api_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bound": "hbm", "hot_path_share": wall / api_ms,
+               "d2h_bytes": int(sum(o.nbytes for o in out)), "parity": parity}
+        return hot, e2e
+    finally:
+        engine.clear_plan_cache()
+
+
+def sub_c5(device, spec, n_sets=64, steps=10, oracle_sets=1):
+    """configs[4] on one device = one rank's share of the 512 evidence sets: 64 sets over the shared width-20 tables
+    (JTP_MULTISET).  Parity: Z of `oracle_sets` sets against the numpy oracle on indicator-multiplied potentials, and a
+    marginal of every set sums to that set's Z."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import jt_oracle as oracle
+    from junctiontree_amd import engine, synthetic
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", device=device, n_batch=n_sets, multiset=True)
+    try:
+        plan.fill_synthetic(1, spec["scales"])
+        labels = sorted(spec["sizes"])
+        evidence = []
+        for b in range(n_sets):
+            rng = np.random.default_rng(1000 + b)
+            ev = {labels[i]: int(rng.integers(0, spec["sizes"][labels[i]])) for i in rng.choice(len(labels), size=16, replace=False)}
+            evidence.append(ev)
+            plan.set_evidence(ev, batch=b)
+        wall, dev = _timed(plan, steps)
+        n = spec["n_cliques"]
+        sz = [1] * len(spec["node_vars"])
+        for i, labs in enumerate(spec["node_vars"]):
+            for v in labs:
+                sz[i] *= spec["sizes"][v]
+        tables, seps = sum(sz[:n]) * 4, sum(sz[n:]) * 8
+        alg = 2 * tables + 5 * seps * n_sets             # tables once per batch (collect + distribute), messages per set
+        zs = [plan.z(b) for b in range(n_sets)]
+        worst = 0.0
+        for b in range(n_sets):
+            m = plan.marginals([(n - 1 - (b % 8), [spec["node_vars"][n - 1 - (b % 8)][0]])], batch=b)[0]
+            worst = max(worst, abs(float(m.sum()) - zs[b]) / abs(zs[b]))
+        zerr = 0.0
+        t0 = time.perf_counter()
+        for b in range(oracle_sets):
+            pots = synthetic.potentials_for(spec, seed=1, dtype=np.float32)
+            done = set()
+            for c in range(n):                            # the indicator goes into the first clique that holds the variable
+                for ax, v in enumerate(spec["node_vars"][c]):
+                    if v in evidence[b] and v not in done:
+                        done.add(v)
+                        ind = np.zeros(spec["sizes"][v])
+                        ind[evidence[b][v]] = 1.0
+                        shape = [1] * pots[c].ndim
+                        shape[ax] = -1
+                        pots[c] = pots[c] * ind.reshape(shape)
+            _, zo = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"], return_z=True)
+            zerr = max(zerr, abs(zs[b] - zo) / abs(zo))
+        t_oracle = time.perf_counter() - t0
+        st = plan.stats()
+        parity = {"kind": "Z of %d evidence set(s) vs oracle (indicator-multiplied potentials, %.1f s of numpy); every set: a marginal sums to its Z" % (oracle_sets, t_oracle),
+                  "Z_rel_err": zerr, "marginal_sums_rel_err": worst, "tolerance": 1e-6, "ok": bool(zerr <= 1e-6 and worst <= 1e-6)}
+        return _sub_result("BASELINE.json configs[4], one rank's share: %d evidence sets (16 observed variables each) over the shared tables of the "
+                           "width-20 tree, JTP_MULTISET" % n_sets, alg, 2 * (n - 1) * n_sets, wall, dev, steps, parity, dtype="f32",
+                           evidence_sets_per_step=n_sets, ms_per_evidence_set=wall / n_sets,
+                           engine_table_bytes_per_step=st["algorithmic_bytes"], launches_per_step=st["n_launches"])
+    finally:
+        plan.close()
+
+
+def sub_configs(device, spec_c4):
+    """Run the sub-configs one after the other; a failure is recorded in its place, never raised (the headline line stands)."""
+    out = {}
+    t_all = time.perf_counter()
+
+    def guard(name, fn):
+        t0 = time.perf_counter()
+        try:
+            res = fn()
+        except Exception as exc:          # noqa: BLE001 - recorded, not raised
+            res = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if isinstance(res, tuple):
+            for k, r in zip(name, res):
+                out[k] = r
+        elif isinstance(name, tuple):
+            for k in name:
+                out[k] = res
+        else:
+            out[name] = res
+        return time.perf_counter() - t0
+
+    secs = {"c2": guard("c2", lambda: sub_c2(device)),
+            "c3": guard(("c3", "c3_api_end_to_end"), lambda: sub_c3(device)),
+            "c5_multiset64": guard("c5_multiset64", lambda: sub_c5(device, spec_c4))}
+    out["wall_s"] = dict(secs, total=time.perf_counter() - t_all)
+    return out
+
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N rank processes from HERE - this process never loads
     libjtprop.so and never touches a GPU - wait for them, pass rank 0's JSON line on, and fail if any rank fails or
@@ -244,6 +454,9 @@ def main():
     ap.add_argument("--idle-plans", type=int, default=0,
                     help="create this many other (small, idle) device plans first: A/B for the launch-order rule - an idle "
                          "plan must not cost the benchmark plan its blockIdx-order launches")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the sub-results for the other BASELINE configs (c2, c3, c3 API call, c5 multi-set) that the default "
+                         "one-GPU run adds to its line")
     ap.add_argument("--spawn-timeout", type=int, default=900, help="seconds the self-started rank processes may take")
     args = ap.parse_args()
 
@@ -257,6 +470,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.config == "c3" and world != 1:
         raise SystemExit("--config c3 runs on one GPU")
+    if args.config == "c3" and (args.batch != 1 or args.share or args.multiset or args.split_variants or args.dtype != "f32"):
+        raise SystemExit("--config c3 is one float32 evidence set: --batch / --share / --multiset / --split-variants / --dtype do not apply")
     if (args.share or args.multiset) and world != 1:
         raise SystemExit("evidence sets are independent: replicas only (every rank its own sets), no sharded run")
 
@@ -272,7 +487,14 @@ def main():
     ndev = _capi.device_count()
     if ndev <= 0:
         raise SystemExit("no HIP device visible: bench.py measures the GPU path only")
-    device = local_rank % ndev                      # one process per GPU (ranks > GPUs only in smoke runs)
+    if world > ndev and not os.environ.get("JTP_RCCL_LIB"):
+        # one process per GPU: RCCL refuses two ranks on one device ("invalid usage", duplicate GPU) - say what is wrong
+        # instead.  (JTP_RCCL_LIB = a stand-in transport, tests/mock_rccl: ranks may then share a GPU.)
+        if rank == 0:
+            print("bench.py: %d ranks need %d devices, found %d (one process per GPU over RCCL; HIP_VISIBLE_DEVICES / "
+                  "ROCR_VISIBLE_DEVICES limit what a process sees)" % (world, world, ndev), file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    device = local_rank % ndev                      # one process per GPU (ranks > GPUs only over the mock transport)
     if world > ndev:                                # ranks sharing a GPU: dataflow launches need ticket order
         os.environ["JTP_FLOW_TICKETS"] = "1"
     version = lib.jtp_version().decode()
@@ -372,20 +594,28 @@ def main():
         tables, seps = sum(sz[:spec["n_cliques"]]) * itemsize, sum(sz[spec["n_cliques"]:]) * 8
         per_set = 5 * seps + (0 if args.multiset else tables)
         alg = dict(alg, total=(2 * tables + per_set * args.batch) / args.batch, read=2 * tables / args.batch)
-    prof_stride = 1
-    if not args.no_profile:
-        # hipEvents on the plan's stream inside the timed region, around every FOURTH propagate (the first included): an event
-        # costs 2-3 us of idle GPU - with every propagate timed the 0.6 ms step of config 4 measured 1.3 % longer than without
-        prof_stride = 4 if args.steps >= 8 and not (args.per_launch or args.split_variants) else 1
-        plan.set_profiling(args.steps, per_launch=args.per_launch or args.split_variants, stride=prof_stride)
+    # The timed region holds NO per-propagate events: one event before its first launch and one after its last
+    # (jtp_region_begin / jtp_region_end) give the device time of the K steps, which cannot exceed the wall clock around them.
+    plan.set_profiling(0)
     barrier()
     plan.sync()                                      # hipStreamSynchronize on the plan's stream
     t0 = time.perf_counter()
+    plan.region_begin()
     for _ in range(args.steps):
         plan.propagate(sync=False)
+    region_ms = plan.region_end()
     plan.sync()
     barrier()
     elapsed = rdzv.allreduce_max(time.perf_counter() - t0)      # max over ranks
+    # How a step divides over its launches (plans of two launches: collect, distribute; per level with --per-launch): from a
+    # few propagates timed with events AFTER the timed region - the events cost 2-3 us of idle GPU each, which is why they
+    # are not in it.
+    if not args.no_profile:
+        n_prof = 8
+        plan.set_profiling(n_prof, per_launch=args.per_launch or args.split_variants, stride=1)
+        for _ in range(n_prof):
+            plan.propagate(sync=False)
+        plan.sync()
 
     stats = plan.stats()
     z = plan.z() if plan.owns(plan.root) else None
@@ -445,7 +675,12 @@ def main():
         if not args.no_profile and stats["kernels"]:
             name, k = max(stats["kernels"].items(), key=lambda kv: kv[1]["ms"])
             per_launch_bytes = k["bytes"] / k["launches"]          # (profiled: evidence set 0 only)
-            per_launch_ms = k["ms"] / k["launches"]
+            # the kernel's share of a step, from the evented propagates after the timed region; its time = that share of
+            # the region's device time per step (one launch per step: share 1)
+            all_ms = sum(kv["ms"] for kv in stats["kernels"].values())
+            share = k["ms"] / all_ms if all_ms > 0 else 1.0
+            step_dev_ms = region_ms / args.steps
+            per_launch_ms = step_dev_ms * share / k["launches"]
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             # HBM bytes per launch: NOT measured in this run - read from the committed rocprofv3 PMC passes of the same
             # command (tools/collect_profiles.sh), and only when that file was measured on THIS build of the library
@@ -466,14 +701,19 @@ def main():
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 "launches_per_step": k["launches"], "avg_launch_ms": per_launch_ms,
-                "steps_timed_with_events": (args.steps + prof_stride - 1) // prof_stride,
-                "avg_launch_ms_note": "span between the two events of a timed propagate: it contains the events' own cost (2-3 us each), which the untimed steps of the region do not pay - it can exceed ms_per_step by about 1 %",
+                "device_ms_per_step": step_dev_ms, "kernel_share_of_step": share,
+                "avg_launch_ms_note": "device time of the %d timed steps between ONE hipEvent pair on the plan's stream (no event between the steps) / steps%s"
+                                      % (args.steps, "" if len(stats["kernels"]) == 1 and k["launches"] == 1 else
+                                         " x this kernel's share of a step, the share from 8 propagates timed with events after the timed region"),
                 "algorithmic_bytes_per_launch": per_launch_bytes,
-                "rank0_kernels": {kn: {"ms_per_step": kv["ms"], "launches": kv["launches"],
-                                       "GBps": kv["bytes"] / max(kv["ms"], 1e-12) / 1e6}
+                "rank0_kernels": {kn: {"ms_per_step": step_dev_ms * (kv["ms"] / all_ms if all_ms > 0 else 1.0), "launches": kv["launches"],
+                                       "GBps": kv["bytes"] / max(step_dev_ms * (kv["ms"] / all_ms if all_ms > 0 else 1.0), 1e-12) / 1e6}
                                   for kn, kv in stats["kernels"].items()},
                 "collect_ms": stats["collect_ms"], "distribute_ms": stats["distribute_ms"],
             }
+            if world > 1:
+                out["roofline"]["note_multi_rank"] = ("rank 0's figures; the phase spans of a sharded plan contain its exchange steps "
+                                                      "(ncclSend/ncclRecv between the launches)")
             if any(kn.startswith("jt_propagate_flow") for kn in stats["kernels"]):
                 # both phases ran inside ONE launch (plans whose messages are small beside their tables): there is no
                 # boundary between the phases to put an event on
@@ -526,6 +766,12 @@ def main():
                              "calibration_rel_err": worst, "tolerance": 5e-6,
                              "ok": bool(np.max(np.abs(sums - z)) <= 5e-6 * z and worst < 5e-6)}
             out["config"]["junction_tree_build_s"] = lattice["t_build"]
+        run_subs = (default_c4 and world == 1 and args.batch == 1 and not args.no_configs and not args.level_launches
+                    and not args.split_variants and not args.per_launch and args.idle_plans == 0
+                    and args.block_log2 == 0 and args.lds_budget == 0 and args.layout_policy == 0)
+        if run_subs:
+            plan.close()                 # (its 2 GiB of arenas are not needed any more; config 3 wants 18)
+            out["configs"] = sub_configs(device, spec)
         print(json.dumps(out), flush=True)
 
     for p in idle:

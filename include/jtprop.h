@@ -159,6 +159,14 @@ typedef struct jtp_factor {
 int jtp_set_potential_product(jtp_plan *plan, int32_t batch, int32_t clique, int32_t n_factors,
                               const jtp_factor *factors);
 
+/* The same for a LIST of cliques - all of CliqueGraph.evaluate (junctiontree.py:203-226: one helper einsum per clique)
+ * as ONE host-to-device copy of every factor table and ONE kernel launch over all the listed cliques.  Clique cliques[i]
+ * receives the product of factors[factor_off[i] .. factor_off[i+1]); a clique may be listed with no factors (all ones).
+ * The tables are copied before the call returns.  A caller that knows which factor tables changed since the last call
+ * lists only their cliques (junctiontree_amd/junctiontree.py does). */
+int jtp_set_potential_products(jtp_plan *plan, int32_t batch, int32_t n_cliques, const int32_t *cliques,
+                               const int32_t *factor_off, const jtp_factor *factors);
+
 /* Fill every clique potential on the device with the counter-based synthetic values of
  * junctiontree_amd/synthetic.py: psi[i] = (0.5 + u(seed, node, i)) * scale[node], i the
  * C-order host index.  For benchmarks (no host transfer). */
@@ -217,6 +225,11 @@ int jtp_set_profiling_granularity(jtp_plan *plan, int32_t per_launch);
 /* Time only every `stride`-th propagate (the first one after this call included): an event costs 2-3 us of idle GPU, which a
  * benchmark of 0.6 ms propagates sees (1.3 % with every propagate timed).  Default 1. */
 int jtp_set_profiling_stride(jtp_plan *plan, int32_t stride);
+/* Device time of a whole REGION of work on the plan's (first) stream: jtp_region_begin records one event, jtp_region_end a
+ * second one, waits for it and returns the milliseconds between them.  A benchmark brackets its K timed propagates with the
+ * pair and divides by K: no event sits between the propagates, so the figure cannot exceed the wall-clock step. */
+int jtp_region_begin(jtp_plan *plan);
+int jtp_region_end(jtp_plan *plan, double *ms);
 int jtp_get_stats(jtp_plan *plan, jtp_stats *stats);
 /* Mean device time (ms) of each of the plan's launches, in schedule order; `n` = capacity of
  * `ms`.  Returns the number of launches (or a negative error).  Needs jtp_set_profiling. */

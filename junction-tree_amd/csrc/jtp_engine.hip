@@ -140,7 +140,7 @@ struct KernelTable {
             if (variant >= JT_K_DIST_P0C0 && variant <= JT_K_DIST_P1C3) return jt_distribute_level_mix<T>;
             if (variant == JT_K_COLLECT_LEVEL) return jt_collect_level_mix<T>;
             if (variant == JT_K_DISTRIBUTE_LEVEL) return jt_distribute_level_mix<T>;
-            if (variant == JT_K_SINGLE) return jt_single_mix<T>;
+            if (variant == JT_K_SINGLE || variant == JT_K_MARGINALS) return jt_single_mix<T>;
         }
         switch (variant) {
             case JT_K_COLLECT0: return jt_collect<T, 0>;
@@ -161,6 +161,7 @@ struct KernelTable {
             case JT_K_MULTI_COLLECT: return jt_multi_flow<T>;
             case JT_K_MULTI_DISTRIBUTE: return jt_multi_flow<T>;
             case JT_K_SINGLE: return jt_single<T>;
+            case JT_K_MARGINALS: return jt_marginals<T>;
         }
         return nullptr;
     }
@@ -176,7 +177,7 @@ static const char *k_names[JT_K_COUNT] = {
     "jt_distribute<T, 0, 0>", "jt_distribute<T, 0, 1>", "jt_distribute<T, 0, 2>", "jt_distribute<T, 0, 3>",
     "jt_distribute<T, 1, 0>", "jt_distribute<T, 1, 1>", "jt_distribute<T, 1, 2>", "jt_distribute<T, 1, 3>",
     "jt_collect_level<T>", "jt_distribute_level<T>", "jt_collect_flow<T>", "jt_distribute_flow<T>", "jt_reduce_level<T>",
-    "jt_multi_flow<T>", "jt_multi_flow<T>", "jt_single<T>", "jt_propagate_flow<T>",
+    "jt_multi_flow<T>", "jt_multi_flow<T>", "jt_single<T>", "jt_propagate_flow<T>", "jt_marginals<T>",
 };
 
 struct BatchBuffers {
@@ -275,6 +276,8 @@ struct jtp_plan {
     hipEvent_t up_ev[2] = {nullptr, nullptr};
     bool up_busy[2] = {false, false};
     unsigned up_cursor = 0;
+    hipEvent_t region_ev[2] = {nullptr, nullptr};      // jtp_region_begin / jtp_region_end
+    bool region_open = false;
     int prof_steps = 0;             // 0: off; else ring of this many event sets
     std::vector<hipEvent_t> ev;     // prof_steps x (2 per launch)
     int prof_cursor = 0;            // propagates recorded since profiling was switched on
@@ -288,8 +291,8 @@ struct jtp_plan {
     bool fake_comm = false;         // JTP_FAKE_COMM
     bool psi_dirty = false;         // shared potentials were written (on stream 0) since the last propagate
     std::vector<MargBatch *> marg_cache;
-    // factor tables on their way to jt_eval_product: slices of one buffer handed out in turn, so that
-    // evaluating clique after clique needs no synchronisation until the buffer wraps
+    // factor tables and records on their way to jt_eval_batch: slices of one buffer handed out in turn, so that
+    // evaluate calls following each other need no synchronisation until the buffer wraps
     char *eval_stage = nullptr;          // device
     char *eval_host = nullptr;           // pinned mirror: the caller's tables are copied here before the call returns
     size_t eval_bytes = 0, eval_cursor = 0;
@@ -440,6 +443,8 @@ void jtp_plan_destroy(jtp_plan *pl) {
         if (pl->eval_stage) (void)hipFree(pl->eval_stage);
         if (pl->eval_host) (void)hipHostFree(pl->eval_host);
         for (auto e : pl->ev) (void)hipEventDestroy(e);
+        for (auto e : pl->region_ev)
+            if (e) (void)hipEventDestroy(e);
         for (auto s : pl->streams) (void)hipStreamDestroy(s);
     }
     delete pl;
@@ -708,47 +713,129 @@ int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *hos
     return JTP_OK;
 }
 
-int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32_t n_factors, const jtp_factor *factors) {
+// CliqueGraph.evaluate (junctiontree.py:203-226) for a list of cliques: ONE host-to-device copy of every factor table and
+// of the kernel's records, ONE launch of jt_eval_batch over all the cliques (plus one per further JT_EVAL_MAX_F factors of
+// the clique with the most).  Round 3 ran a copy and a launch per clique, and a kernel that decoded every element.
+int jtp_set_potential_products(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cliques, const int32_t *factor_off,
+                               const jtp_factor *factors) {
     int rc = check_ready(pl, batch);
     if (rc) return rc;
     rc = check_writable(pl, batch);
     if (rc) return rc;
-    pl->psi_dirty = true;
+    if (n < 0 || (n > 0 && (!cliques || !factor_off))) return set_err(JTP_EINVAL, "null argument");
+    if (n == 0) return JTP_OK;
     HostPlan &hp = pl->hp;
-    if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
-    if (!(hp.pn[clique].owner == hp.rank || hp.pn[clique].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
-    if (n_factors < 0 || (n_factors > 0 && !factors)) return set_err(JTP_EINVAL, "bad factor list");
-    const std::vector<int> &cvars = hp.node_vars[clique];
-    // lay the tables out in the staging buffer (8-byte slots so that f32 and f64 tables can mix)
-    std::vector<int64_t> offs(n_factors);
-    std::vector<int64_t> elems(n_factors);
-    size_t bytes = 0;
-    for (int f = 0; f < n_factors; ++f) {
-        const jtp_factor &ft = factors[f];
-        if (ft.n_vars < 0 || ft.n_vars > JT_MAX_VARS) return set_err(JTP_EINVAL, "factor %d: bad variable count", f);
-        if (ft.dtype != JTP_F32 && ft.dtype != JTP_F64) return set_err(JTP_EINVAL, "factor %d: bad dtype", f);
-        int64_t n = 1;
-        for (int j = 0; j < ft.n_vars; ++j) {
-            const int v = ft.var_ids[j];
-            bool found = false;
-            for (int cv : cvars) found = found || cv == v;
-            if (!found) return set_err(JTP_EINVAL, "factor %d: variable %d is not in clique %d", f, v, clique);
-            const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
-            if (len != hp.card[v] && len != 1) return set_err(JTP_EINVAL, "factor %d axis %d has length %lld, expected %d or 1", f, j, (long long)len, hp.card[v]);
-            n *= len;
+    if (factor_off[0] < 0) return set_err(JTP_EINVAL, "bad factor list");
+    const int32_t f0 = factor_off[0], nfact = factor_off[n] - f0;
+    if (nfact < 0 || (nfact > 0 && !factors)) return set_err(JTP_EINVAL, "bad factor list");
+    // the tables in the staging buffer: 8-byte slots so that f32 and f64 tables can mix
+    std::vector<int64_t> offs((size_t)nfact), elems((size_t)nfact);
+    size_t tbytes = 0;
+    int npass = 1;
+    for (int i = 0; i < n; ++i) {
+        const int clique = cliques[i];
+        if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
+        if (!(hp.pn[clique].owner == hp.rank || hp.pn[clique].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
+        if (factor_off[i + 1] < factor_off[i]) return set_err(JTP_EINVAL, "bad factor list");
+        const std::vector<int> &cvars = hp.node_vars[clique];
+        npass = std::max(npass, (factor_off[i + 1] - factor_off[i] + JT_EVAL_MAX_F - 1) / JT_EVAL_MAX_F);
+        for (int f = factor_off[i]; f < factor_off[i + 1]; ++f) {
+            const jtp_factor &ft = factors[f];
+            const int fi = f - factor_off[i];
+            if (ft.n_vars < 0 || ft.n_vars > JT_MAX_VARS) return set_err(JTP_EINVAL, "factor %d: bad variable count", fi);
+            if (ft.dtype != JTP_F32 && ft.dtype != JTP_F64) return set_err(JTP_EINVAL, "factor %d: bad dtype", fi);
+            if (!ft.host || (ft.n_vars > 0 && !ft.var_ids)) return set_err(JTP_EINVAL, "factor %d: null argument", fi);
+            int64_t ne = 1;
+            for (int j = 0; j < ft.n_vars; ++j) {
+                const int v = ft.var_ids[j];
+                bool found = false;
+                for (int cv : cvars) found = found || cv == v;
+                if (!found) return set_err(JTP_EINVAL, "factor %d: variable %d is not in clique %d", fi, v, clique);
+                const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
+                if (len != hp.card[v] && len != 1) return set_err(JTP_EINVAL, "factor %d axis %d has length %lld, expected %d or 1", fi, j, (long long)len, hp.card[v]);
+                ne *= len;
+            }
+            elems[f - f0] = ne;
+            offs[f - f0] = (int64_t)(tbytes / 8);
+            tbytes += (size_t)((ne * (ft.dtype == JTP_F32 ? 4 : 8) + 7) / 8) * 8;
         }
-        elems[f] = n;
-        offs[f] = (int64_t)(bytes / 8);
-        bytes += (size_t)((n * (ft.dtype == JTP_F32 ? 4 : 8) + 7) / 8) * 8;
     }
+    pl->psi_dirty = true;
     HIP_TRY(hipSetDevice(hp.device));
     hipStream_t s = pl->streams[batch % pl->streams.size()];
     BatchBuffers &b = pl->bufs[batch];
-    // the kernel's records (one per pass of JT_EVAL_MAX_F factors) travel in front of the tables
-    const size_t descb = (sizeof(JtEvalDesc) + 255) & ~(size_t)255;
-    const size_t npass = (size_t)std::max(1, (n_factors + JT_EVAL_MAX_F - 1) / JT_EVAL_MAX_F);
-    const size_t tables_at = npass * descb;
-    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256) + tables_at;
+    // the kernel's records: per pass the clique records, then the workgroup prefix sums
+    std::vector<std::vector<JtEvalTask>> tasks((size_t)npass);
+    std::vector<JtEvalVar> fvars;
+    int lds_doubles = 0;
+    for (int i = 0; i < n; ++i) {
+        const int clique = cliques[i];
+        const std::vector<int> &cvars = hp.node_vars[clique];
+        const PNode &p = hp.pn[clique];
+        const int nfc = factor_off[i + 1] - factor_off[i];
+        int done = 0, pass = 0;
+        do {
+            JtEvalTask tk;
+            memset(&tk, 0, sizeof tk);
+            tk.clique = hp.pack[clique];
+            tk.accumulate = done > 0;
+            tk.nf = std::min(nfc - done, JT_EVAL_MAX_F);
+            tk.row_len = tk.clique.row_elems > 0 ? tk.clique.row_elems : 1 << tk.clique.low_bits;
+            tk.n_rows = (int32_t)(tk.clique.phys_elems / tk.row_len);
+            // the variable with a digit part inside the row and one above it
+            tk.straddle = tk.clique.row_elems > 0 ? tk.clique.split_var : -1;
+            if (tk.clique.row_elems == 0)
+                for (int j = 0; j < tk.clique.nvars; ++j)
+                    if (tk.clique.pos[j] < tk.clique.low_bits && tk.clique.pos[j] + tk.clique.nb[j] > tk.clique.low_bits) tk.straddle = j;
+            int used = 0;
+            for (int k = 0; k < tk.nf; ++k) {
+                const int f = factor_off[i] + done + k;
+                const jtp_factor &ft = factors[f];
+                tk.fnv[k] = ft.n_vars;
+                tk.fis64[k] = ft.dtype == JTP_F64;
+                tk.foff[k] = ft.dtype == JTP_F64 ? offs[f - f0] : offs[f - f0] * 2;     // in elements of its own type
+                tk.felems[k] = (int32_t)std::min<int64_t>(elems[f - f0], INT32_MAX);
+                tk.flds[k] = -1;
+                if (used + elems[f - f0] <= JT_EVAL_LDS_DOUBLES) {
+                    tk.flds[k] = used;
+                    used += (int)((elems[f - f0] + 1) & ~(int64_t)1);
+                }
+                tk.fv_off[k] = (int32_t)fvars.size();
+                fvars.resize(fvars.size() + (size_t)ft.n_vars);
+                JtEvalVar *fv = fvars.data() + tk.fv_off[k];
+                int64_t stride = 1;
+                for (int j = ft.n_vars - 1; j >= 0; --j) {
+                    const int v = ft.var_ids[j];
+                    int pos = 0;
+                    while (cvars[pos] != v) ++pos;
+                    const JtPackDesc &cd = tk.clique;
+                    fv[j].ds = cd.dstride[pos];
+                    fv[j].mod = cd.dmod[pos];
+                    fv[j].kind = cd.row_elems > 0 && cd.pos[pos] < cd.low_bits ? (pos == cd.split_var ? 2 : 1) : 0;
+                    const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
+                    fv[j].stride = (len == 1) ? 0 : (int32_t)stride;
+                    stride *= len;
+                }
+            }
+            lds_doubles = std::max(lds_doubles, used);
+            tasks[pass].push_back(tk);
+            done += tk.nf;
+            ++pass;
+        } while (done < nfc);
+        (void)p;
+    }
+    std::vector<size_t> task_at((size_t)npass), blk_at((size_t)npass);
+    size_t bytes = 0;
+    for (int k = 0; k < npass; ++k) {
+        task_at[k] = bytes;
+        bytes += (tasks[k].size() * sizeof(JtEvalTask) + 255) & ~(size_t)255;
+        blk_at[k] = bytes;
+        bytes += ((tasks[k].size() + 1) * sizeof(int32_t) + 255) & ~(size_t)255;
+    }
+    const size_t fvars_at = bytes;
+    bytes += std::max<size_t>((fvars.size() * sizeof(JtEvalVar) + 255) & ~(size_t)255, 256);
+    const size_t tables_at = bytes;
+    bytes += std::max<size_t>((tbytes + 255) & ~(size_t)255, 256);
     if (pl->eval_pending && pl->eval_stream != s) {        // another evidence set's kernels may still read the buffer
         HIP_TRY(hipStreamSynchronize(pl->eval_stream));
         pl->eval_pending = false;
@@ -774,49 +861,40 @@ int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32
     pl->eval_cursor += bytes;
     pl->eval_stream = s;
     pl->eval_pending = true;
-    for (int f = 0; f < n_factors; ++f)
-        memcpy(hstage + tables_at + offs[f] * 8, factors[f].host, (size_t)elems[f] * (factors[f].dtype == JTP_F32 ? 4 : 8));
-    const int64_t n = hp.pack[clique].phys_elems;
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
-    int done = 0;
-    size_t pass = 0;
-    do {
-        JtEvalDesc &d = *reinterpret_cast<JtEvalDesc *>(hstage + pass * descb);
-        memset(&d, 0, sizeof d);
-        d.clique = hp.pack[clique];
-        d.accumulate = done > 0;
-        d.nf = std::min(n_factors - done, JT_EVAL_MAX_F);
-        for (int k = 0; k < d.nf; ++k) {
-            const jtp_factor &ft = factors[done + k];
-            JtEvalFactor &e = d.f[k];
-            e.nv = ft.n_vars;
-            e.is_f64 = ft.dtype == JTP_F64;
-            e.off = ft.dtype == JTP_F64 ? offs[done + k] : offs[done + k] * 2;     // in elements of its own type
-            int64_t stride = 1;
-            for (int j = ft.n_vars - 1; j >= 0; --j) {
-                const int v = ft.var_ids[j];
-                int pos = 0;
-                while (cvars[pos] != v) ++pos;
-                e.cvar[j] = (uint8_t)pos;
-                e.vds[j] = d.clique.dstride[pos];
-                e.vmod[j] = d.clique.dmod[pos];
-                e.vrow[j] = d.clique.row_elems > 0 && d.clique.pos[pos] < d.clique.low_bits ? (pos == d.clique.split_var ? 2 : 1) : 0;
-                const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
-                e.stride[j] = (len == 1) ? 0 : (int32_t)stride;
-                stride *= len;
-            }
+    for (int f = 0; f < nfact; ++f)
+        memcpy(hstage + tables_at + offs[f] * 8, factors[f0 + f].host, (size_t)elems[f] * (factors[f0 + f].dtype == JTP_F32 ? 4 : 8));
+    if (!fvars.empty()) memcpy(hstage + fvars_at, fvars.data(), fvars.size() * sizeof(JtEvalVar));
+    std::vector<int> grid((size_t)npass, 0);
+    for (int k = 0; k < npass; ++k) {
+        memcpy(hstage + task_at[k], tasks[k].data(), tasks[k].size() * sizeof(JtEvalTask));
+        int32_t *bs = reinterpret_cast<int32_t *>(hstage + blk_at[k]);
+        int64_t at = 0;
+        for (size_t t = 0; t < tasks[k].size(); ++t) {
+            bs[t] = (int32_t)at;
+            at += (tasks[k][t].n_rows + JT_EVAL_ROWS - 1) / JT_EVAL_ROWS;
         }
-        done += d.nf;
-        ++pass;
-    } while (done < n_factors);
+        bs[tasks[k].size()] = (int32_t)at;
+        if (at > INT32_MAX) return set_err(JTP_EUNSUPPORTED, "too many rows in one evaluate call");
+        grid[k] = (int)at;
+    }
     HIP_TRY(hipMemcpyAsync(stage, hstage, bytes, hipMemcpyHostToDevice, s));
-    for (size_t k = 0; k < pass; ++k) {
-        const JtEvalDesc *dd = reinterpret_cast<const JtEvalDesc *>(stage + k * descb);
-        if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_product<float>), dim3(grid), dim3(256), 0, s, dd, (const char *)(stage + tables_at), (float *)b.psi);
-        else hipLaunchKernelGGL((jt_eval_product<double>), dim3(grid), dim3(256), 0, s, dd, (const char *)(stage + tables_at), (double *)b.psi);
+    const int lds = lds_doubles * 8;
+    for (int k = 0; k < npass; ++k) {
+        if (grid[k] == 0) continue;
+        const JtEvalTask *dt = reinterpret_cast<const JtEvalTask *>(stage + task_at[k]);
+        const int32_t *bs = reinterpret_cast<const int32_t *>(stage + blk_at[k]);
+        const JtEvalVar *fvp = reinterpret_cast<const JtEvalVar *>(stage + fvars_at);
+        if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_batch<float>), dim3(grid[k]), dim3(256), lds, s, dt, bs, (int)tasks[k].size(), fvp, (const char *)(stage + tables_at), (float *)b.psi);
+        else hipLaunchKernelGGL((jt_eval_batch<double>), dim3(grid[k]), dim3(256), lds, s, dt, bs, (int)tasks[k].size(), fvp, (const char *)(stage + tables_at), (double *)b.psi);
     }
     HIP_TRY(hipGetLastError());
     return JTP_OK;                        // (the caller's tables were copied to pinned memory above)
+}
+
+int jtp_set_potential_product(jtp_plan *pl, int32_t batch, int32_t clique, int32_t n_factors, const jtp_factor *factors) {
+    if (n_factors < 0 || (n_factors > 0 && !factors)) return set_err(JTP_EINVAL, "bad factor list");
+    const int32_t off[2] = {0, n_factors};
+    return jtp_set_potential_products(pl, batch, 1, &clique, off, factors);
 }
 
 static uint64_t host_splitmix64(uint64_t x) {
@@ -1369,65 +1447,94 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         std::vector<JtTask> tasks;
         std::vector<JtBlock> blocks;
         std::vector<int32_t> itab;
-        std::vector<JtMargDesc> descs;
-        std::vector<int64_t> elems;
+        std::vector<JtMargDesc> descs((size_t)n);
+        std::vector<int64_t> elems((size_t)n);
         int64_t scratch_doubles = 0, total_out = 0;
         int lds = 0;
-        for (int i = 0; i < n; ++i) {
-            const int clique = cliques[i];
-            if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "request %d: node %d is not a clique", i, clique);
-            if (!(hp.pn[clique].owner == hp.rank || hp.pn[clique].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
-            const int n_out = var_off[i + 1] - var_off[i];
-            if (n_out < 0 || n_out > JT_MAX_VARS) return set_err(JTP_EINVAL, "request %d: bad variable count", i);
-            std::vector<int> ov(var_ids + var_off[i], var_ids + var_off[i + 1]);
-            for (int a = 0; a < n_out; ++a)
-                for (int c = 0; c < a; ++c)
-                    if (ov[a] == ov[c]) return set_err(JTP_EINVAL, "request %d: variable %d requested twice", i, ov[a]);
+        // Requests on ONE clique share passes over its belief table, JT_MAX_OUT of them per pass (a pairwise model asks a
+        // clique for two or three factor marginals: round 3 read the table once per request - config 3: 1831 reads of 878
+        // tables, 2.1 x the bytes).  Multi-set plans marginalise psi x messages directly and keep one request per task.
+        std::vector<std::vector<int>> groups;
+        {
+            std::map<int, int> open;                         // clique -> its group that still has room
+            for (int i = 0; i < n; ++i) {
+                const int clique = cliques[i];
+                if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "request %d: node %d is not a clique", i, clique);
+                if (!(hp.pn[clique].owner == hp.rank || hp.pn[clique].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
+                auto it = open.find(clique);
+                if (pl->multiset || it == open.end() || (int)groups[it->second].size() >= hp.knobs.marg_group) {
+                    open[clique] = (int)groups.size();
+                    groups.push_back(std::vector<int>());
+                }
+                groups[open[clique]].push_back(i);
+            }
+        }
+        for (const std::vector<int> &grp : groups) {
+            const int clique = cliques[grp[0]];
+            std::vector<std::vector<int>> ovs;
+            for (int i : grp) {
+                const int n_out = var_off[i + 1] - var_off[i];
+                if (n_out < 0 || n_out > JT_MAX_VARS) return set_err(JTP_EINVAL, "request %d: bad variable count", i);
+                std::vector<int> ov(var_ids + var_off[i], var_ids + var_off[i + 1]);
+                for (int a = 0; a < n_out; ++a) {
+                    if (ov[a] < 0 || ov[a] >= hp.n_vars) return set_err(JTP_EINVAL, "request %d: variable %d out of range", i, ov[a]);
+                    for (int c = 0; c < a; ++c)
+                        if (ov[a] == ov[c]) return set_err(JTP_EINVAL, "request %d: variable %d requested twice", i, ov[a]);
+                }
+                ovs.push_back(ov);
+            }
             JtTask tk;
-            int out_bits = 0, npart = 1;
+            std::vector<int> out_bits, npart;
             std::vector<JtBlock> blk;
             std::vector<int32_t> tab;
             std::string err;
-            rc = jtp_plan_marginal_task(hp, clique, ov, tk, tab, out_bits, npart, blk, err, pl->multiset);
-            if (rc) return set_err(rc, "request %d: %s", i, err.c_str());
+            rc = jtp_plan_marginal_task(hp, clique, ovs, tk, tab, out_bits, npart, blk, err, pl->multiset);
+            if (rc) return set_err(rc, "request %d: %s", grp[0], err.c_str());
             tk.itab_off = (int64_t)itab.size();
             if (tk.tmap_off >= 0) tk.tmap_off += tk.itab_off;      // (the clique's thread map travels behind the task's rows)
-            tk.msg[JT_MAX_IN].off = scratch_doubles;
             itab.insert(itab.end(), tab.begin(), tab.end());
             for (JtBlock &bk : blk) {
-                bk.task = (uint32_t)i;
+                bk.task = (uint32_t)tasks.size();
                 blocks.push_back(bk);
             }
             lds = std::max(lds, tk.lds_bytes);
-            JtMargDesc md;
-            memset(&md, 0, sizeof md);
-            md.d.nvars = n_out;
-            md.d.nbits = out_bits;
-            int64_t stride = 1;
-            int bit = 0;
-            std::vector<int> pos(n_out);
-            for (int a = n_out - 1; a >= 0; --a) {          // last requested variable = lowest bits
-                pos[a] = bit;
-                bit += hp.vbits[ov[a]];
+            for (size_t j = 0; j < grp.size(); ++j) {
+                const int i = grp[j];
+                const std::vector<int> &ov = ovs[j];
+                const int n_out = (int)ov.size();
+                tk.msg[JT_MAX_IN + j].off = scratch_doubles;
+                JtMargDesc md;
+                memset(&md, 0, sizeof md);
+                md.d.nvars = n_out;
+                md.d.nbits = out_bits[j];
+                int64_t stride = 1;
+                int bit = 0;
+                std::vector<int> pos(n_out);
+                for (int a = n_out - 1; a >= 0; --a) {          // last requested variable = lowest bits
+                    pos[a] = bit;
+                    bit += hp.vbits[ov[a]];
+                }
+                for (int a = n_out - 1; a >= 0; --a) {
+                    md.d.pos[a] = (uint8_t)pos[a];
+                    md.d.nb[a] = (uint8_t)hp.vbits[ov[a]];
+                    md.d.card[a] = hp.card[ov[a]];
+                    md.d.hstride[a] = stride;
+                    stride *= hp.card[ov[a]];
+                }
+                md.d.host_elems = stride;
+                bitfield_desc(md.d);
+                md.src_off = scratch_doubles;
+                md.pstride = (int64_t)1 << out_bits[j];
+                md.npart = npart[j];
+                descs[i] = md;
+                elems[i] = stride;
+                scratch_doubles += md.pstride * npart[j];
             }
-            for (int a = n_out - 1; a >= 0; --a) {
-                md.d.pos[a] = (uint8_t)pos[a];
-                md.d.nb[a] = (uint8_t)hp.vbits[ov[a]];
-                md.d.card[a] = hp.card[ov[a]];
-                md.d.hstride[a] = stride;
-                stride *= hp.card[ov[a]];
-            }
-            md.d.host_elems = stride;
-            bitfield_desc(md.d);
-            md.src_off = scratch_doubles;
-            md.pstride = (int64_t)1 << out_bits;
-            md.dst_off = total_out;
-            md.npart = npart;
-            descs.push_back(md);
-            elems.push_back(stride);
             tasks.push_back(tk);
-            scratch_doubles += md.pstride * npart;
-            total_out += stride;
+        }
+        for (int i = 0; i < n; ++i) {                          // results in request order
+            descs[i].dst_off = total_out;
+            total_out += elems[i];
         }
         mb = new MargBatch();
         mb->key = key;
@@ -1462,7 +1569,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         pl->marg_cache.push_back(mb);
     }
     {   // the kernel that is actually launched below must be allowed this much dynamic LDS
-        const int v = pl->multiset ? JT_K_SINGLE : JT_K_COLLECT0;
+        const int v = pl->multiset ? JT_K_SINGLE : JT_K_MARGINALS;
         HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v, hp.tmix) : (const void *)KernelTable<double>::get(v, hp.tmix), mb->lds));
     }
     // marginalise the BELIEF tables: each is the "potential" argument of a childless collect
@@ -1477,7 +1584,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         plain.out_shift = (int64_t)(mb->scratch - (b.msg + plain.cur_off));
         launch_variant(pl, JT_K_SINGLE, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.psi, b.bel, b.msg, plain);
     } else
-        launch_variant(pl, JT_K_COLLECT0, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.bel, b.bel, mb->scratch, plain);
+        launch_variant(pl, JT_K_MARGINALS, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.bel, b.bel, mb->scratch, plain);
     hipLaunchKernelGGL(jt_marg_unpack, dim3(mb->max_grid_x, mb->n), dim3(256), 0, s, mb->d_descs, mb->scratch, mb->stage);
     HIP_TRY(hipGetLastError());
     bool packed = true;
@@ -1528,6 +1635,34 @@ int jtp_set_profiling_granularity(jtp_plan *pl, int32_t per_launch) {
     if (!pl) return set_err(JTP_EINVAL, "null plan");
     pl->prof_per_launch = per_launch != 0;
     pl->prof_cursor = 0;
+    return JTP_OK;
+}
+
+// ONE event pair around a whole region of propagates (a benchmark's timed steps): the device time from the first launch of
+// the region to the end of its last, nothing in between - per-propagate events cost 2-3 us of idle GPU each, and a span
+// that contains them reads longer than the step it is meant to time.
+int jtp_region_begin(jtp_plan *pl) {
+    int rc = check_ready(pl, 0);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(pl->hp.device));
+    for (int i = 0; i < 2; ++i)
+        if (!pl->region_ev[i]) HIP_TRY(hipEventCreate(&pl->region_ev[i]));
+    HIP_TRY(hipEventRecord(pl->region_ev[0], pl->streams[0]));
+    pl->region_open = true;
+    return JTP_OK;
+}
+
+int jtp_region_end(jtp_plan *pl, double *ms) {
+    int rc = check_ready(pl, 0);
+    if (rc) return rc;
+    if (!pl->region_open || !ms) return set_err(JTP_EINVAL, "jtp_region_end without jtp_region_begin");
+    HIP_TRY(hipSetDevice(pl->hp.device));
+    HIP_TRY(hipEventRecord(pl->region_ev[1], pl->streams[0]));
+    HIP_TRY(hipEventSynchronize(pl->region_ev[1]));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, pl->region_ev[0], pl->region_ev[1]));
+    *ms = t;
+    pl->region_open = false;
     return JTP_OK;
 }
 

@@ -196,27 +196,40 @@ struct JtMargDesc {
     int32_t pad;
 };
 
-// clique potential = product of factor tables (jt_eval_product)
-#define JT_EVAL_MAX_F 8
-struct JtEvalFactor {
-    int64_t off;               // element offset of the table in the staging buffer
-    int32_t nv;
-    int32_t is_f64;
-    uint8_t cvar[JT_MAX_VARS]; // position of factor variable j in the clique's host variable list
-    int32_t stride[JT_MAX_VARS]; // C-order stride of factor variable j (0: broadcast axis)
-    // where factor variable j's digit sits in the clique's device index (copied from the clique's record by the
-    // host: the kernel indexes these with its loop counter only)
-    uint32_t vds[JT_MAX_VARS];   // device element stride of the digit
-    int32_t vmod[JT_MAX_VARS];   // digits stored along it
-    uint8_t vrow[JT_MAX_VARS];   // 1: a mixed-radix digit INSIDE a row (JtPackDesc::row_elems): taken of (x mod row_elems);
-                                 // 2: the clique's variable across the thread part's top bit (JtPackDesc::split_*)
-};
-struct JtEvalDesc {
+#define JT_EVAL_MAX_F 8        // factor tables multiplied per pass over a clique (more: further passes that multiply into the table)
+// clique potentials of MANY cliques in ONE launch (jt_eval_batch, jtp_set_potential_products): one record per clique (and
+// pass of JT_EVAL_MAX_F factors).  A workgroup forms `rows per workgroup` consecutive stored rows of one clique; an element's
+// place x = row * row_len + t splits every variable's digit into a part that depends on t only and a part that depends on
+// the row only (jt_digit is additive over the two), so the index arithmetic is done once per thread and once per row, not
+// once per element (jt_eval_product did it per element: 9.2 GiB of config-3 tables took 31 ms, bound by integer division).
+struct JtEvalTask {
     JtPackDesc clique;
     int32_t nf;
-    int32_t accumulate;        // 1: multiply into the table already in the arena
-    JtEvalFactor f[JT_EVAL_MAX_F];
+    int32_t accumulate;        // 1: multiply into the table already in the arena (factors beyond the first JT_EVAL_MAX_F)
+    int32_t row_len;           // elements of one stored row (2^TB, or JtPackDesc::row_elems)
+    int32_t n_rows;            // stored rows of the table
+    int32_t straddle;          // the clique variable (index into clique.*) whose digit has a part inside the row AND a part
+                               // above it (a bit field across bit TB, or JtPackDesc::split_var); -1: none
+    int32_t pad;
+    int64_t foff[JT_EVAL_MAX_F];        // element offset of factor f's table in the staging buffer (in elements of its own type)
+    int32_t fnv[JT_EVAL_MAX_F];
+    int32_t fis64[JT_EVAL_MAX_F];
+    int32_t flds[JT_EVAL_MAX_F];        // offset (doubles) of the table's copy in LDS, or -1: read from the staging buffer
+    int32_t felems[JT_EVAL_MAX_F];
+    int32_t fv_off[JT_EVAL_MAX_F];      // factor f's variables: records fv_off[f] .. fv_off[f] + fnv[f] of the launch's JtEvalVar pool
 };
+// one variable of one factor: where its digit sits in the clique's device index (copied from the clique's record by the host -
+// the kernel indexes nothing with an index it has loaded: hipcc (ROCm 7.2) returned the digit of clique.dmod[split_var] for
+// clique.dmod[cvar[j]] there) and its stride in the factor's table
+struct JtEvalVar {
+    uint32_t ds;               // device element stride of the digit
+    int32_t mod;               // digits stored along it
+    int32_t stride;            // C-order stride in the factor's table (0: broadcast axis)
+    int32_t kind;              // 0: taken of x; 1: a mixed-radix digit INSIDE a row (JtPackDesc::row_elems): taken of (x mod row_elems);
+                               // 2: the clique's variable across the thread part's top bit (JtPackDesc::split_*)
+};
+#define JT_EVAL_ROWS 32          // rows per workgroup of jt_eval_batch (128 KiB of table)
+#define JT_EVAL_LDS_DOUBLES 6144 // factor tables of one clique kept in LDS (as doubles): 48 KiB
 
 // kernel variant ids: collect with n children; distribute with (has_parent, n children)
 enum {
@@ -229,5 +242,6 @@ enum {
     JT_K_MULTI_COLLECT, JT_K_MULTI_DISTRIBUTE,      // multi-set plans: JT_MSETS evidence sets per pass over a table
     JT_K_SINGLE,                                    // one task list, any mix of modes and neighbour counts (read-out)
     JT_K_BOTH_FLOW,                                 // collect and distribute in ONE dataflow launch (Segment::phase 2)
+    JT_K_MARGINALS,                                 // read-out: up to JT_MAX_OUT marginals of one belief table per pass over it
     JT_K_COUNT
 };

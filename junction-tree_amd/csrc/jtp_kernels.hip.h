@@ -716,7 +716,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 double w = p[e];
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) w *= in[k][e];
-                if constexpr (NOUT > 0) acc[0][e] += w;
+                // (several outputs - read-out tasks only, jt_marginals: every one the sum over its own complement)
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) acc[j][e] += w;
             }
         } else {
             double b[VEC];
@@ -1716,6 +1718,22 @@ __global__ __launch_bounds__(JT_THREADS) void jt_single(const JtTask *__restrict
     }
 }
 
+// Read-out of single-set plans (jtp_get_marginals, CliqueGraph.marginalize junctiontree.py:229-274): a pass over a BELIEF
+// table (the `psi` argument) that forms one to JT_MAX_OUT marginals of it at once - the requests of a model's factors on one
+// clique share the read of its table.  Bound: HBM read, sizeof(T) per element.
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 4) void jt_marginals(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                              const int *__restrict__ itab, const T *__restrict__ psi,
+                                                              T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    const JtBlock &bk = blk[blockIdx.x];
+    const JtTask &tk = tasks[bk.task];
+    switch (tk.n_out) {
+        case 1: jt_pass<T, 0, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        case 2: jt_pass<T, 0, 2, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+        default: jt_pass<T, 0, 3, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Kernels of plans with a mixed-radix thread part (HostPlan::tmix: some clique stores the variables of its low index
 // bits at their TRUE cardinalities): the same passes with TMIX = true - a thread reaches its elements through the
@@ -1725,6 +1743,11 @@ template <typename T, bool FLOW>
 __device__ __forceinline__ void jt_collect_mix(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                uint32_t *flow_ctl, uint64_t t_entry) {
+    if (tk.n_out > 1) {                        // read-out tasks: several marginals of one belief table per pass
+        if (tk.n_out == 2) jt_pass<T, 0, 2, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
+        else jt_pass<T, 0, 3, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
+        return;
+    }
     switch (tk.n_in) {
         case 0: jt_pass<T, 0, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
         case 1: jt_pass<T, 1, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
@@ -1892,39 +1915,143 @@ __global__ __launch_bounds__(256) void jt_fill_value(double *__restrict__ dst, i
 }
 #endif
 
-// clique potential = product of factor tables, written in the clique's device layout
-// (CliqueGraph.evaluate for one clique, junctiontree/junctiontree.py:203-226)
+// Clique potentials = products of factor tables, written in the cliques' device layouts: CliqueGraph.evaluate
+// (junctiontree/junctiontree.py:203-226) for a LIST of cliques in ONE launch (jtp_set_potential_products).
+// Bound: HBM writes (sizeof(T) per element; the factor tables are small and sit in LDS, or are gathered through L2).
+// A workgroup forms JT_EVAL_ROWS consecutive stored rows of one clique.  The element at x = row * row_len + t has
+// digit_i(x) = digit_i(t) + digit_i(row * row_len) for every variable i (jt_digit is additive over the two parts: a variable
+// lies inside the row, above it, or - one variable at most, JtEvalTask::straddle - has a low part inside and a high part
+// above), so every factor's table index is tin[f](t) + rin[f](row): the divisions happen once per thread and once per
+// row.  (Round 3's jt_eval_product decoded every element: 9.2 GiB of config-3 tables in 31 ms, 0.3 TB/s.)
 template <typename T>
-__global__ __launch_bounds__(256) void jt_eval_product(const JtEvalDesc *__restrict__ dp, const char *__restrict__ stage, T *__restrict__ arena) {
-    // (the record is read from memory, not passed as a kernel argument: hipcc (ROCm 7.2) mis-read the 32-bit arrays of a
+__global__ __launch_bounds__(256) void jt_eval_batch(const JtEvalTask *__restrict__ tasks, const int32_t *__restrict__ blk_start, int ntasks,
+                                                     const JtEvalVar *__restrict__ fvars, const char *__restrict__ stage, T *__restrict__ arena) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T ext_t __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *lds_tab = reinterpret_cast<double *>(smem);
+    __shared__ int32_t s_rin[JT_EVAL_ROWS][JT_EVAL_MAX_F];
+    __shared__ int32_t s_rdig[JT_EVAL_ROWS], s_rok[JT_EVAL_ROWS];
+    // (the records are read from memory, not passed as kernel arguments: hipcc (ROCm 7.2) mis-read the 32-bit arrays of a
     //  kernel-argument struct when indexed with a run-time index - dstride[cvar] came back as dstride[0])
-    const JtEvalDesc &d = *dp;
-    const JtPackDesc &c = d.clique;
-    const int64_t n = c.phys_elems;
-    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
-        int64_t unused;
-        const bool valid = jt_dev_to_host(c, (uint32_t)x, unused);
-        double v = d.accumulate ? (double)arena[c.dev_off + x] : 1.0;
-        if (valid) {
-            for (int f = 0; f < d.nf; ++f) {
-                const JtEvalFactor &ff = d.f[f];
-                int64_t idx = 0;
-                for (int j = 0; j < ff.nv; ++j) {
-                    const uint32_t ds = ff.vds[j];
-                    // (a digit of the thread part stored at true cardinalities is a digit of the place INSIDE the row, as in
-                    //  jt_digit: taken of x itself it was wrong from the second row on - found by the round-3 API check below)
-                    const uint32_t xr = ff.vrow[j] ? (uint32_t)x % (uint32_t)c.row_elems : (uint32_t)x;
-                    int digit = ds > 0 ? (int)((xr / ds) % (uint32_t)ff.vmod[j]) : 0;
-                    if (ff.vrow[j] == 2) digit += (int)(((uint32_t)x / c.split_ds2) % (uint32_t)c.split_mod2) << c.split_lb;
-                    idx += (int64_t)digit * ff.stride[j];
-                }
-                v *= ff.is_f64 ? reinterpret_cast<const double *>(stage)[ff.off + idx]
-                               : (double)reinterpret_cast<const float *>(stage)[ff.off + idx];
-            }
+    int lo = 0, hi = ntasks;
+    const int b = (int)blockIdx.x;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk_start[mid] <= b) lo = mid;
+        else hi = mid;
+    }
+    const JtEvalTask &tk = tasks[lo];
+    const JtPackDesc &c = tk.clique;
+    const int tid = (int)threadIdx.x;
+    const int row0 = (b - blk_start[lo]) * JT_EVAL_ROWS;
+    const int nrows = tk.n_rows - row0 < JT_EVAL_ROWS ? tk.n_rows - row0 : JT_EVAL_ROWS;
+    const int L = tk.row_len, nf = tk.nf, sv = tk.straddle;
+    const int scard = sv >= 0 ? c.card[sv] : 1;
+    // small factor tables -> LDS, as doubles
+#pragma unroll
+    for (int f = 0; f < JT_EVAL_MAX_F; ++f) {
+        if (f >= nf || tk.flds[f] < 0) continue;
+        double *dst = lds_tab + tk.flds[f];
+        const int n = tk.felems[f];
+        if (tk.fis64[f]) {
+            const double *src = reinterpret_cast<const double *>(stage) + tk.foff[f];
+            for (int i = tid; i < n; i += 256) dst[i] = src[i];
         } else {
-            v = 0.0;
+            const float *src = reinterpret_cast<const float *>(stage) + tk.foff[f];
+            for (int i = tid; i < n; i += 256) dst[i] = (double)src[i];
         }
-        arena[c.dev_off + x] = (T)v;
+    }
+    // place x (x = t inside the first row, or x = row * row_len) -> is it the part of a table entry, the straddling
+    // variable's part of its digit, and every factor's part of its table index
+    auto decode = [&](const uint32_t x, const bool high, int &sdig, int (&fidx)[JT_EVAL_MAX_F]) {
+        bool ok = true;
+        int64_t back = 0;
+        sdig = 0;
+        for (int i = 0; i < c.nvars; ++i) {
+            const int d = jt_digit(c, i, x);
+            if (i == sv) sdig = d;
+            else ok = ok && d < c.card[i];
+            if (c.row_elems > 0 && i == c.split_var)
+                back += high ? (int64_t)(d >> c.split_lb) * c.split_ds2 : (int64_t)d * c.dstride[i];
+            else
+                back += (int64_t)d * c.dstride[i];
+        }
+        ok = ok && back == (int64_t)x;          // index bits no variable owns must be clear
+#pragma unroll
+        for (int f = 0; f < JT_EVAL_MAX_F; ++f) {
+            int idx = 0;
+            if (f < nf && ok) {
+                const JtEvalVar *fv = fvars + tk.fv_off[f];
+                for (int j = 0; j < tk.fnv[f]; ++j) {
+                    const uint32_t ds = fv[j].ds;
+                    const uint32_t xr = fv[j].kind ? x % (uint32_t)c.row_elems : x;
+                    int digit = ds > 0 ? (int)((xr / ds) % (uint32_t)fv[j].mod) : 0;
+                    if (fv[j].kind == 2) digit += (int)((x / c.split_ds2) % (uint32_t)c.split_mod2) << c.split_lb;
+                    idx += digit * fv[j].stride;
+                }
+            }
+            fidx[f] = idx;
+        }
+        return ok;
+    };
+    int tin[VEC][JT_EVAL_MAX_F], tdig[VEC];
+    bool tok[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int t = tid * VEC + e;
+        tok[e] = decode((uint32_t)(t < L ? t : 0), false, tdig[e], tin[e]) && t < L;
+    }
+    if (tid < nrows) {
+        int hd, rin[JT_EVAL_MAX_F];
+        const bool ok = decode((uint32_t)(row0 + tid) * (uint32_t)L, true, hd, rin);
+        s_rok[tid] = ok ? 1 : 0;
+        s_rdig[tid] = hd;
+#pragma unroll
+        for (int f = 0; f < JT_EVAL_MAX_F; ++f) s_rin[tid][f] = rin[f];
+    }
+    __syncthreads();
+    const bool active = tid * VEC < L;
+    T *row = arena + c.dev_off + (int64_t)row0 * L + tid * VEC;
+    for (int r = 0; r < nrows; ++r, row += L) {
+        const bool rok = s_rok[r] != 0;
+        const int hd = s_rdig[r];
+        bool ok[VEC];
+        double v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            ok[e] = tok[e] && rok && tdig[e] + hd < scard;
+            v[e] = 1.0;
+        }
+        if (tk.accumulate && active) {
+            const ext_t old = *reinterpret_cast<const ext_t *>(row);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = (double)old[e];
+        }
+#pragma unroll
+        for (int f = 0; f < JT_EVAL_MAX_F; ++f) {
+            if (f >= nf) continue;
+            const int ri = s_rin[r][f];
+            if (tk.flds[f] >= 0) {
+                const double *tab = lds_tab + tk.flds[f];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] *= tab[ok[e] ? tin[e][f] + ri : 0];
+            } else if (tk.fis64[f]) {
+                const double *tab = reinterpret_cast<const double *>(stage) + tk.foff[f];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] *= tab[ok[e] ? tin[e][f] + ri : 0];
+            } else {
+                const float *tab = reinterpret_cast<const float *>(stage) + tk.foff[f];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] *= (double)tab[ok[e] ? tin[e][f] + ri : 0];
+            }
+        }
+        if (active) {
+            ext_t ov;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) ov[e] = ok[e] ? (T)v[e] : (T)0;
+            __builtin_nontemporal_store(ov, reinterpret_cast<ext_t *>(row));
+        }
     }
 }
 
@@ -1996,7 +2123,8 @@ __global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restri
     X template __global__ void jt_collect_level<T>(JT_KARGS(T));             \
     X template __global__ void jt_distribute_level<T>(JT_KARGS(T));          \
     X template __global__ void jt_reduce_level<T>(JT_KARGS(T));              \
-    X template __global__ void jt_single<T>(JT_KARGS(T));
+    X template __global__ void jt_single<T>(JT_KARGS(T));                    \
+    X template __global__ void jt_marginals<T>(JT_KARGS(T));
 #define JT_INST_SHAPE(X, T)                                                  \
     X template __global__ void jt_collect<T, 0>(JT_KARGS(T));                \
     X template __global__ void jt_collect<T, 1>(JT_KARGS(T));                \

@@ -634,6 +634,8 @@ PlanKnobs jtp_read_knobs() {
     k.lane_low = geti("JTP_LANE_LOW", 2);
     k.longest_first = geti("JTP_LONGEST_FIRST", 1);
     k.top_share = getd("JTP_TOP_SHARE", 0.12);
+    k.marg_group = std::max(1, std::min(geti("JTP_MARG_GROUP", JT_MAX_OUT), JT_MAX_OUT));
+    k.marg_block_log2 = geti("JTP_MARG_BLOCK_LOG2", 0);
     return k;
 }
 
@@ -1996,35 +1998,43 @@ static void neighbour_inputs(const HostPlan &hp, const PNode &p, std::vector<Msg
     }
 }
 
-int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
-                           JtTask &tk, std::vector<int32_t> &itab, int &out_bits, int &npart,
+int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<std::vector<int>> &out_vars,
+                           JtTask &tk, std::vector<int32_t> &itab, std::vector<int> &out_bits, std::vector<int> &npart,
                            std::vector<JtBlock> &blocks, std::string &err, bool with_neighbours) {
     const PNode &p = hp.pn[pnode];
-    PSep s;
-    s.vars.assign(out_vars.rbegin(), out_vars.rend());       // last requested variable = lowest bits
-    int bit = 0;
-    for (int v : s.vars) {
-        if (find_var(p.vars, v) < 0) FAIL(JTP_EINVAL, "variable %d is not in clique %d", v, p.real);
-        s.pos.push_back(bit);
-        s.nb.push_back(hp.vbits[v]);
-        bit += hp.vbits[v];
+    if (out_vars.empty() || (int)out_vars.size() > JT_MAX_OUT) FAIL(JTP_EINVAL, "internal: %zu marginals in one task", out_vars.size());
+    if (with_neighbours && out_vars.size() != 1) FAIL(JTP_EINVAL, "internal: several marginals in one task of a multi-set plan");
+    std::vector<PSep> seps(out_vars.size());
+    out_bits.clear();
+    for (size_t j = 0; j < out_vars.size(); ++j) {
+        PSep &s = seps[j];
+        s.vars.assign(out_vars[j].rbegin(), out_vars[j].rend());       // last requested variable = lowest bits
+        int bit = 0;
+        for (int v : s.vars) {
+            if (find_var(p.vars, v) < 0) FAIL(JTP_EINVAL, "variable %d is not in clique %d", v, p.real);
+            s.pos.push_back(bit);
+            s.nb.push_back(hp.vbits[v]);
+            bit += hp.vbits[v];
+        }
+        s.nbits = bit;
+        if (bit > 28) FAIL(JTP_EUNSUPPORTED, "marginal with %d index bits", bit);
+        out_bits.push_back(bit);
     }
-    s.nbits = bit;
-    if (bit > 28) FAIL(JTP_EUNSUPPORTED, "marginal with %d index bits", bit);
     memset(&tk, 0, sizeof tk);
     tk.pnode = pnode;
     tk.psi_off = p.arena_off;
     tk.bel_off = -1;
-    tk.mode = 0;
+    tk.mode = 0;                                 // (several outputs: every one of them the sum over its own complement)
     std::vector<MsgView> ins, outs;
     std::vector<std::pair<int64_t, int>> src;
     // multi-set plans keep no belief table: the marginal is taken of psi * (every incoming message) directly
     if (with_neighbours) neighbour_inputs(hp, p, ins, src);
     if ((int)ins.size() > JT_MAX_IN) FAIL(JTP_EUNSUPPORTED, "clique with %zu neighbours", ins.size());
-    outs.push_back(make_view(p, s, -1, true));
+    for (const PSep &s : seps) outs.push_back(make_view(p, s, -1, true));
     int real_bits = 0;
     for (int nb : p.nb) real_bits += nb;
-    int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
+    // (a pass over a belief table with nothing to stage: the longest workgroups the loop allows, fewest partial copies)
+    int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, with_neighbours ? 14 : (hp.knobs.marg_block_log2 > 0 ? hp.knobs.marg_block_log2 : hp.TB + JT_MAX_ITER_LOG2), err);
     tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
     if (hp.tmix) {                               // the task travels with its own table buffer: the clique's thread map behind its rows
@@ -2036,8 +2046,8 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int>
         tk.msg[k].npart = src[k].second;
         tk.msg[k].same_launch = 0;
     }
-    out_bits = bit;
-    npart = tk.msg[JT_MAX_IN].npart;
+    npart.clear();
+    for (size_t j = 0; j < out_vars.size(); ++j) npart.push_back(tk.msg[JT_MAX_IN + j].npart);
     blocks.clear();
     for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(hp, tk, 0u, f));
     return JTP_OK;

@@ -125,6 +125,8 @@ struct PlanKnobs {
     int no_tmix = 0;                                                // JTP_NO_TMIX: thread parts stay padded bit fields (round-2 layout)
     int no_tsplit = 0;                                              // JTP_NO_TSPLIT: no variable across bit TB in a clique with mixed-radix rows (the first form of round 3)
     double tmix_fill = 0.6;                                         // JTP_TMIX_FILL: mixed-radix rows for cliques whose bit-field thread part would be emptier than this
+    int marg_group = JT_MAX_OUT;                                    // JTP_MARG_GROUP: marginals of one belief table formed by one pass over it (1: a pass each, round 3)
+    int marg_block_log2 = 0;                                        // JTP_MARG_BLOCK_LOG2: log2 of the elements per workgroup of a marginal pass (0: the 64 rows a workgroup can hold)
     int merge_phases = -1;                                          // JTP_MERGE_PHASES: 1 / 0 = both phases in one dataflow launch / never; -1: where messages are small
 };
 PlanKnobs jtp_read_knobs();
@@ -182,12 +184,13 @@ struct HostPlan {
 // Build the plan.  Returns JTP_OK or an error code with `err` set.
 int jtp_build_plan(const jtp_tree_desc *desc, HostPlan &hp, std::string &err);
 
-// One-off task: marginalise table `src_off` (layout of pnode `p`) onto `out_vars` (message layout:
-// out_vars[0] slowest, padded to power-of-two bits).  The task writes `npart` partial copies of
-// 2^out_bits doubles at msg-arena offset `dst_off`.  Returns JTP_OK or error.
-int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<int> &out_vars,
-                           JtTask &task, std::vector<int32_t> &itab, int &out_bits, int &npart, std::vector<JtBlock> &blocks,
-                           std::string &err, bool with_neighbours = false);
+// One-off task: marginalise the table of pnode `p` onto each of the variable lists `out_vars` (one to JT_MAX_OUT of them:
+// ONE pass over the table serves them all; message layout: out_vars[j][0] slowest, padded to power-of-two bits).  Output j is
+// written as npart[j] partial copies of 2^out_bits[j] doubles at the msg-arena offset the caller puts into
+// task.msg[JT_MAX_IN + j].off.  Returns JTP_OK or error.
+int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<std::vector<int>> &out_vars,
+                           JtTask &task, std::vector<int32_t> &itab, std::vector<int> &out_bits, std::vector<int> &npart,
+                           std::vector<JtBlock> &blocks, std::string &err, bool with_neighbours = false);
 
 // Multi-set plans keep no belief tables: the belief of clique `pnode` for one evidence set is formed on
 // demand as psi * (every incoming message of that set) into the scratch belief arena (mode 1, no outputs).

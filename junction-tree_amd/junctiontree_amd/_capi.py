@@ -21,7 +21,7 @@ JTP_SHARE_POTENTIALS = 32
 JTP_FLOW_TICKETS = 16
 JTP_MULTISET = 64
 JTP_NO_COMPACT = 128
-N_VARIANTS = 21
+N_VARIANTS = 22
 MAX_VARS = 32            # variables per node the C ABI takes (JT_MAX_VARS); engine.Plan keeps one-state variables beyond that on the host
 
 
@@ -93,6 +93,7 @@ SYMBOLS = {
     "jtp_set_potential": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                     C.POINTER(C.c_int64), C.c_int32]),
     "jtp_set_potential_product": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Factor)]),
+    "jtp_set_potential_products": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jtp_fill_synthetic": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_double)]),
     "jtp_set_evidence": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "jtp_propagate": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -106,6 +107,8 @@ SYMBOLS = {
     "jtp_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "jtp_set_profiling_granularity": (C.c_int, [C.c_void_p, C.c_int32]),
     "jtp_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int32]),
+    "jtp_region_begin": (C.c_int, [C.c_void_p]),
+    "jtp_region_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "jtp_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "jtp_get_launch_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "jtp_debug_read_msg": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),

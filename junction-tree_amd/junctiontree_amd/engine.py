@@ -170,7 +170,7 @@ class Plan:
         if arr.dtype not in (np.float32, np.float64):
             arr = arr.astype(np.float64)
         arr = np.ascontiguousarray(arr).reshape(arr.shape)      # ascontiguousarray makes 0-d 1-d
-        self.__dict__.get("_factor_digests", {}).pop(node, None)    # (JunctionTree.propagate's record of what is staged)
+        self._factor_tables = None                              # (what stage_factors believes the device holds is no longer true)
         full = self.node_shape[node]
         if arr.ndim != len(full):
             raise ValueError("potential of node %r has %d axes, its variable list has %d"
@@ -192,7 +192,7 @@ class Plan:
         layout (`CliqueGraph.evaluate` for one clique, `junctiontree.py:203-226`): only the factor
         tables are uploaded.  `var_lists[i]` labels the axes of `arrays[i]`; an axis may have length
         1 to broadcast.  No factors gives an all-ones potential."""
-        self.__dict__.get("_factor_digests", {}).pop(node, None)
+        self._factor_tables = None
         keep, recs = [], (_capi.Factor * max(len(arrays), 1))()
         for i, (arr, labels) in enumerate(zip(arrays, var_lists)):
             a = np.asarray(arr)
@@ -214,6 +214,31 @@ class Plan:
             recs[i].shape = C.cast(shape, C.POINTER(C.c_int64))
         _capi.check(self._lib.jtp_set_potential_product(self._handle, batch, self.abi_of[node], len(arrays), recs))
 
+    def stage_factors(self, factor_labels, factor_to_clique, xs):
+        """`CliqueGraph.evaluate` (`junctiontree.py:203-226`) on the device for a whole factor graph: clique c's potential is
+        the product of the tables `xs[f]` with `factor_to_clique[f] == c` (labels `factor_labels[f]`, one axis each; an axis
+        may have length 1 to broadcast).  ONE call into the library for all cliques whose tables differ from what this
+        plan was last staged with (`jtp_set_potential_products`: one host-to-device copy, one kernel launch); the reference
+        recomputes every clique on every call and says so in a FIXME (`junctiontree.py:206-214`).  Returns the number of
+        cliques formed (also kept as `staged_cliques`)."""
+        arrs = [x if type(x) is np.ndarray else np.asarray(x) for x in xs]
+        all_f32 = all(a.dtype == np.float32 for a in arrs)
+        key = (tuple(map(tuple, factor_labels)), tuple(factor_to_clique), [a.shape for a in arrs], all_f32)
+        ft = self.__dict__.get("_factor_tables")
+        if ft is None or ft.key != key:
+            ft = self._factor_tables = _FactorTables(self, key)
+        self.staged_cliques = ft.stage(self, arrs)
+        return self.staged_cliques
+
+    def factor_marginals(self, factor_labels, factor_to_clique, batch=0):
+        """`CliqueGraph.marginalize` (`junctiontree.py:229-274`) on the device: the marginal of clique
+        `factor_to_clique[f]`'s belief onto `factor_labels[f]` for every factor, as float64 arrays (views of one buffer)."""
+        key = (tuple(map(tuple, factor_labels)), tuple(factor_to_clique))
+        req = self.__dict__.get("_marginal_requests")
+        if req is None or req.key != key:
+            req = self._marginal_requests = _MarginalRequests(self, key)
+        return req.read(self, batch)
+
     def set_evidence(self, observed, batch=0):
         """Hard evidence of evidence set `batch`: `observed` maps variable label -> observed state; it
         replaces the set's previous evidence ({} clears it) and applies from the next propagate."""
@@ -231,7 +256,7 @@ class Plan:
     def fill_synthetic(self, seed, scales=None, batch=0):
         """Device-side counter-based potentials (see synthetic.synth_values).  `scales` is
         indexed by the caller's clique index."""
-        self.__dict__.pop("_factor_digests", None)
+        self._factor_tables = None
         sc = None
         if scales is not None:
             sc = (C.c_double * self.n_cliques)(*[float(scales[c]) for c in self.cliques])
@@ -311,6 +336,16 @@ class Plan:
         _capi.check(self._lib.jtp_set_profiling_stride(self._handle, int(stride)))
         _capi.check(self._lib.jtp_set_profiling(self._handle, int(keep)))
 
+    def region_begin(self):
+        """One hipEvent on the plan's stream now; `region_end` records a second one and returns the device time between
+        them in ms (a benchmark's timed steps: no event between the propagates)."""
+        _capi.check(self._lib.jtp_region_begin(self._handle))
+
+    def region_end(self):
+        ms = C.c_double(0.0)
+        _capi.check(self._lib.jtp_region_end(self._handle, C.byref(ms)))
+        return ms.value
+
     def debug_set(self, knob, value):
         """Test hook (`jtp_debug_set`): e.g. ("flow_debug", 8) makes every dataflow wait time out."""
         _capi.check(self._lib.jtp_debug_set(self._handle, knob.encode(), int(value)))
@@ -344,6 +379,154 @@ class Plan:
                 "distribute_ms": st.distribute_ms, "kernels": kernels, "flow_fallbacks": st.flow_fallbacks,
                 "launch_mode": ("level", "flow", "flow_tickets")[st.launch_mode], "tickets_used": st.tickets_used,
                 "flow_propagates": st.flow_propagates, "device_bytes": st.device_bytes}
+
+
+_DIGEST_LIMIT = 1 << 20          # bytes: larger factor tables are handed over again on every call rather than compared
+
+# numpy view of an array of jtp_factor records (_capi.Factor): the host pointers of all factors are written in one go
+_FACTOR_REC = np.dtype({"names": ["host", "n_vars", "dtype", "var_ids", "shape"], "formats": ["u8", "i4", "i4", "u8", "u8"],
+                        "offsets": [0, 8, 12, 16, 24], "itemsize": C.sizeof(_capi.Factor)})
+
+
+class _FactorTables:
+    """The argument tables of `jtp_set_potential_products` for one factor graph on one plan, built once, and the factor
+    values the plan was last staged with (small tables: one concatenated copy, compared element by element on the next
+    call, so that arrays updated in place are seen; tables above `_DIGEST_LIMIT` always count as changed)."""
+
+    def __init__(self, plan, key):
+        labels, f2c, shapes, all_f32 = key
+        self.key = key
+        self.np_dtype = np.float32 if all_f32 else np.float64
+        n_f = len(labels)
+        if len(f2c) != n_f or len(shapes) != n_f:
+            raise ValueError("%d factors, %d clique assignments, %d value arrays" % (n_f, len(f2c), len(shapes)))
+        pos_of = {c: i for i, c in enumerate(plan.cliques)}          # caller's clique index -> place in this plan's clique list
+        var_ids, var_off, shape_all = [], [0], []
+        sizes = np.empty(n_f, dtype=np.int64)
+        for f in range(n_f):
+            if len(shapes[f]) != len(labels[f]):
+                raise ValueError("factor %d has %d axes but %d variables" % (f, len(shapes[f]), len(labels[f])))
+            for ax, lab in enumerate(labels[f]):
+                if lab in plan._trivial:
+                    if shapes[f][ax] != 1:
+                        raise ValueError("axis %d of factor %d belongs to variable %r of cardinality 1 but has length %d"
+                                         % (ax, f, lab, shapes[f][ax]))
+                    continue
+                try:
+                    var_ids.append(plan.var_id[lab])
+                except KeyError as exc:                              # (the reference raises KeyError too)
+                    raise KeyError(exc.args[0])
+                shape_all.append(shapes[f][ax])
+            var_off.append(len(var_ids))
+            sizes[f] = int(np.prod(shapes[f], dtype=np.int64)) if len(shapes[f]) else 1
+        self._var_ids = np.asarray(var_ids + [0], dtype=np.int32)
+        self._shape = np.asarray(shape_all + [0], dtype=np.int64)
+        var_off = np.asarray(var_off, dtype=np.int64)
+        small = sizes * np.dtype(self.np_dtype).itemsize <= _DIGEST_LIMIT
+        self.small_idx = np.flatnonzero(small)
+        self.big_idx = np.flatnonzero(~small)
+        self.small_off = np.zeros(n_f + 1, dtype=np.int64)           # element offset of every small table in the copy
+        np.cumsum(np.where(small, sizes, 0), out=self.small_off[1:])
+        self.seg_start = self.small_off[self.small_idx]
+        self.f_pos = np.asarray([pos_of[c] for c in f2c], dtype=np.int64)     # factor -> place of its clique
+        self.order = np.argsort(self.f_pos, kind="stable")           # factors clique by clique
+        n_c = len(plan.cliques)
+        self.cliques = np.asarray([plan.abi_of[c] for c in plan.cliques], dtype=np.int32)
+        self.factor_off = np.zeros(n_c + 1, dtype=np.int32)
+        np.cumsum(np.bincount(self.f_pos, minlength=n_c), out=self.factor_off[1:])
+        recs = np.zeros(max(n_f, 1), dtype=_FACTOR_REC)
+        o = self.order
+        recs["n_vars"][:n_f] = (var_off[1:] - var_off[:-1])[o]
+        recs["dtype"][:n_f] = _capi.JTP_F32 if all_f32 else _capi.JTP_F64
+        recs["var_ids"][:n_f] = self._var_ids.ctypes.data + 4 * var_off[:-1][o]
+        recs["shape"][:n_f] = self._shape.ctypes.data + 8 * var_off[:-1][o]
+        self.recs = recs
+        self.n_f = n_f
+        self.prev = None             # the small tables as last staged
+        self.mine = np.asarray([plan.owns(c) for c in plan.cliques], dtype=bool)
+
+    def stage(self, plan, arrs):
+        n_f, item = self.n_f, np.dtype(self.np_dtype).itemsize
+        if len(self.small_idx):
+            flat = np.concatenate([arrs[i].reshape(-1) for i in self.small_idx], dtype=self.np_dtype)
+        else:
+            flat = np.empty(0, dtype=self.np_dtype)
+        dirty = np.ones(len(self.cliques), dtype=bool)
+        if self.prev is not None:
+            changed = np.zeros(n_f, dtype=bool)
+            changed[self.big_idx] = True
+            if len(flat):
+                changed[self.small_idx] = np.logical_or.reduceat(flat != self.prev, self.seg_start)
+            dirty[:] = False
+            dirty[self.f_pos[changed]] = True
+        dirty &= self.mine                                           # (sharded plans: this rank's cliques only)
+        todo = np.flatnonzero(dirty)
+        if len(todo) == 0:
+            self.prev = flat
+            return 0
+        host = np.zeros(max(n_f, 1), dtype=np.uint64)
+        host[self.small_idx] = flat.ctypes.data + item * self.small_off[self.small_idx]
+        keep = []
+        for i in self.big_idx:
+            a = arrs[i]
+            a = np.ascontiguousarray(a, dtype=np.float32 if a.dtype == np.float32 else np.float64)
+            keep.append(a)
+            host[i] = a.ctypes.data
+        recs = self.recs
+        recs["host"][:n_f] = host[:n_f][self.order]
+        for i in self.big_idx:                                        # (their type is their own: float32 stays float32)
+            recs["dtype"][np.flatnonzero(self.order == i)] = _capi.JTP_F32 if arrs[i].dtype == np.float32 else _capi.JTP_F64
+        fo = self.factor_off
+        if len(todo) == len(self.cliques):
+            cl, off, rr = self.cliques, fo, recs
+        else:
+            cl = np.ascontiguousarray(self.cliques[todo])
+            counts = (fo[1:] - fo[:-1])[todo]
+            off = np.zeros(len(todo) + 1, dtype=np.int32)
+            np.cumsum(counts, out=off[1:])
+            pick = np.concatenate([np.arange(fo[c], fo[c + 1]) for c in todo]) if off[-1] else np.zeros(0, dtype=np.int64)
+            rr = np.ascontiguousarray(recs[pick]) if off[-1] else recs[:1].copy()
+        self.prev = None                                             # (whatever happens below, the device no longer matches it)
+        _capi.check(plan._lib.jtp_set_potential_products(plan._handle, 0, len(todo), cl.ctypes.data, off.ctypes.data, rr.ctypes.data))
+        self.prev = flat
+        return int(len(todo))
+
+
+class _MarginalRequests:
+    """The argument tables of `jtp_get_marginals` for one factor graph on one plan, built once."""
+
+    def __init__(self, plan, key):
+        labels, f2c = key
+        self.key = key
+        n = len(labels)
+        var_ids, var_off, out_off, self.shapes = [], [0], [0], []
+        for labs in labels:
+            var_ids += [plan.var_id[lab] for lab in labs if lab not in plan._trivial]
+            var_off.append(len(var_ids))
+            shape = tuple(1 if lab in plan._trivial else plan.card[plan.var_id[lab]] for lab in labs)
+            self.shapes.append(shape)
+            out_off.append(out_off[-1] + (int(np.prod(shape, dtype=np.int64)) if shape else 1))
+        self.n = n
+        self.cliques = np.asarray([plan.abi_of[c] for c in f2c] + [0], dtype=np.int32)
+        self.var_off = np.asarray(var_off, dtype=np.int32)
+        self.var_ids = np.asarray(var_ids + [0], dtype=np.int32)
+        self.out_off = np.asarray(out_off, dtype=np.int64)
+        self.bounds = out_off
+        # (runs of equally shaped results are cut out of the buffer with one reshape: a pairwise model has thousands)
+        self.uniform = len(set(self.shapes)) == 1 and n > 0 and len(self.shapes[0]) > 0
+
+    def read(self, plan, batch):
+        if self.n == 0:
+            return []
+        flat = np.empty(self.bounds[-1], dtype=np.float64)
+        _capi.check(plan._lib.jtp_get_marginals(
+            plan._handle, batch, self.n, self.cliques.ctypes.data_as(C.POINTER(C.c_int32)),
+            self.var_off.ctypes.data_as(C.POINTER(C.c_int32)), self.var_ids.ctypes.data_as(C.POINTER(C.c_int32)),
+            self.out_off.ctypes.data_as(C.POINTER(C.c_int64)), flat.ctypes.data_as(C.POINTER(C.c_double))))
+        if self.uniform:
+            return list(flat.reshape((self.n,) + self.shapes[0]))
+        b = self.bounds
+        return [flat[b[i]:b[i + 1]].reshape(self.shapes[i]) for i in range(self.n)]
 
 
 def pinned_empty(shape, dtype=np.float64):

@@ -69,43 +69,14 @@ def einsum(xs, xs_keys, y_keys):
     return np.einsum(*call)
 
 
-_DIGEST_LIMIT = 1 << 20          # bytes: larger tables are uploaded again rather than hashed (PCIe beats the hash)
-
-
-def _digest(x):
-    """Content fingerprint of one factor table (shape, dtype, 128-bit hash of the bytes), or None for tables too
-    large to be worth hashing.  Identity is not enough: callers update arrays in place."""
-    a = np.asarray(x)
-    if a.nbytes > _DIGEST_LIMIT:
-        return None
-    try:
-        import xxhash
-        h = xxhash.xxh3_128_digest(np.ascontiguousarray(a).view(np.uint8).reshape(-1).data)
-    except ImportError:               # pragma: no cover - xxhash ships with the image
-        import hashlib
-        h = hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
-    return (a.shape, a.dtype.str, h)
-
-
 def _stage_changed_cliques(plan, ct, xs):
-    """`evaluate` on the device for the cliques whose member factors differ from what `plan` holds.  Returns the
-    number of cliques staged (`plan.staged_cliques` keeps the count of the last call for tests and tools)."""
-    seen = plan.__dict__.setdefault("_factor_digests", {})
-    staged = 0
-    factors = ct.factor_graph.factors
-    for c, members in enumerate(ct._members()):
-        # what is staged = which factors, over which variables in which axis order, with which values: two
-        # JunctionTree objects whose junction trees coincide share one cached plan (engine.plan_for keys on the
-        # tree, not on the factors), and the same bytes under a transposed label list are another table
-        digests = tuple(_digest(xs[i]) for i in members)
-        key = tuple((i, tuple(factors[i]), d) for i, d in zip(members, digests))
-        if None not in digests and seen.get(c) == key:
-            continue
-        plan.set_potential_product(c, take(xs, members), take(ct.factor_graph.factors, members))
-        seen[c] = key
-        staged += 1
-    plan.staged_cliques = staged
-    return staged
+    """`evaluate` on the device for the cliques whose member factors differ from what `plan` holds: one call into the
+    library for all of them (`engine.Plan.stage_factors`).  Returns the number of cliques formed (`plan.staged_cliques`
+    keeps the count of the last call for tests and tools).  What is staged = which factors, over which variables in which
+    axis order, with which values: two JunctionTree objects whose junction trees coincide share one cached plan
+    (`engine.plan_for` keys on the tree, not on the factors), and the same bytes under a transposed label list are
+    another table - `stage_factors` compares all of that."""
+    return plan.stage_factors(ct.factor_graph.factors, ct.factor_to_maxclique, xs)
 
 
 @dataclass(frozen=True)
@@ -193,8 +164,9 @@ class JunctionTree:
         # every call and says so in a FIXME, junctiontree.py:206-214)
         _stage_changed_cliques(plan, ct, xs)
         plan.propagate()
-        # marginalize (junctiontree.py:229-274) on the device, all factors in one launch
-        return plan.marginals([(mc, list(fvars)) for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)])
+        # marginalize (junctiontree.py:229-274) on the device: one launch for all factors, the factors of one clique
+        # sharing the passes over its belief table
+        return plan.factor_marginals(ct.factor_graph.factors, ct.factor_to_maxclique)
 
     def propagate_evidence_sets(self, xs, evidence_sets):
         """`propagate` for several hard-evidence sets over the same factor values (no counterpart in the
@@ -224,5 +196,4 @@ class JunctionTree:
         for b, observed in enumerate(evidence_sets):
             plan.set_evidence(observed, batch=b)
         plan.propagate(0, len(evidence_sets))
-        requests = [(mc, list(fvars)) for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)]
-        return [plan.marginals(requests, batch=b) for b in range(len(evidence_sets))]
+        return [plan.factor_marginals(ct.factor_graph.factors, ct.factor_to_maxclique, batch=b) for b in range(len(evidence_sets))]

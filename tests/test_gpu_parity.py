@@ -701,7 +701,9 @@ def test_batched_marginals_match_single_requests():
         assert len(got) == len(reqs)
         for (c, labels), g in zip(reqs, got):
             single = plan.marginal(c, labels)
-            assert g.shape == single.shape and np.array_equal(g, single)
+            # (a request that shares the pass over its clique's belief table with two others - round 4 - is summed in another
+            #  order than the same request on its own: equal to rounding, not bit for bit)
+            assert g.shape == single.shape and np.allclose(g, single, rtol=1e-13, atol=0.0)
             axes = [spec["node_vars"][c].index(lab) for lab in labels]
             drop = tuple(a for a in range(len(spec["node_vars"][c])) if a not in axes)
             ref = np.transpose(want[c].sum(axis=drop), np.argsort(np.argsort(axes))) if labels else want[c].sum()

@@ -27,15 +27,41 @@ plan = tree.plan("f32"); t2 = time.perf_counter()
 d = plan.describe()
 print("plan %.2f s: arena %.2f GiB, %d launches, %d blocks, max LDS %d" % (t2 - t1, d["arena_elems"] * 4 / 2**30, len(d["launches"]), d["n_blocks"], d["max_lds"]))
 t3 = time.perf_counter(); out = tree.propagate(values); t4 = time.perf_counter()
-print("propagate() end to end (H2D factors, device evaluate, collect+distribute, %d device marginals, D2H) %.2f s" % (len(factors), t4 - t3))
+print("propagate() first call (H2D factors, device evaluate, collect+distribute, %d device marginals, D2H) %.3f s" % (len(factors), t4 - t3))
 ct = tree.clique_tree
-ta = time.perf_counter()
-for c, members in enumerate(ct._members()):
-    plan.set_potential_product(c, jt.take(values, members), jt.take(ct.factor_graph.factors, members))
-plan.sync(); tb = time.perf_counter()
-plan.propagate(); tc = time.perf_counter()
-plan.marginals([(mc, list(fvars)) for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique)]); td = time.perf_counter()
-print("   of which: device evaluate of %d cliques %.3f s, collect+distribute %.3f s, %d marginals %.3f s" % (len(widths), tb - ta, tc - tb, len(factors), td - tc))
+labels, f2c = ct.factor_graph.factors, ct.factor_to_maxclique
+# steady state, every factor table changed (the worst case for evaluate): end to end, then stage by stage
+reps = 5
+e2e, ev, pr, mg = [], [], [], []
+for r in range(reps):
+    vals = [v * np.float32(1.0 + 1e-3 * (r + 1)) for v in values]
+    plan.sync()
+    t0 = time.perf_counter(); out = tree.propagate(vals); t1 = time.perf_counter()
+    e2e.append(t1 - t0)
+    vals = [v * np.float32(1.0 - 1e-3 * (r + 1)) for v in values]
+    ta = time.perf_counter(); n_staged = plan.stage_factors(labels, f2c, vals); plan.sync(); tb = time.perf_counter()
+    plan.propagate(); tc = time.perf_counter()
+    out = plan.factor_marginals(labels, f2c); td = time.perf_counter()
+    ev.append(tb - ta); pr.append(tc - tb); mg.append(td - tc)
+d2h = sum(o.nbytes for o in out)
+phys = {p["real"]: p["phys_elems"] for p in d["pnodes"] if p["real"] >= 0}
+with_factors = sorted(set(f2c))
+staged_bytes = sum(phys[c] for c in with_factors) * 4
+# every clique (also the ones no factor is assigned to: all-ones tables, formed once per plan)
+cold = []
+for r in range(3):
+    plan._factor_tables.prev = None
+    plan.sync()
+    ta = time.perf_counter(); n_all = plan.stage_factors(labels, f2c, values); plan.sync(); cold.append(time.perf_counter() - ta)
+all_bytes = sum(phys.values()) * 4
+print("evaluate of ALL %d cliques (first call of a plan): %.2f ms for %.2f GiB written -> %.2f TB/s" % (n_all, min(cold) * 1e3, all_bytes / 2**30, all_bytes / min(cold) / 1e12))
+print("propagate() steady state, all %d factor tables new each call: end to end %.2f ms (min of %d; median %.2f)" % (len(factors), min(e2e) * 1e3, reps, sorted(e2e)[reps // 2] * 1e3))
+print("   stage by stage (each synchronised, min of %d): evaluate of the %d cliques that have factors %.2f ms (%.2f GiB written -> %.2f TB/s), collect+distribute %.2f ms, %d factor marginals %.2f ms (%.2f GiB of belief tables read; D2H %.2f MB)"
+      % (reps, n_staged, min(ev) * 1e3, staged_bytes / 2**30, staged_bytes / min(ev) / 1e12, min(pr) * 1e3, len(factors), min(mg) * 1e3, staged_bytes / 2**30, d2h / 1e6))
+out = tree.propagate(vals)
+t0 = time.perf_counter(); out = tree.propagate(vals); t1 = time.perf_counter()
+print("propagate() with unchanged factor tables (nothing staged: %d cliques): %.2f ms" % (plan.staged_cliques, (t1 - t0) * 1e3))
+out = tree.propagate(values)
 plan.set_profiling(3)
 for _ in range(3): plan.propagate()
 st = plan.stats()
