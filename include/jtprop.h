@@ -111,6 +111,9 @@ typedef struct jtp_stats {
     int32_t tickets_used;           /* propagates (counted per evidence set) since plan creation that ran in ticket order */
     int32_t flow_propagates;        /* propagates (per evidence set) since plan creation that ran as dataflow launches  */
     double  device_bytes;           /* device memory the plan allocated at creation (arenas, messages, task tables)     */
+    int32_t storage_dtype;          /* JTP_F32 / JTP_F64 the clique tables are stored as: a float32 request is made with float64
+                                       tables where the float32 layout cannot be planned (sub-boxes beyond the LDS of a CU) */
+    int32_t reserved;
 } jtp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

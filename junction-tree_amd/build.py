@@ -33,9 +33,10 @@ def source_id():
 
 
 def built_id():
+    """Source digest of the library in place (without the "+flags" suffix an experimental build carries)."""
     try:
         with open(ID_FILE) as fh:
-            return fh.read().split()[0]
+            return fh.read().split()[0].split("+")[0]
     except (OSError, IndexError):
         return None
 
@@ -51,6 +52,8 @@ def needs_build():
 
 def build(force=False, verbose=True, extra=(), out=None, jobs=None):
     out = out or LIB
+    if out == LIB and extra:
+        raise SystemExit("experimental flags (%s) build to --out, not onto the product library" % " ".join(extra))
     if out == LIB and not force and not needs_build():
         return LIB
     from concurrent.futures import ThreadPoolExecutor
@@ -70,13 +73,22 @@ def build(force=False, verbose=True, extra=(), out=None, jobs=None):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             return obj
-        jobs = jobs or max(1, min(len(SOURCES), (os.cpu_count() or 2)))
+        # (the template translation units take 1-2 GiB of compiler each: at most eight at once, JTP_BUILD_JOBS overrides)
+        jobs = jobs or int(os.environ.get("JTP_BUILD_JOBS", 0)) or max(1, min(len(SOURCES), os.cpu_count() or 2, 8))
         with ThreadPoolExecutor(jobs) as pool:          # (the heaviest translation units are listed first)
             objs = list(pool.map(compile_one, INST + ["jtp_engine.hip", "jtp_plan.cpp"]))
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-ldl"]
+        # link beside the target and move the result into place: a process that has the old library mapped keeps it,
+        # nobody ever sees a half-written one
+        tmp_out = out + ".tmp%d" % os.getpid()
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp_out, "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp_out, out)
+        finally:
+            if os.path.exists(tmp_out):
+                os.remove(tmp_out)
     finally:
         shutil.rmtree(objdir, ignore_errors=True)
     if out == LIB:

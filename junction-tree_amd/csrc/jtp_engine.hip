@@ -242,6 +242,7 @@ static hipError_t raise_lds(const void *func, int bytes) {
 struct jtp_plan {
     HostPlan hp;
     bool device = false;
+    bool widened = false;           // asked for float32 tables, made with float64 ones (jtp_plan_create)
     bool inflight = false;          // counted in g_inflight: a dataflow propagate of this plan may still be running
     int launch_mode = 0;            // of the last propagate: 0 one launch per level, 1 dataflow in blockIdx order, 2 dataflow, ticket order
     int tickets_used = 0;           // propagates (per evidence set) that ran in ticket order
@@ -386,8 +387,12 @@ int jtp_device_count(int32_t *count) {
 
 int jtp_device_memory(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes) {
     size_t f = 0, t = 0;
+    int before = 0;
+    HIP_TRY(hipGetDevice(&before));
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMemGetInfo(&f, &t));
+    const hipError_t e = hipMemGetInfo(&f, &t);
+    (void)hipSetDevice(before);                    // (the caller's current device stays what it was)
+    if (e != hipSuccess) return set_err(JTP_EHIP, "hipMemGetInfo failed: %s", hipGetErrorString(e));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
     return JTP_OK;
@@ -476,6 +481,27 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         const int rc2 = jtp_build_plan(&again, pl->hp, err2);
         if (rc2 == JTP_OK) rc = rc2;
         else if (rc2 != JTP_EUNSUPPORTED) rc = rc2, err = err2;
+    }
+    //  - float32 storage means 1024-element rows: a clique of few rows with four or more neighbours whose separators are
+    //    nearly the whole clique then needs more LDS than a CU has ("message sub-boxes do not fit in LDS").  The same tree in
+    //    float64 storage (512-element rows) plans: the plan is then made with double tables - twice the device bytes of
+    //    what was asked for, the host interface unchanged (every call names its host type) - and says so in
+    //    jtp_stats.storage_dtype.  (Round 3 did this in the Python layer only, keyed on the message text.)
+    if (rc == JTP_EUNSUPPORTED && desc && desc->dtype == JTP_F32 && !(desc->flags & JTP_MULTISET)) {
+        for (int attempt = 0; attempt < 2 && rc == JTP_EUNSUPPORTED; ++attempt) {
+            jtp_tree_desc again = *desc;
+            again.dtype = JTP_F64;
+            if (attempt == 1) {
+                if (desc->flags & JTP_NO_COMPACT) break;
+                again.flags |= JTP_NO_COMPACT;
+            }
+            std::string err2;
+            delete pl;
+            pl = new jtp_plan();
+            const int rc2 = jtp_build_plan(&again, pl->hp, err2);
+            if (rc2 == JTP_OK) rc = rc2, pl->widened = true;
+            else if (rc2 != JTP_EUNSUPPORTED) rc = rc2, err = err2;
+        }
     }
     if (rc != JTP_OK) {
         delete pl;
@@ -1683,6 +1709,7 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     st->tickets_used = pl->tickets_used;
     st->flow_propagates = pl->flow_propagates;
     st->device_bytes = pl->device_bytes;
+    st->storage_dtype = hp.dtype;
     if (pl->multiset) {
         const int groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS;
         for (const Launch &L : hp.launches) {

@@ -76,11 +76,18 @@ class Stats(C.Structure):
         ("tickets_used", C.c_int32),
         ("flow_propagates", C.c_int32),
         ("device_bytes", C.c_double),
+        ("storage_dtype", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
 class JtpError(RuntimeError):
     """HIP / RCCL / allocation failure reported by libjtprop."""
+
+
+class UnsupportedStructure(ValueError):
+    """JTP_EUNSUPPORTED: a well-formed structure outside the engine's limits (a table beyond 2^31 entries, sub-boxes that
+    no layout fits into the LDS of a CU, ...).  A ValueError, as every structural refusal is."""
 
 
 _lib = None
@@ -157,7 +164,9 @@ def check(rc):
     if rc == JTP_OK:
         return
     msg = lib().jtp_last_error().decode("utf-8", "replace")
-    if rc in (JTP_EINVAL, JTP_EUNSUPPORTED):
+    if rc == JTP_EUNSUPPORTED:
+        raise UnsupportedStructure(msg)
+    if rc == JTP_EINVAL:
         raise ValueError(msg)
     if rc == JTP_ENOMEM:
         raise MemoryError(msg)

@@ -32,8 +32,12 @@ def _first_seen_order(factors, sizes):
     return order
 
 
-def triangulate(factors, sizes):
-    """Return (maxcliques, factor_to_maxclique) for the factor graph."""
+def triangulate(factors, sizes, order=None):
+    """Return (maxcliques, factor_to_maxclique) for the factor graph.
+
+    `order`: an elimination order to follow instead of greedy min-fill - a sequence of variables, eliminated first in
+    that order (variables it does not list follow by min-fill).  On a lattice the column-by-column order gives the
+    chain of width-(h+1) cliques of SURVEY.md 8d, where min-fill trades a shallower tree for some wider cliques."""
     rank = _first_seen_order(factors, sizes)
     adj = {v: set() for v in rank}
     for f in factors:
@@ -55,11 +59,15 @@ def triangulate(factors, sizes):
             w *= sizes[a]
         return w
 
-    cost = {v: (fill_of(v), weight_of(v), rank[v]) for v in adj}
+    forced = [v for v in (order or []) if v in adj]
+    if len(set(forced)) != len(forced):
+        raise ValueError("the elimination order lists a variable twice")
+    forced.reverse()                                  # (popped from the end)
+    cost = {v: (fill_of(v), weight_of(v), rank[v]) for v in adj} if len(forced) < len(adj) else {}
     remaining = set(adj)
     cliques, member_of = [], {v: [] for v in adj}
     while remaining:
-        v = min(remaining, key=cost.__getitem__)
+        v = forced.pop() if forced else min(remaining, key=cost.__getitem__)
         nb = adj[v]
         cand = [v] + sorted(nb, key=rank.__getitem__)
         cset = set(cand)
@@ -78,9 +86,10 @@ def triangulate(factors, sizes):
             touched |= adj[a]
         remaining.discard(v)
         del adj[v]
-        for u in touched:
-            if u in remaining:
-                cost[u] = (fill_of(u), weight_of(u), rank[u])
+        if len(forced) < len(remaining):              # (costs are only looked at once the given order is used up)
+            for u in (touched if not forced else remaining):
+                if u in remaining:
+                    cost[u] = (fill_of(u), weight_of(u), rank[u])
 
     maxcliques = [c[0] for c in cliques]
     factor_to_maxclique = []

@@ -100,6 +100,7 @@ class Plan:
                       np.float64: _capi.JTP_F64}[dtype]
         self.n_batch = n_batch
         self.rank, self.n_ranks = rank, n_ranks
+        self.device = int(device)
 
         off, ids = [0], []
         for n in self.node_ids:
@@ -135,6 +136,16 @@ class Plan:
         d.block_log2 = block_log2
         d.layout_policy = layout_policy
         _capi.check(self._lib.jtp_plan_create(C.byref(d), C.byref(self._handle)))
+        # what the tables are stored as: a float32 request whose layout cannot be planned (sub-boxes beyond the LDS of a CU:
+        # cliques of few rows with four or more large separators) is made with float64 tables by jtp_plan_create
+        self.requested_dtype = self.dtype
+        st = _capi.Stats()
+        _capi.check(self._lib.jtp_get_stats(self._handle, C.byref(st)))
+        self.dtype = int(st.storage_dtype)
+        if self.dtype != self.requested_dtype:
+            import warnings
+            warnings.warn("junctiontree_amd: float32 tables asked for, float64 tables made (the float32 layout of this tree does "
+                          "not fit the LDS of a CU): twice the device memory", RuntimeWarning, stacklevel=3)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -552,7 +563,8 @@ def pinned_empty(shape, dtype=np.float64):
 
 _cache = {}                       # key -> Plan, least recently used first
 _cache_stats = {"hits": 0, "misses": 0, "evictions": 0}
-_cache_budget = None              # bytes; None: a quarter of the device's total memory, asked for at first use
+_cache_budget = None              # bytes per device; None: a quarter of the device's total memory, asked for at first use
+_device_budget = {}               # device -> that quarter
 _CACHE_MAX_PLANS = 16
 
 
@@ -564,13 +576,16 @@ def set_plan_cache_budget(nbytes):
     _evict(keep=None)
 
 
-def _budget():
-    global _cache_budget
-    if _cache_budget is None:
+def _budget(device=0):
+    """Bytes the cached plans of one device may hold together: what set_plan_cache_budget said, else a quarter of THAT
+    device's memory (asked for once per device)."""
+    if _cache_budget is not None:
+        return _cache_budget
+    if device not in _device_budget:
         free, total = C.c_uint64(0), C.c_uint64(0)
-        rc = _capi.lib().jtp_device_memory(0, C.byref(free), C.byref(total))
-        _cache_budget = int(total.value // 4) if rc == _capi.JTP_OK and total.value else 1 << 62
-    return _cache_budget
+        rc = _capi.lib().jtp_device_memory(int(device), C.byref(free), C.byref(total))
+        _device_budget[device] = int(total.value // 4) if rc == _capi.JTP_OK and total.value else 1 << 62
+    return _device_budget[device]
 
 
 def _plan_bytes(plan):
@@ -580,14 +595,16 @@ def _plan_bytes(plan):
 
 
 def _evict(keep):
-    """Forget least recently used plans until the cache fits its budget.  A forgotten plan is destroyed when its last
-    holder lets go (JunctionTree.plan() hands these objects out: closing here could pull a plan from under its user)."""
-    budget = _budget() if _cache else 0
+    """Forget least recently used plans until every device's cached plans fit its budget.  A forgotten plan is destroyed when
+    its last holder lets go (JunctionTree.plan() hands these objects out: closing here could pull a plan from under its user)."""
     while _cache:
-        total = sum(_plan_bytes(p) for p in _cache.values())
-        if total <= budget and len(_cache) <= _CACHE_MAX_PLANS:
+        per_device = {}
+        for p in _cache.values():
+            per_device[p.device] = per_device.get(p.device, 0) + _plan_bytes(p)
+        over = [dev for dev, b in per_device.items() if b > _budget(dev)]
+        if not over and len(_cache) <= _CACHE_MAX_PLANS:
             break
-        victim = next((k for k in _cache if k is not keep), None)
+        victim = next((k for k, p in _cache.items() if k is not keep and (not over or p.device in over)), None)
         if victim is None:
             break                     # the plan just asked for is larger than the budget on its own: it stays
         _cache.pop(victim)
@@ -595,9 +612,12 @@ def _evict(keep):
 
 
 def plan_cache_info():
-    """{"plans", "device_bytes", "budget_bytes", "hits", "misses", "evictions"} of the plan cache."""
+    """{"plans", "device_bytes", "budget_bytes", "hits", "misses", "evictions", "widened"} of the plan cache ("widened": cached
+    plans asked for with float32 tables and made with float64 ones; budget_bytes: per device, of the first cached plan's)."""
+    first = next(iter(_cache.values()), None)
     return dict(_cache_stats, plans=len(_cache), device_bytes=sum(_plan_bytes(p) for p in _cache.values()),
-                budget_bytes=_budget() if _cache or _cache_budget is not None else None)
+                widened=sum(1 for p in _cache.values() if p.dtype != p.requested_dtype),
+                budget_bytes=_budget(first.device) if first is not None else _cache_budget)
 
 
 def _freeze(tree):
@@ -621,15 +641,7 @@ def plan_for(tree, node_vars, sizes, dtype, **kwargs):
         return plan
     _cache_stats["misses"] += 1
     try:
-        try:
-            plan = Plan(tree, node_vars, sizes, dtype=dtype, **kwargs)
-        except ValueError as exc:
-            # float32 storage means 1024-element rows: a clique of few rows with four or more neighbours whose separators are
-            # nearly the whole clique then needs more LDS than a CU has (limits).  The same tree in float64
-            # storage (512-element rows) plans; it stays on the device, the tables are converted on upload.
-            if dtype not in ("f32", np.float32) or "do not fit in LDS" not in str(exc):
-                raise
-            plan = Plan(tree, node_vars, sizes, dtype="f64", **kwargs)
+        plan = Plan(tree, node_vars, sizes, dtype=dtype, **kwargs)
     except MemoryError:
         # the device is full: let go of every cached plan (those nobody else holds are destroyed now) and try once more
         import gc

@@ -22,10 +22,11 @@ __all__ = ["create_junction_tree", "argfind1", "take", "is_subset", "einsum",
            "FactorGraph", "CliqueGraph", "JunctionTree"]
 
 
-def create_junction_tree(factors, sizes):
-    """Create a junction tree for a factor graph (reference: `junctiontree.py:12-16`)."""
+def create_junction_tree(factors, sizes, order=None):
+    """Create a junction tree for a factor graph (reference: `junctiontree.py:12-16`).  `order` (not in the reference):
+    an elimination order for the triangulation instead of greedy min-fill (`construction.triangulate`)."""
     assert all(type(f) == list for f in factors), "Provided factor is not a list"
-    return FactorGraph(factors=factors, sizes=sizes).triangulate().create_junction_tree()
+    return FactorGraph(factors=factors, sizes=sizes).triangulate(order=order).create_junction_tree()
 
 
 def argfind1(xs, cond):
@@ -86,9 +87,9 @@ class FactorGraph:
     factors: Any
     sizes: Any
 
-    def triangulate(self):
+    def triangulate(self, order=None):
         """Triangulate and collect the maximal cliques (`junctiontree.py:102-117`)."""
-        maxcliques, factor_to_maxclique = cons.triangulate(self.factors, self.sizes)
+        maxcliques, factor_to_maxclique = cons.triangulate(self.factors, self.sizes, order=order)
         return CliqueGraph(maxcliques=maxcliques, factor_to_maxclique=factor_to_maxclique,
                            factor_graph=self)
 

@@ -189,3 +189,10 @@ def lattice_mrf(h=6, w=167, card=8, seed=0, dtype=np.float32):
     scale = card ** (-len(names) / len(factors))
     values = [(rng.uniform(0.5, 1.5, (card, card)) * scale).astype(dtype) for _ in factors]
     return factors, sizes, values
+
+
+def lattice_column_order(h=6, w=167):
+    """The column-by-column elimination order of `lattice_mrf`'s variables ("column-sweep elimination"):
+    every elimination clique is a variable, what is left of its column and the frontier in the next - h + 1 variables,
+    one maximal clique per variable but the last h, a chain."""
+    return [i * w + j for j in range(w) for i in range(h)]

@@ -396,8 +396,9 @@ def test_plans_created_and_run_from_two_host_threads():
 def test_float32_trees_the_planner_refuses_run_in_float64_storage():
     """A clique of few rows with four or more neighbours whose separators are nearly the whole clique cannot be planned with
     1024-element (float32) rows - every message needs the whole thread part in LDS (found by tools/gpu_fuzz.py, FUZZ_BIG, seed
-    92488).  An explicit float32 plan says so; `compute_beliefs` / `propagate` (engine.plan_for) store such a tree as float64 on
-    the device instead."""
+    92488).  Round 4: `jtp_plan_create` itself makes such a plan with float64 tables (round 3: only the Python layer behind
+    `compute_beliefs` did, keyed on the message text; a C caller got JTP_EUNSUPPORTED) and says so - `jtp_stats.storage_dtype`,
+    a RuntimeWarning from `engine.Plan`, `plan_cache_info()["widened"]`."""
     from test_planner_emulated import random_junction_tree
     rng = np.random.default_rng(92488)
     while True:
@@ -405,10 +406,16 @@ def test_float32_trees_the_planner_refuses_run_in_float64_storage():
         if 1 << 14 <= max(p.size for p in pots) <= 1 << 22 and sum(p.size for p in pots) <= 1 << 24:
             break
     cast = [p.astype(np.float32) for p in pots]
-    with pytest.raises(ValueError, match="do not fit in LDS"):
-        engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
+    from junctiontree_amd import _capi
+    with pytest.warns(RuntimeWarning, match="float64 tables made"):
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32")
+    assert plan.requested_dtype == _capi.JTP_F32 and plan.dtype == _capi.JTP_F64
+    plan.close()
     want = oracle.beliefs_exact(spec["tree"], cast, spec["node_vars"])
-    got = comp.compute_beliefs(spec["tree"], cast, spec["node_vars"])
+    engine.clear_plan_cache()
+    with pytest.warns(RuntimeWarning):
+        got = comp.compute_beliefs(spec["tree"], cast, spec["node_vars"])
+    assert engine.plan_cache_info()["widened"] == 1
     for g, w in zip(got, want):
         close(g, w, rtol=RTOL64)
 

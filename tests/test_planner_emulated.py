@@ -396,3 +396,28 @@ def test_more_than_32_variables_on_a_node_when_the_rest_have_one_state():
     # the same tree with the one-state variables given two states is beyond the C ABI's limit, and says so
     with pytest.raises(Exception, match="variables"):
         engine.Plan(tree, node_vars, {lab: max(2, k) for lab, k in sizes.items()}, plan_only=True)
+
+
+def test_float32_layouts_that_do_not_fit_lds_are_planned_with_float64_tables():
+    """A clique of few rows with four or more neighbours whose separators are nearly the whole clique cannot be planned with
+    1024-element (float32) rows (tools/gpu_fuzz.py, FUZZ_BIG, seed 92488).  `jtp_plan_create` makes the plan with float64
+    tables then (`jtp_stats.storage_dtype`; `engine.Plan` warns) - for a C caller as for the Python layer - and the task
+    tables it emits compute the oracle's beliefs."""
+    from junctiontree_amd import _capi
+    rng = np.random.default_rng(92488)
+    while True:
+        spec, pots = random_junction_tree(rng, n_cliques=int(rng.integers(2, 12)), max_width=9, cards=(2, 3, 3, 4, 5, 6, 7))
+        if 1 << 14 <= max(p.size for p in pots) <= 1 << 22 and sum(p.size for p in pots) <= 1 << 24:
+            break
+    with pytest.warns(RuntimeWarning, match="float64 tables made"):
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", plan_only=True)
+    assert plan.requested_dtype == _capi.JTP_F32 and plan.dtype == _capi.JTP_F64 and plan.describe()["dtype"] == _capi.JTP_F64
+    plan.close()
+    want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
+    with pytest.warns(RuntimeWarning):
+        got, _ = emulate(spec["tree"], pots, spec["node_vars"], spec["sizes"], dtype="f32")
+    for n, arr in got.items():
+        np.testing.assert_allclose(arr, np.broadcast_to(want[n], arr.shape), rtol=1e-11, atol=1e-13, err_msg="node %d" % n)
+    # a multi-set request is NOT widened: its caller chooses between the multi-set pass and one pass per set
+    with pytest.raises(ValueError):
+        engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", plan_only=True, n_batch=4, multiset=True, lds_budget=64)

@@ -20,7 +20,9 @@ sizes = {v: K for v in names.values()}
 rng = np.random.default_rng(0)
 scale = K ** (-len(names) / len(factors))
 values = [(rng.uniform(0.5, 1.5, (K, K)) * scale).astype(np.float32) for _ in factors]
-t0 = time.perf_counter(); tree = jt.create_junction_tree(factors, sizes); t1 = time.perf_counter()
+# argv[3] = "sweep": the column-by-column elimination order of SURVEY.md 8d (a chain of width-(H+1) cliques) instead of min-fill
+ORDER = [names[i, j] for j in range(W) for i in range(H)] if len(sys.argv) > 3 and sys.argv[3] == "sweep" else None
+t0 = time.perf_counter(); tree = jt.create_junction_tree(factors, sizes, order=ORDER); t1 = time.perf_counter()
 widths = [len(c) for c in tree.clique_tree.maxcliques]
 print("variables %d factors %d cliques %d max width %d  construction %.2f s" % (len(names), len(factors), len(widths), max(widths), t1 - t0))
 plan = tree.plan("f32"); t2 = time.perf_counter()
