@@ -561,9 +561,12 @@ def main():
         alg = synthetic.algorithmic_bytes(spec, itemsize)
         n = spec["n_cliques"]
         # the small top part of the partition is replicated on every rank (one exchange per propagate instead of two)
-        owner = partition.subtree_owners(spec["parent"], [1.0] * n, world, replicate_top=not args.no_replicate_top)
+        # (re-rooted at the weighted centroid first, SURVEY.md 8e: the balanced tree of config 4 is rooted there already,
+        #  a chain handed over with its end as the root is hung from its middle)
+        part_root, _, owner = partition.partition_tree(spec["parent"], [1.0] * n, world, replicate_top=not args.no_replicate_top)
         plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=args.dtype,
                            device=device, n_ranks=world, rank=rank, owner=owner, n_batch=args.batch,
+                           root=part_root if world > 1 else None,
                            block_log2=args.block_log2, lds_budget=args.lds_budget,
                            layout_policy=args.layout_policy, split_variants=args.split_variants,
                            level_launches=args.level_launches, share_potentials=args.share, multiset=args.multiset)

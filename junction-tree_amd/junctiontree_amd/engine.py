@@ -57,10 +57,21 @@ class Plan:
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
                  layout_policy=0, split_variants=False, keep_root=False, level_launches=False,
-                 flow_tickets=False, share_potentials=False, multiset=False, no_compact=False):
+                 flow_tickets=False, share_potentials=False, multiset=False, no_compact=False, root=None):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
+        if root is not None and root != order[0]:
+            # the same tree hung from another clique (partition.partition_tree: the weighted centroid): the edges on the
+            # path root .. old root turn round, every edge keeps its separator
+            if root not in parent:
+                raise ValueError("root %r is not a clique of the tree" % (root,))
+            prev, prev_sep, c = -1, -1, root
+            while c != -1:
+                nxt, nxt_sep = parent[c], parent_sep[c]
+                parent[c], parent_sep[c] = prev, prev_sep
+                prev, prev_sep, c = c, nxt_sep, nxt
+            order = [root] + [c for c in order if c != root]
         cliques = sorted(order)
         seps = sorted(parent_sep[c] for c in order if parent[c] != -1)
         if set(cliques) & set(seps):

@@ -9,7 +9,56 @@ heavier than an even share, then packs frontier subtrees onto ranks largest-firs
 gives the top part to the least loaded rank.
 """
 
-__all__ = ["subtree_owners", "part_weights"]
+__all__ = ["subtree_owners", "part_weights", "weighted_centroid", "reroot", "partition_tree"]
+
+
+def weighted_centroid(parent, weights):
+    """The clique whose removal leaves no component heavier than half the tree (ties: the lowest index): rooted there,
+    no subtree outweighs the rest, so the frontier of `subtree_owners` can be balanced and the quotient tree is as
+    shallow as the weights allow ("re-root at the weighted centroid first")."""
+    n = len(parent)
+    children = [[] for _ in range(n)]
+    root = 0
+    for c, p in enumerate(parent):
+        if p < 0:
+            root = c
+        else:
+            children[p].append(c)
+    order, stack = [], [root]
+    while stack:
+        c = stack.pop()
+        order.append(c)
+        stack.extend(children[c])
+    sub = list(weights)
+    for c in reversed(order):
+        if parent[c] >= 0:
+            sub[parent[c]] += sub[c]
+    total = sub[root]
+    best, best_key = root, None
+    for c in range(n):
+        heaviest = max([total - sub[c]] + [sub[k] for k in children[c]])
+        if best_key is None or heaviest < best_key:
+            best, best_key = c, heaviest
+    return best
+
+
+def reroot(parent, root):
+    """The same tree with `root` as its root: parent list with the edges on the path root .. old root turned round."""
+    new = list(parent)
+    prev, c = -1, root
+    while c >= 0:
+        nxt = parent[c]
+        new[c] = prev
+        prev, c = c, nxt
+    return new
+
+
+def partition_tree(parent, weights, n_parts, slack=1.05, replicate_top=False):
+    """`subtree_owners` on the tree re-rooted at its weighted centroid.  Returns (root, parent, owner): the plan must be
+    made with that root (`engine.Plan(..., root=root)`; the replicated top part has to contain the plan's root)."""
+    root = weighted_centroid(parent, weights) if n_parts > 1 else [c for c, p in enumerate(parent) if p < 0][0]
+    new_parent = reroot(parent, root)
+    return root, new_parent, subtree_owners(new_parent, weights, n_parts, slack=slack, replicate_top=replicate_top)
 
 
 def subtree_owners(parent, weights, n_parts, slack=1.05, replicate_top=False):

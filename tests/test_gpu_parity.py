@@ -1135,3 +1135,118 @@ def test_plan_cache_is_bounded_by_device_bytes():
         assert start_free - free_bytes() <= 5 * one + (64 << 20)        # forgotten plans gave their memory back
     finally:
         engine.set_plan_cache_budget(None)
+
+
+def _joint_marginals(factors, sizes, values):
+    names = sorted(sizes)
+    ax = {v: i for i, v in enumerate(names)}
+    ops = []
+    for f, val in zip(factors, values):
+        ops += [np.asarray(val, dtype=np.float64), [ax[v] for v in f]]
+    joint = np.einsum(*ops, list(range(len(names))))
+    return [np.einsum(joint, list(range(len(names))), [ax[v] for v in f]) for f in factors]
+
+
+def test_factor_tables_are_staged_in_one_call_and_only_where_they_changed():
+    """`JunctionTree.propagate` forms the clique potentials with ONE `jtp_set_potential_products` call (round 3: a copy and
+    a launch per clique) and only for cliques whose factor tables differ from what the plan holds - compared by VALUE, so
+    an array updated in place is seen, the same values in new arrays are not staged again."""
+    rng = np.random.default_rng(3)
+    names = list("abcdefgh")
+    sizes = dict(zip(names, (2, 3, 2, 4, 3, 2, 5, 2)))
+    factors = [["a", "b"], ["b", "c"], ["c", "d", "e"], ["e", "f"], ["f", "g"], ["g", "h"], ["a"], ["d"], ["h", "g"]]
+    values = [rng.uniform(0.2, 1.0, [sizes[v] for v in f]) for f in factors]
+    tree = jt.create_junction_tree(factors, sizes)
+    n_cl = len(tree.clique_tree.maxcliques)
+    got = tree.propagate(values)
+    plan = tree.plan("f64")
+    assert plan.staged_cliques == n_cl
+    for g, w in zip(got, _joint_marginals(factors, sizes, values)):
+        close(g, w)
+    tree.propagate([v.copy() for v in values])               # same values, other arrays
+    assert plan.staged_cliques == 0
+    values[3][0, 1] *= 3.0                                    # one table, in place
+    got = tree.propagate(values)
+    assert plan.staged_cliques == 1
+    for g, w in zip(got, _joint_marginals(factors, sizes, values)):
+        close(g, w)
+    mixed = [v.astype(np.float32) if i % 2 else v for i, v in enumerate(values)]      # float32 and float64 tables mixed
+    mixed[6] = np.array([1, 2])                                                       # ... and an integer one
+    values[6] = np.array([1.0, 2.0])
+    got = tree.propagate(mixed)
+    for g, w in zip(got, _joint_marginals(factors, sizes, [np.asarray(m, dtype=np.float64) for m in mixed])):
+        close(g, w, rtol=RTOL64)
+    plan.set_potential(0, np.ones([sizes[v] for v in tree.clique_tree.maxcliques[0]]))    # behind the staging's back:
+    got = tree.propagate(mixed)                                                            # everything is formed again
+    assert plan.staged_cliques == n_cl
+    for g, w in zip(got, _joint_marginals(factors, sizes, [np.asarray(m, dtype=np.float64) for m in mixed])):
+        close(g, w, rtol=RTOL64)
+    with pytest.raises(ValueError):
+        tree.propagate(values[:-1] + [np.ones((3, 3))])      # a table of the wrong shape
+    engine.clear_plan_cache()
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_cliques_of_many_factors_and_of_large_factor_tables(dt):
+    """`jtp_set_potential_products`: a clique that collects more factors than one pass multiplies (JT_EVAL_MAX_F = 8: the rest
+    multiply INTO the table in further launches), factor tables too large for LDS (gathered from the staging buffer) and
+    beyond the compare-by-value limit (handed over on every call), a broadcast axis."""
+    rng = np.random.default_rng(5)
+    names = list("abcdefghijklmnopq")[:17]
+    sizes = {v: 2 for v in names}
+    big = names[:15]                                          # 2^15 entries: 256 KiB as float64 - beyond the 48 KiB of LDS tables
+    factors = [big] + [[a, b] for a, b in zip(big[:-1], big[1:])][:10] + [[names[15], names[0]], [names[16], names[15]]] + [[v] for v in big[:3]]
+    values = [rng.uniform(0.5, 1.5, [sizes[v] for v in f]).astype(dt) for f in factors]
+    tree = jt.create_junction_tree(factors, sizes)
+    members = tree.clique_tree._members()
+    assert max(len(m) for m in members) > 8
+    got = tree.propagate(values)
+    want = _joint_marginals(factors, sizes, values)
+    for g, w in zip(got, want):
+        close(g, w, rtol=RTOL32 if dt == np.float32 else RTOL64)
+    # the same through the plan's own entry, with a length-1 (broadcast) axis and tables above the compare-by-value limit
+    plan = tree.plan("f32" if dt == np.float32 else "f64")
+    c0 = next(c for c, m in enumerate(members) if 0 in m)
+    labels = [factors[i] for i in members[c0]]
+    arrays = [values[i] for i in members[c0]]
+    arrays[1] = arrays[1][:1, :]                               # factor [a, b] given for a = 0 only: broadcast along a
+    plan.set_potential_product(c0, arrays, labels)
+    plan.propagate()
+    vals2 = list(values)
+    vals2[members[c0][1]] = np.broadcast_to(arrays[1], values[members[c0][1]].shape)
+    for f, w in zip(factors, _joint_marginals(factors, sizes, vals2)):
+        mc = tree.clique_tree.factor_to_maxclique[factors.index(f)]
+        close(plan.marginal(mc, f), w, rtol=RTOL32 if dt == np.float32 else RTOL64)
+    from junctiontree_amd import engine as eng
+    old = eng._DIGEST_LIMIT
+    eng._DIGEST_LIMIT = 1 << 12                               # the 2^15-entry table now counts as large: always handed over
+    try:
+        engine.clear_plan_cache()
+        got = tree.propagate(values)
+        assert tree.plan("f32" if dt == np.float32 else "f64").staged_cliques == len(members)
+        got = tree.propagate(values)
+        assert tree.plan("f32" if dt == np.float32 else "f64").staged_cliques == 1          # only the large table's clique
+        for g, w in zip(got, want):
+            close(g, w, rtol=RTOL32 if dt == np.float32 else RTOL64)
+    finally:
+        eng._DIGEST_LIMIT = old
+        engine.clear_plan_cache()
+
+
+def test_junction_trees_of_a_given_elimination_order():
+    """`create_junction_tree(factors, sizes, order=...)`: whatever elimination order builds the tree, the factor marginals are
+    the brute-force ones (a 3 x 4 lattice: min-fill, column by column, row by row, a random order)."""
+    factors, sizes, values = synthetic.lattice_mrf(3, 4, 3, seed=2, dtype=np.float64)
+    want = _joint_marginals(factors, sizes, values)
+    rng = np.random.default_rng(0)
+    orders = [None, synthetic.lattice_column_order(3, 4), list(range(12)), [int(v) for v in rng.permutation(12)], [5, 6]]
+    shapes = set()
+    for order in orders:
+        tree = jt.create_junction_tree(factors, sizes, order=order)
+        shapes.add(tuple(sorted(len(c) for c in tree.clique_tree.maxcliques)))
+        for g, w in zip(tree.propagate(values), want):
+            close(g, w)
+    assert len(shapes) > 1                                    # (the orders really give different trees)
+    with pytest.raises(ValueError):
+        jt.create_junction_tree(factors, sizes, order=[1, 1])
+    engine.clear_plan_cache()

@@ -38,3 +38,26 @@ def test_apply_evidence_case_of_the_reference_test(golden):
     np.testing.assert_array_equal(out[3][0], pots[3])
     np.testing.assert_array_equal(out[4][0], pots[4][0:1])
     np.testing.assert_array_equal(out[6][0], pots[6])
+
+
+def test_elimination_order_gives_valid_junction_trees():
+    """`construction.triangulate(..., order=...)` (round 4): every factor lies in its clique, the tree has the running
+    intersection property, and the column-by-column order on a lattice gives the chain of width-(h+1) cliques of SURVEY.md 8d."""
+    from junctiontree_amd import construction as cons, synthetic
+    from junctiontree_amd.engine import flatten_tree
+    factors, sizes, _ = synthetic.lattice_mrf(4, 9, 2)
+    for order in (None, synthetic.lattice_column_order(4, 9), list(range(36))[::-1], [7, 3]):
+        cliques, f2c = cons.triangulate(factors, sizes, order=order)
+        for f, c in zip(factors, f2c):
+            assert set(f) <= set(cliques[c])
+        tree, seps = cons.construct_junction_tree(cliques, sizes)
+        order_, parent, parent_sep, _ = flatten_tree(tree)
+        assert sorted(order_) == list(range(len(cliques)))
+        for v in sizes:                                   # the cliques holding v form a connected subtree
+            holders = {c for c in range(len(cliques)) if v in cliques[c]}
+            tops = [c for c in holders if parent[c] not in holders]
+            assert len(tops) == 1, (v, tops)
+        for c in order_[1:]:
+            assert set(seps[parent_sep[c] - len(cliques)]) == set(cliques[c]) & set(cliques[parent[c]])
+    cliques, _ = cons.triangulate(factors, sizes, order=synthetic.lattice_column_order(4, 9))
+    assert len(cliques) == 36 - 4 and max(len(c) for c in cliques) == 5

@@ -39,15 +39,21 @@ def _worker(rank, world, port, recipe, kwargs, queue):
         kwargs = dict(kwargs)
         perm_seed = kwargs.pop("renumber", None)
         replicate = kwargs.pop("replicate_top", False)
-        spec = getattr(synthetic, recipe)(**kwargs)
+        spec = getattr(synthetic, recipe)(**{k: v for k, v in kwargs.items() if k != "centroid"})
         if perm_seed is not None:       # arbitrary clique numbering, as construct_junction_tree produces
             spec = synthetic.renumber(spec, np.random.default_rng(perm_seed).permutation(spec["n_cliques"]))
+        centroid = kwargs.pop("centroid", False)
         n = spec["n_cliques"]
         weights = [float(np.prod([spec["sizes"][v] for v in spec["node_vars"][c]])) for c in range(n)]
-        owner = partition.subtree_owners(spec["parent"], weights, world, replicate_top=replicate)
+        root, parent_of = None, spec["parent"]
+        if centroid:        # re-rooted at the weighted centroid: the plan hangs the tree from there
+            root, parent_of, owner = partition.partition_tree(spec["parent"], weights, world, replicate_top=replicate)
+            assert root != 0 and parent_of[root] == -1
+        else:
+            owner = partition.subtree_owners(spec["parent"], weights, world, replicate_top=replicate)
         assert len(set(owner) - {world}) == world and (world in owner) == bool(replicate)
         plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", plan_only=True,
-                           n_ranks=world, rank=rank, owner=owner, block_log2=12)
+                           n_ranks=world, rank=rank, owner=owner, block_log2=12, root=root)
         desc = plan.describe()
         emu = Emulator(desc)
         pots = synthetic.potentials_for(spec, seed=9)
@@ -83,21 +89,22 @@ def _worker(rank, world, port, recipe, kwargs, queue):
                 mine[c] = emu.belief(c, ids, [spec["sizes"][v] for v in spec["node_vars"][c]])
         n_comm = len(desc["comm"])
         gathered = [None] * world
-        dist.gather_object((mine, n_comm, owner), gathered if rank == 0 else None, dst=0)
+        dist.gather_object((mine, n_comm, owner, parent_of), gathered if rank == 0 else None, dst=0)
         if rank == 0:
             import jt_oracle as oracle
             want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
             seen = {}
-            for part, _, _ in gathered:
+            for part, _, _, _ in gathered:
                 seen.update(part)
             assert sorted(seen) == list(range(n))
             for c in range(n):
                 np.testing.assert_allclose(seen[c], want[c], rtol=1e-11, atol=1e-14)
-            cut = [c for c in range(n) if spec["parent"][c] >= 0 and owner[c] != owner[spec["parent"][c]]]
+            par = gathered[0][3]
+            cut = [c for c in range(n) if par[c] >= 0 and owner[c] != owner[par[c]]]
             cuts = len(cut)
             # every cut edge carries one message up and one down, seen once by each side; below a replicated
             # parent the upward message goes to every other rank and the downward one is formed locally
-            assert sum(g[1] for g in gathered) == sum(2 * (world - 1) if owner[spec["parent"][c]] == world else 4 for c in cut)
+            assert sum(g[1] for g in gathered) == sum(2 * (world - 1) if owner[par[c]] == world else 4 for c in cut)
             queue.put(("ok", cuts))
     except Exception as exc:                        # noqa: BLE001
         queue.put(("error rank %d" % rank, repr(exc)))
@@ -116,6 +123,10 @@ def _worker(rank, world, port, recipe, kwargs, queue):
     # (round 3) cardinalities that are not powers of two: mixed-radix rows on both ranks, padded bit-field messages across the cut
     ("wide_binary_tree", {"n_cliques": 15, "width": 7, "sep": 3, "card": 3, "seed": 5}),
     ("random_tree", {"n_cliques": 18, "width": 5, "sep": 2, "card": 5, "seed": 6, "renumber": 2, "replicate_top": True}),
+    # (round 4) a chain given with its END as the root: partitioned after re-rooting at the weighted centroid, the plan hung from there
+    ("chain_tree", {"n_cliques": 21, "card": 6, "width": 3, "centroid": True}),
+    ("chain_tree", {"n_cliques": 24, "card": 5, "width": 3, "centroid": True, "replicate_top": True}),
+    ("random_tree", {"n_cliques": 26, "width": 9, "sep": 4, "card": 2, "seed": 11, "renumber": 4, "centroid": True, "replicate_top": True}),
 ])
 def test_two_rank_exchange_schedule(recipe, kwargs, monkeypatch):
     import multiprocessing as mp
@@ -148,6 +159,25 @@ def test_partition_is_balanced_for_the_benchmark_tree():
         assert max(loads) <= 256 / world * 1.25
         cuts = sum(1 for c in range(1, 256) if owner[c] != owner[spec["parent"][c]])
         assert cuts <= world          # shallow quotient tree: at most one cut per part
+
+
+def test_partition_after_rerooting_at_the_weighted_centroid():
+    """"general trees: re-root at the weighted centroid first".  A chain handed over with its end as the root:
+    from there the first cut leaves the top part holding half the chain; hung from its middle, two ranks get a half each."""
+    from junctiontree_amd import partition, synthetic
+    spec = synthetic.chain_tree(n_cliques=41, card=4, width=3)
+    w = [1.0] * 41
+    assert partition.weighted_centroid(spec["parent"], w) == 20
+    root, par, owner = partition.partition_tree(spec["parent"], w, 2, replicate_top=True)
+    assert root == 20 and par[20] == -1 and par[19] == 20 and par[21] == 20 and par[0] == 1
+    loads = partition.part_weights(owner, w, 2)
+    assert max(loads) <= 22 and owner[20] == 2 and owner[0] != owner[40]
+    # weights count: a heavy end pulls the centroid towards it
+    heavy = [1.0] * 40 + [100.0]
+    assert partition.weighted_centroid(spec["parent"], heavy) == 40
+    # the balanced binary tree of the benchmark is rooted at its centroid already
+    c4 = synthetic.wide_binary_tree(n_cliques=255, width=12, sep=6, card=2, seed=0)
+    assert partition.weighted_centroid(c4["parent"], [1.0] * 255) == 0
 
 
 def _rdzv_worker(rank, world, port, queue):
