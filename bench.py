@@ -43,6 +43,24 @@ sys.path.insert(0, os.path.join(ROOT, "junction-tree_amd"))
 
 Z_DEFAULT_C4 = 1.0058528272803358     # partition function of the default workload (one GPU; numpy oracle agrees to 1e-9)
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md "Chip-level parameters": 8.0 TB/s spec
+# float64 vector pipe: v_fma_f64 measured on this pool with every CU busy (tools/f64_rate.hip, profiles/r02_f64_rate.txt:
+# 5.1 cycles per wave instruction and SIMD = 61.1 TFLOP/s of fused multiply-adds, 30.5 T lane instructions/s; a
+# v_mul_f64 takes the same 5.1 cycles); 78.6 TFLOP/s is the data-sheet figure (4 cycles)
+F64_PEAK_TFLOPS, F64_PEAK_TINSTS, F64_SPEC_TFLOPS = 61.1, 30.5, 78.6
+
+
+def multiset_roofline(stats, ms, alg_bytes):
+    """jt_multi_flow (evidence sets over shared tables): bound by the float64 vector pipe, not by HBM - one pass over a table
+    row serves eight sets, so the arithmetic per byte is eight times a single set's."""
+    tf = stats["f64_flops"] / (ms * 1e-3) / 1e12
+    ti = stats["f64_insts"] / (ms * 1e-3) / 1e12
+    return {"bound": "valu_f64", "kernel": "jt_multi_flow<float>", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
+            "peak_source": "v_fma_f64 measured on this pool (profiles/r02_f64_rate.txt); data sheet %.1f" % F64_SPEC_TFLOPS,
+            "f64_flops_per_step": stats["f64_flops"], "f64_lane_insts_per_step": stats["f64_insts"],
+            "pipe_occupancy": ti / F64_PEAK_TINSTS,
+            "pipe_occupancy_note": "float64 vector instructions (a multiplication holds the pipe as long as a fused multiply-add) / %.1f T lane instructions/s measured" % F64_PEAK_TINSTS,
+            "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps": alg_bytes / (ms * 1e-3) / 1e9, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --batch 64 --multiset)"}}
 TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
 REF_OVER_PORT_FILE = os.path.join("tests", "golden", "ref_over_port.json")
 
@@ -178,6 +196,10 @@ def _sub_result(workload, alg_bytes, messages, wall_ms, dev_ms, steps, parity, *
            "messages_per_sec": messages / (wall_ms * 1e-3), "frac": alg_bytes / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "bound": "hbm", "parity": parity}
     out.update(more)
+    if "roofline" in out:
+        out["bound"] = out["roofline"]["bound"]
+        out["frac"] = out["roofline"]["frac"]
+        out["frac_of_hbm"] = out["roofline"]["hbm"]["frac"]
     return out
 
 
@@ -326,7 +348,7 @@ def sub_c5(device, spec, n_sets=64, steps=10, oracle_sets=1):
                   "Z_rel_err": zerr, "marginal_sums_rel_err": worst, "tolerance": 1e-6, "ok": bool(zerr <= 1e-6 and worst <= 1e-6)}
         return _sub_result("BASELINE.json configs[4], one rank's share: %d evidence sets (16 observed variables each) over the shared tables of the "
                            "width-20 tree, JTP_MULTISET" % n_sets, alg, 2 * (n - 1) * n_sets, wall, dev, steps, parity, dtype="f32",
-                           evidence_sets_per_step=n_sets, ms_per_evidence_set=wall / n_sets,
+                           evidence_sets_per_step=n_sets, ms_per_evidence_set=wall / n_sets, roofline=multiset_roofline(st, dev, alg),
                            engine_table_bytes_per_step=st["algorithmic_bytes"], launches_per_step=st["n_launches"])
     finally:
         plan.close()
@@ -714,6 +736,10 @@ def main():
                                   for kn, kv in stats["kernels"].items()},
                 "collect_ms": stats["collect_ms"], "distribute_ms": stats["distribute_ms"],
             }
+            if args.multiset:
+                hbm_line = {k: out["roofline"][k] for k in ("achieved", "frac", "traffic", "traffic_source")}
+                out["roofline"] = dict(multiset_roofline(stats, step_dev_ms, alg["total"] * args.batch), hbm_engine_bytes=hbm_line,
+                                       collect_ms=stats["collect_ms"], distribute_ms=stats["distribute_ms"])
             if world > 1:
                 out["roofline"]["note_multi_rank"] = ("rank 0's figures; the phase spans of a sharded plan contain its exchange steps "
                                                       "(ncclSend/ncclRecv between the launches)")

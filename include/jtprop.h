@@ -113,7 +113,14 @@ typedef struct jtp_stats {
     double  device_bytes;           /* device memory the plan allocated at creation (arenas, messages, task tables)     */
     int32_t storage_dtype;          /* JTP_F32 / JTP_F64 the clique tables are stored as: a float32 request is made with float64
                                        tables where the float32 layout cannot be planned (sub-boxes beyond the LDS of a CU) */
-    int32_t reserved;
+    int32_t foreign_seen;           /* propagates since plan creation that found ANOTHER PROCESS with a dataflow propagate in flight
+                                       on the device (a shared-memory board, /dev/shm/jtprop_flight_<PCI bus id>) and therefore ran
+                                       in ticket order - counted in tickets_used as well                                    */
+    double  f64_flops;              /* multi-set plans: float64 operations of one propagate (multiplications and additions of the
+                                       element loop, a fused multiply-add counted as two; conversions, index arithmetic, staging and
+                                       epilogues not counted): the kernel jt_multi_flow is bound by them, not by HBM; else 0 */
+    double  f64_insts;              /* ... and the float64 vector instructions (per lane) that stands for: a multiplication
+                                       occupies the pipe as long as a fused multiply-add does                              */
 } jtp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

@@ -2,7 +2,14 @@
 // RCCL point-to-point exchange at subtree cuts, host<->device layout conversion.
 // Plain HIP runtime + RCCL; no PyTorch, no Triton.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <atomic>
@@ -246,6 +253,7 @@ struct jtp_plan {
     bool inflight = false;          // counted in g_inflight: a dataflow propagate of this plan may still be running
     int launch_mode = 0;            // of the last propagate: 0 one launch per level, 1 dataflow in blockIdx order, 2 dataflow, ticket order
     int tickets_used = 0;           // propagates (per evidence set) that ran in ticket order
+    int foreign_seen = 0;           // propagates that found ANOTHER PROCESS with a dataflow propagate in flight on the device
     double device_bytes = 0;        // device memory allocated at plan creation (arenas, message arenas, tables)
     int flow_propagates = 0;        // propagates (per evidence set) that ran as dataflow launches
     uint32_t flow_debug = 0;        // JTP_FLOW_DEBUG at plan creation, or jtp_debug_set(plan, "flow_debug", v)
@@ -302,23 +310,96 @@ struct jtp_plan {
     int esize = 4;
 };
 
+// ... and the same across PROCESSES (round 4): every process using this library on a device keeps its count of in-flight
+// dataflow propagates in a slot of a small shared-memory board, /dev/shm/jtprop_flight_<PCI bus id>; a process that finds
+// another LIVE process's count above zero launches in ticket order, as it does for a second plan of its own.  Round 3 left
+// that case to an environment variable (JTP_FLOW_TICKETS) and to the 2 s time-out with its fall-back to level launches.
+// Processes that do not share /dev/shm (containers) still cannot see each other: for them the time-out stands.
+namespace board {
+struct Slot { std::atomic<int32_t> pid, count; };
+constexpr int SLOTS = 64;
+struct Board { Slot *slots = nullptr; int mine = -1; bool tried = false; };
+static Board g_board[64];
+static std::mutex g_mutex;
+
+static bool alive(int32_t pid) { return pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM); }
+
+static Board &open_board(int device) {
+    Board &b = g_board[device & 63];
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (b.tried) return b;
+    b.tried = true;
+    char bus[64] = "unknown";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return b;
+    for (char *c = bus; *c; ++c)
+        if (*c == ':' || *c == '.') *c = '_';
+    char name[128];
+    snprintf(name, sizeof name, "/jtprop_flight_%s", bus);
+    const mode_t old = umask(0);
+    const int fd = shm_open(name, O_RDWR | O_CREAT, 0666);
+    umask(old);
+    if (fd < 0) return b;
+    if (ftruncate(fd, sizeof(Slot) * SLOTS) != 0) { close(fd); return b; }
+    void *m = mmap(nullptr, sizeof(Slot) * SLOTS, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return b;
+    b.slots = static_cast<Slot *>(m);
+    const int32_t me = (int32_t)getpid();
+    for (int pass = 0; pass < 2 && b.mine < 0; ++pass)
+        for (int i = 0; i < SLOTS && b.mine < 0; ++i) {
+            int32_t owner = b.slots[i].pid.load();
+            if (owner == me) { b.mine = i; break; }                     // (a forked child inherits nothing useful: it has its own pid)
+            if (owner != 0 && (pass == 0 || alive(owner))) continue;    // pass 0: free slots only; pass 1: slots of dead processes too
+            if (b.slots[i].pid.compare_exchange_strong(owner, me)) {
+                b.slots[i].count.store(0);
+                b.mine = i;
+            }
+        }
+    return b;
+}
+
+// this process has `n` dataflow propagates in flight on the device; returns whether another live process has any
+static bool publish(int device, int n) {
+    Board &b = open_board(device);
+    if (!b.slots || b.mine < 0) return false;
+    b.slots[b.mine].count.store(n);
+    bool others = false;
+    for (int i = 0; i < SLOTS; ++i) {
+        if (i == b.mine || b.slots[i].count.load() <= 0) continue;
+        const int32_t owner = b.slots[i].pid.load();
+        if (alive(owner)) others = true;
+        else {                                             // left behind by a process that died in flight
+            b.slots[i].count.store(0);
+            int32_t expect = owner;
+            b.slots[i].pid.compare_exchange_strong(expect, 0);
+        }
+    }
+    return others;
+}
+}  // namespace board
+
 // Dataflow launches in blockIdx order are safe only while no OTHER dataflow kernel can be resident on the device at the
 // same time (jtp_propagate).  A plan enters the count at its first dataflow propagate and leaves it when the host has
 // seen all its streams idle (jtp_sync, a read-out's settle, jtp_plan_destroy).
-static bool enter_flight(jtp_plan *pl) {          // returns whether ANOTHER plan is in flight on the device
+static bool enter_flight(jtp_plan *pl) {          // returns whether ANOTHER plan - of this process or of another - is in flight on the device
     std::atomic<int> &g = g_inflight[pl->hp.device & 63];
+    bool mine = false;
     if (!pl->inflight) {
         pl->inflight = true;
-        return g.fetch_add(1) > 0;
-    }
-    return g.load() > 1;
+        mine = g.fetch_add(1) > 0;
+    } else
+        mine = g.load() > 1;
+    const bool foreign = board::publish(pl->hp.device, g.load());
+    if (foreign) pl->foreign_seen++;
+    return mine || foreign;
 }
 static void leave_flight(jtp_plan *pl) {
     if (!pl->inflight) return;
     for (const auto &b : pl->bufs)
         if (b.unchecked) return;                   // some evidence set's stream has not been waited for yet
     pl->inflight = false;
-    g_inflight[pl->hp.device & 63]--;
+    const int left = --g_inflight[pl->hp.device & 63];
+    (void)board::publish(pl->hp.device, left);
 }
 
 static int ensure_stage(jtp_plan *pl, size_t bytes) {
@@ -410,7 +491,10 @@ void jtp_plan_destroy(jtp_plan *pl) {
     if (pl->device) {
         (void)hipSetDevice(pl->hp.device);
         for (auto s : pl->streams) (void)hipStreamSynchronize(s);
-        if (pl->inflight) g_inflight[pl->hp.device & 63]--, pl->inflight = false;
+        if (pl->inflight) {
+            pl->inflight = false;
+            (void)board::publish(pl->hp.device, --g_inflight[pl->hp.device & 63]);
+        }
         if (pl->multiset) {
             if (!pl->bufs.empty()) {
                 if (pl->bufs[0].psi) (void)hipFree(pl->bufs[0].psi);
@@ -1710,8 +1794,34 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     st->flow_propagates = pl->flow_propagates;
     st->device_bytes = pl->device_bytes;
     st->storage_dtype = hp.dtype;
+    st->foreign_seen = pl->foreign_seen;
     if (pl->multiset) {
         const int groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS;
+        // float64 operations of the element loop of jt_mpass, per thread and table row (VEC elements), G = JT_MSETS sets:
+        //   elements summed first (JtTask::esum == 3): VEC - 1 additions, then per set (n_in - 1) multiplications and one
+        //   fused multiply-add;  no message on the element bits: per set (n_in - 1) multiplications and VEC fused multiply-adds;
+        //   else per set and element n_in multiplications and one fused multiply-add
+        const int VEC = hp.VEC;
+        double flops = 0, insts = 0;
+        for (const Launch &L : hp.launches) {
+            if (L.variant != JT_K_MULTI_COLLECT && L.variant != JT_K_MULTI_DISTRIBUTE) continue;
+            for (int t : L.tasks) {
+                const JtTask &tk = hp.tasks[t];
+                if (tk.kind != 0) continue;
+                bool edep = false;
+                for (int k = 0; k < tk.n_in; ++k) edep = edep || tk.msg[k].e_dep != 0;
+                const double nin1 = std::max(tk.n_in - 1, 0);
+                double per, ins;
+                if (tk.esum == 3 && tk.setb <= JT_SETB_SMALL) per = (VEC - 1) + JT_MSETS * (nin1 + 2.0), ins = (VEC - 1) + JT_MSETS * (nin1 + 1.0);
+                else if (!edep) per = JT_MSETS * (nin1 + 2.0 * VEC), ins = JT_MSETS * (nin1 + VEC);
+                else per = JT_MSETS * VEC * (tk.n_in + 2.0), ins = JT_MSETS * VEC * (tk.n_in + 1.0);
+                const double rows = (double)JT_THREADS * (double)tk.total * (double)(1u << tk.nF);
+                flops += per * rows;
+                insts += ins * rows;
+            }
+        }
+        st->f64_flops = flops * groups;
+        st->f64_insts = insts * groups;
         for (const Launch &L : hp.launches) {
             if (L.variant != JT_K_MULTI_COLLECT && L.variant != JT_K_MULTI_DISTRIBUTE) continue;
             double tb = 0, mb = 0;

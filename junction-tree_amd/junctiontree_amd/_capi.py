@@ -77,7 +77,9 @@ class Stats(C.Structure):
         ("flow_propagates", C.c_int32),
         ("device_bytes", C.c_double),
         ("storage_dtype", C.c_int32),
-        ("reserved", C.c_int32),
+        ("foreign_seen", C.c_int32),
+        ("f64_flops", C.c_double),
+        ("f64_insts", C.c_double),
     ]
 
 

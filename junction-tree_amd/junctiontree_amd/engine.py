@@ -400,7 +400,8 @@ class Plan:
                 "algorithmic_bytes": st.algorithmic_bytes, "collect_ms": st.collect_ms,
                 "distribute_ms": st.distribute_ms, "kernels": kernels, "flow_fallbacks": st.flow_fallbacks,
                 "launch_mode": ("level", "flow", "flow_tickets")[st.launch_mode], "tickets_used": st.tickets_used,
-                "flow_propagates": st.flow_propagates, "device_bytes": st.device_bytes}
+                "flow_propagates": st.flow_propagates, "device_bytes": st.device_bytes, "f64_flops": st.f64_flops, "f64_insts": st.f64_insts,
+                "foreign_seen": st.foreign_seen}
 
 
 _DIGEST_LIMIT = 1 << 20          # bytes: larger factor tables are handed over again on every call rather than compared
