@@ -50,6 +50,7 @@
 // rows whose digits do not exist (digit >= cardinality, padding bit set) read the arena's ZERO ROW (offset 0) and
 // are marked in the tables with JT_NO_ROW.
 #define JT_NO_ROW 0xFFFFFFFFu
+#define JT_BLOCK_KEEP_ROWS 2u  // JtBlock::flags: JtTask::keep_rows
 #define JT_BLOCK_INVALID 1u    // JtBlock::flags: the chunk's own digits do not exist - every row is the zero row (the
                                // workgroup still writes its - all zero - partial copy and padded message entries)
 // Multi-set plans (JTP_MULTISET): evidence sets that share ONE copy of the clique tables are processed
@@ -104,6 +105,10 @@ struct JtTask {
                                // task (planner), bit 1 = no evidence set observes a variable on them (engine, updated by
                                // jtp_set_evidence).  Both set: the four elements are summed BEFORE they meet the message
                                // product - one fused multiply-add per evidence set and row instead of four.
+    int32_t keep_rows;         // 1: the table rows are loaded with the default cache policy instead of non-temporal - this pass
+                               // and the next over the same table are close enough in time for the second to find the rows in
+                               // the Infinity Cache (the top of a tree: read last by collect, first by distribute; a plan whose
+                               // tables fit the cache altogether).  Copied into JtBlock::flags (JT_BLOCK_KEEP_ROWS).
     uint32_t out_run;          // byte j: log2 of the iterations over which outgoing message j's sums stay in registers
                                // (the leading loop-counter bits that message j does not contain: the nR bits no
                                // outgoing message contains, then A bits of other messages only); message j's epilogue

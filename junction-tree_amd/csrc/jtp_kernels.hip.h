@@ -276,6 +276,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // zero row; their belief stores go to the row behind it (jtp_internal.h).  The whole chunk may be such.
     const T *zero_row = psi_arena + (uint32_t)tid * VEC;
     const bool chunk_ok = !(bk.flags & JT_BLOCK_INVALID);
+    const bool keep_rows = (bk.flags & JT_BLOCK_KEEP_ROWS) != 0;     // (uniform) default cache policy for the table rows, see JtTask::keep_rows
     const uint32_t ring_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + (uint32_t)wave * (U * 1024);
     const char *ring = smem + wave * (U * 1024) + lane * 16;
     // The workgroup's iteration table (<= 64 rows of JT_NCOL ints, host built) lives in registers,
@@ -312,7 +313,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024));
+                jt_dma16(bk.first_x[u] == JT_NO_ROW ? zero_row : psi0 + bk.first_x[u], __builtin_amdgcn_readfirstlane(ring_lds + u * 1024), keep_rows);
         }
         const int r = lane < total ? lane : total - 1;
         const int4 a = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL);
@@ -668,7 +669,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             const int inext = (i + U < total) ? i + U : total - 1;
             const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
             jt_dma16((xnext == JT_NO_ROW || !chunk_ok) ? zero_row : psi + (xF + xnext),
-                     __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
+                     __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024), keep_rows);
         }
         }
         const int li = i;

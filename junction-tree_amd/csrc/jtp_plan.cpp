@@ -593,6 +593,7 @@ JtBlock jtp_make_block(const HostPlan &hp, const JtTask &tk, uint32_t task_index
     for (int i = 0; i < 8; ++i) b.first_x[i] = tk.first_x[i];
     // a chunk whose own digits do not exist (a compact variable's digit beyond its cardinality, a padding bit set)
     // has no rows: the workgroup runs on the zero row and writes its all-zero partial copy (jtp_internal.h)
+    if (tk.kind == 0 && tk.keep_rows) b.flags |= JT_BLOCK_KEEP_ROWS;
     if (tk.kind == 0 && !high_digits_exist(hp.pn[tk.pnode], b.lxF, fmask)) {
         b.flags |= JT_BLOCK_INVALID;
         b.xF = 0;
@@ -634,6 +635,7 @@ PlanKnobs jtp_read_knobs() {
     k.lane_low = geti("JTP_LANE_LOW", 2);
     k.longest_first = geti("JTP_LONGEST_FIRST", 1);
     k.top_share = getd("JTP_TOP_SHARE", 0.12);
+    k.keep_rows_mb = getd("JTP_KEEP_ROWS_MB", 128.0);
     k.marg_group = std::max(1, std::min(geti("JTP_MARG_GROUP", JT_MAX_OUT), JT_MAX_OUT));
     k.marg_block_log2 = geti("JTP_MARG_BLOCK_LOG2", 0);
     return k;
@@ -1727,6 +1729,25 @@ int PlanBuilder::messages() {
 }
 
 int PlanBuilder::schedule() {
+    // Which passes load their table rows with the default cache policy (JtTask::keep_rows; everything else non-temporal).
+    // The levels nearest the root are read LAST by collect and FIRST by distribute: while the tables of levels 0..d (this
+    // rank's) stay below knobs.keep_rows_mb, both passes over them keep their rows in the 256 MiB Infinity Cache and the
+    // second finds them there instead of in HBM.  A plan whose tables fit altogether keeps every row (a rank's share of
+    // config 4 at 8 ranks: 152 MiB).
+    if (!hp.multiset && hp.knobs.keep_rows_mb > 0) {
+        std::vector<double> level_bytes(maxdepth + 1, 0.0);
+        for (int c = 0; c < NP; ++c)
+            if (mine(c)) level_bytes[hp.pn[c].depth] += (double)hp.pn[c].phys_elems * esize;
+        double cum = 0;
+        int keep_depth = -1;
+        for (int d = 0; d <= maxdepth; ++d) {
+            cum += level_bytes[d];
+            if (cum > hp.knobs.keep_rows_mb * 1048576.0) break;
+            keep_depth = d;
+        }
+        for (JtTask &tk : hp.tasks)
+            if (tk.kind == 0 && hp.pn[tk.pnode].depth <= keep_depth) tk.keep_rows = 1;
+    }
     // ---- launches, blocks, exchange schedule -----------------------------------------------------
     hp.alg_bytes = 0;
     hp.max_lds = 0;
@@ -2241,7 +2262,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             if (t) o << ",";
             o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
-              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"tmap_off\":" << tk.tmap_off << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
+              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"keep_rows\":" << tk.keep_rows << ",\"tmap_off\":" << tk.tmap_off << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
             json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";
