@@ -298,6 +298,7 @@ struct jtp_plan {
     uint32_t *host_abort = nullptr; // pinned: set by a workgroup that gave up waiting
     int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
     bool fake_comm = false;         // JTP_FAKE_COMM
+    bool esum_dirty = false;        // multi-set plans: JtTask::esum_groups changed on the host since the last upload
     bool psi_dirty = false;         // shared potentials were written (on stream 0) since the last propagate
     std::vector<MargBatch *> marg_cache;
     // factor tables and records on their way to jt_eval_batch: slices of one buffer handed out in turn, so that
@@ -701,7 +702,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     if (pl->multiset) {
         pl->ev_host.assign((size_t)pl->ev_stride * pl->n_groups * JT_MSETS, 0u);
         for (JtTask &tk : hp.tasks)
-            if (tk.esum & 1) tk.esum |= 2;                     // no evidence yet
+            if (tk.esum & 1) tk.esum |= 2, tk.esum_groups = ~0ull;      // no evidence yet
     }
     if (!hp.tasks.empty()) {
         CREATE_TRY(hipMalloc((void **)&pl->d_tasks, hp.tasks.size() * sizeof(JtTask)));
@@ -1169,21 +1170,27 @@ int jtp_set_evidence(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *var_
     if (!b.ev) HIP_TRY(hipMalloc((void **)&b.ev, ev.size() * sizeof(uint32_t)));      // (multi-set plans: a slice of ev_all)
     HIP_TRY(hipMemcpy(b.ev, ev.data(), ev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (pl->multiset) {
-        // a task may sum the elements of a vector before the message product only while NO evidence set observes a
-        // variable on its clique's element bits (JtTask::esum bit 1)
+        // a group of evidence sets may sum the elements of a vector before the message product on a clique while none of ITS
+        // sets observes a variable on that clique's element bits (JtTask::esum_groups; bit b stands for the groups g = b mod 64)
         std::copy(ev.begin(), ev.end(), pl->ev_host.begin() + (size_t)batch * pl->ev_stride);
         const uint32_t emask = (1u << hp.EB) - 1u;
+        const int bit = (batch / JT_MSETS) & 63;
         std::vector<char> on_e(hp.pn.size(), 0);
-        for (size_t sidx = 0; sidx < pl->ev_host.size() / pl->ev_stride; ++sidx)
+        const size_t nsets = pl->ev_host.size() / pl->ev_stride;
+        for (size_t sidx = 0; sidx < nsets; ++sidx) {
+            if ((int)((sidx / JT_MSETS) & 63) != bit) continue;
             for (size_t p = 0; p < hp.pn.size(); ++p)
                 if (pl->ev_host[sidx * pl->ev_stride + 2 * p] & emask) on_e[p] = 1;
+        }
+        const bool always = hp.knobs.esum_always != 0;             // (timing experiment: wrong results)
         for (size_t t = 0; t < hp.tasks.size(); ++t) {
             JtTask &tk = hp.tasks[t];
             if (tk.kind != 0 || !(tk.esum & 1)) continue;
-            const int32_t want = 1 | (on_e[tk.pnode] ? 0 : 2);
-            if (want != tk.esum) {
-                tk.esum = want;
-                HIP_TRY(hipMemcpy(&pl->d_tasks[t].esum, &want, sizeof want, hipMemcpyHostToDevice));
+            const uint64_t want = (on_e[tk.pnode] && !always) ? tk.esum_groups & ~(1ull << bit) : tk.esum_groups | (1ull << bit);
+            if (want != tk.esum_groups) {
+                tk.esum_groups = want;
+                tk.esum = 1 | (want == ~0ull ? 2 : 0);
+                pl->esum_dirty = true;                               // uploaded in one copy by the next jtp_propagate
             }
         }
     }
@@ -1234,6 +1241,16 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         fl.set_stride = pl->set_stride;
         fl.ev_stride = pl->ev_stride;
         fl.sync_stride = (uint32_t)hp.sync_words;
+        if (pl->esum_dirty) {
+            // which groups may sum a vector's elements first on which task (jtp_set_evidence): the fields of ALL tasks in one
+            // strided copy, ordered before the launches below on the plan's stream
+            HIP_TRY(hipMemcpy2DAsync(&pl->d_tasks[0].esum_groups, sizeof(JtTask), &hp.tasks[0].esum_groups, sizeof(JtTask), sizeof(uint64_t),
+                                     hp.tasks.size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpy2DAsync(&pl->d_tasks[0].esum, sizeof(JtTask), &hp.tasks[0].esum, sizeof(JtTask), sizeof(int32_t),
+                                     hp.tasks.size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));                    // (the source is the plan's own task table: pageable)
+            pl->esum_dirty = false;
+        }
         const bool flow = pl->flow;
         if (flow) {
             b0.flow_runs++;
@@ -1811,17 +1828,20 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
                 bool edep = false;
                 for (int k = 0; k < tk.n_in; ++k) edep = edep || tk.msg[k].e_dep != 0;
                 const double nin1 = std::max(tk.n_in - 1, 0);
-                double per, ins;
-                if (tk.esum == 3 && tk.setb <= JT_SETB_SMALL) per = (VEC - 1) + JT_MSETS * (nin1 + 2.0), ins = (VEC - 1) + JT_MSETS * (nin1 + 1.0);
-                else if (!edep) per = JT_MSETS * (nin1 + 2.0 * VEC), ins = JT_MSETS * (nin1 + VEC);
-                else per = JT_MSETS * VEC * (tk.n_in + 2.0), ins = JT_MSETS * VEC * (tk.n_in + 1.0);
                 const double rows = (double)JT_THREADS * (double)tk.total * (double)(1u << tk.nF);
-                flops += per * rows;
-                insts += ins * rows;
+                for (int g = 0; g < groups; ++g) {
+                    double per, ins;
+                    if ((tk.esum & 1) && ((tk.esum_groups >> (g & 63)) & 1ull) && tk.setb <= JT_SETB_SMALL)
+                        per = (VEC - 1) + JT_MSETS * (nin1 + 2.0), ins = (VEC - 1) + JT_MSETS * (nin1 + 1.0);
+                    else if (!edep) per = JT_MSETS * (nin1 + 2.0 * VEC), ins = JT_MSETS * (nin1 + VEC);
+                    else per = JT_MSETS * VEC * (tk.n_in + 2.0), ins = JT_MSETS * VEC * (tk.n_in + 1.0);
+                    flops += per * rows;
+                    insts += ins * rows;
+                }
             }
         }
-        st->f64_flops = flops * groups;
-        st->f64_insts = insts * groups;
+        st->f64_flops = flops;
+        st->f64_insts = insts;
         for (const Launch &L : hp.launches) {
             if (L.variant != JT_K_MULTI_COLLECT && L.variant != JT_K_MULTI_DISTRIBUTE) continue;
             double tb = 0, mb = 0;

@@ -102,9 +102,13 @@ struct JtTask {
     int32_t settle;            // dataflow launches: 1 = from the second staging attempt on, a thread re-loads an entry it
                                // finds unwritten itself (plans made of latency-bound levels: chains), see jt_msg_settle
     int32_t esum;              // multi-set plans: bit 0 = the element bits of the 16-byte vector are in NO message of this
-                               // task (planner), bit 1 = no evidence set observes a variable on them (engine, updated by
-                               // jtp_set_evidence).  Both set: the four elements are summed BEFORE they meet the message
-                               // product - one fused multiply-add per evidence set and row instead of four.
+                               // task (planner), bit 1 = no evidence set of ANY group observes a variable on them (engine, updated by
+                               // jtp_set_evidence; per group: esum_groups).  Where both hold for a group, the four elements are summed
+                               // BEFORE they meet the message product - one fused multiply-add per evidence set and row instead of four.
+    uint64_t esum_groups;      // multi-set plans: bit (g mod 64) set = no evidence set of group g (nor of any other group sharing the
+                               // bit) observes a variable on the element bits of this task's clique: that group sums the four
+                               // elements first (round 3 kept ONE flag per task - esum bit 1 - for all groups: with 64 sets of
+                               // 16 observations more than half of the tasks lost it for everybody).  Engine, jtp_set_evidence.
     int32_t keep_rows;         // 1: the table rows are loaded with the default cache policy instead of non-temporal - this pass
                                // and the next over the same table are close enough in time for the second to find the rows in
                                // the Infinity Cache (the top of a tree: read last by collect, first by distribute; a plan whose

@@ -1668,7 +1668,7 @@ __global__ __launch_bounds__(JT_THREADS, JT_MULTI_WAVES) void jt_multi_flow(cons
         jt_reduce<true, true>(tk, bk, msg0, fl);
         return;
     }
-    if (tk.setb <= JT_SETB_SMALL && tk.esum == 3) {
+    if (tk.setb <= JT_SETB_SMALL && (tk.esum & 1) && ((tk.esum_groups >> (grp & 63u)) & 1ull)) {
         switch (tk.n_in) {
             case 0: jt_mpass<T, 0, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
             case 1: jt_mpass<T, 1, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;

@@ -636,6 +636,7 @@ PlanKnobs jtp_read_knobs() {
     k.longest_first = geti("JTP_LONGEST_FIRST", 1);
     k.top_share = getd("JTP_TOP_SHARE", 0.12);
     k.keep_rows_mb = getd("JTP_KEEP_ROWS_MB", 128.0);
+    k.esum_always = geti("JTP_EXPERIMENT_ESUM_ALWAYS", 0);
     k.marg_group = std::max(1, std::min(geti("JTP_MARG_GROUP", JT_MAX_OUT), JT_MAX_OUT));
     k.marg_block_log2 = geti("JTP_MARG_BLOCK_LOG2", 0);
     return k;

@@ -125,6 +125,7 @@ struct PlanKnobs {
     int no_tmix = 0;                                                // JTP_NO_TMIX: thread parts stay padded bit fields (round-2 layout)
     int no_tsplit = 0;                                              // JTP_NO_TSPLIT: no variable across bit TB in a clique with mixed-radix rows (the first form of round 3)
     double tmix_fill = 0.6;                                         // JTP_TMIX_FILL: mixed-radix rows for cliques whose bit-field thread part would be emptier than this
+    int esum_always = 0;                                            // JTP_EXPERIMENT_ESUM_ALWAYS: multi-set tasks keep summing a vector's elements first whatever the evidence (timing experiment, wrong results)
     double keep_rows_mb = 128.0;                                      // JTP_KEEP_ROWS_MB: table rows of the levels nearest the root, up to this many MiB, are loaded with the default cache policy (0: all non-temporal; A/B on one box: config 4 0.6037 -> 0.5990 ms, an 8-rank share of it 198.5 -> 195.4 us)
     int marg_group = JT_MAX_OUT;                                    // JTP_MARG_GROUP: marginals of one belief table formed by one pass over it (1: a pass each, round 3)
     int marg_block_log2 = 0;                                        // JTP_MARG_BLOCK_LOG2: log2 of the elements per workgroup of a marginal pass (0: the 64 rows a workgroup can hold)

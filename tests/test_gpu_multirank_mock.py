@@ -179,3 +179,20 @@ def test_bench_rank_failure_is_an_error():
     assert res.returncode != 0
     assert not any(ln.startswith("{") for ln in res.stdout.decode().splitlines())
     assert b"exited with code" in res.stderr
+
+
+@pytest.mark.gpu
+def test_bench_with_more_ranks_than_devices_says_so():
+    """`python bench.py --gpus 2` on a box with ONE device and real RCCL (no stand-in transport): one clear line - how many
+    devices the run needs and how many were found - and a non-zero exit, before RCCL is asked to put two ranks on one GPU
+    (round 3: ncclCommInitRank's "invalid usage")."""
+    from junctiontree_amd import _capi
+    if _capi.device_count() != 1:
+        pytest.skip("needs a box with exactly one visible device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "JTP_RCCL_LIB")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-sample", "0",
+                          "--spawn-timeout", "120"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = res.stderr.decode()
+    assert res.returncode != 0, err[-1000:]
+    assert "2 ranks need 2 devices, found 1" in err, err[-1000:]
+    assert not any(ln.startswith("{") for ln in res.stdout.decode().splitlines())
