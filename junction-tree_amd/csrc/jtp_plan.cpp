@@ -323,6 +323,18 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
             // (16 rows: 0.601 -> 0.631 ms, 216 us; 32 rows: 0.665 ms)
             e.min_loop_log2 = std::max(e.min_loop_log2, std::min(hp.knobs.top_min_loop, nbits - TB));
             e.max_iter_log2 = std::max(e.max_iter_log2, e.min_loop_log2);
+            // ... and levels of at most 2048 rows in all (one or two cliques of config 4): exactly FOUR rows, the depth of the
+            // element ring - every row of such a workgroup is in flight while it waits for its messages, where rows 5-8 of
+            // an eight-row workgroup are only asked for once the loop runs (2.2-3.0 us of every hand-over at the top of a tree,
+            // profiles/r03_stage_times_rank0_of_8.txt "more steps"), and one or two such levels still leave room for the next
+            // (at most 512 workgroups).  A/B on one box: a rank's share of config 4 at 8 ranks 198.7 -> 189.3 us, config 4
+            // 0.5981 -> 0.5948 ms; two rows: 210 us.  Larger levels of few cliques (config 3: 64 MiB tables) keep their long workgroups:
+            // held to four rows they took 19.7 instead of 11.7 ms.
+            const double lvl_rows = (double)p.phys_elems / std::max(share, 1e-9) / (double)(1 << TB);
+            if (hp.knobs.top_rows2 > 0 && lvl_rows <= hp.knobs.top_rows2 && nbits - TB >= hp.knobs.top_loop2) {
+                e.min_loop_log2 = std::max(hp.knobs.top_loop2, JT_MIN_LOOP_LOG2);
+                e.max_iter_log2 = std::max(hp.knobs.top_loop2, JT_MIN_LOOP_LOG2);
+            }
         }
         if (hp.lds_budget > 0) e.lds_cap = JT_RING_BYTES + hp.lds_budget + JT_STAGE_SCRATCH * (long)ins.size();
         uint32_t seen = 0;
@@ -635,6 +647,8 @@ PlanKnobs jtp_read_knobs() {
     k.lane_low = geti("JTP_LANE_LOW", 2);
     k.longest_first = geti("JTP_LONGEST_FIRST", 1);
     k.top_share = getd("JTP_TOP_SHARE", 0.12);
+    k.top_rows2 = getd("JTP_TOP_ROWS2", 2048.0);
+    k.top_loop2 = geti("JTP_TOP_LOOP2", 2);
     k.keep_rows_mb = getd("JTP_KEEP_ROWS_MB", 128.0);
     k.esum_always = geti("JTP_EXPERIMENT_ESUM_ALWAYS", 0);
     k.marg_group = std::max(1, std::min(geti("JTP_MARG_GROUP", JT_MAX_OUT), JT_MAX_OUT));

@@ -120,6 +120,8 @@ struct PlanKnobs {
     int longest_first = 1;                                          // JTP_LONGEST_FIRST: within a level, tasks with the longest workgroups go first in the block list
     int lane_low = 2;                                               // JTP_LANE_LOW: a sub-box's index bits that are lane bits come first (0 = message order, 1 = incoming sub-boxes only, 2 = all)
     int top_min_loop = 3;                                           // JTP_TOP_MIN_LOOP: log2 of the fewest rows per workgroup on levels of a few cliques (searched splits)
+    int top_loop2 = 2;                                              // JTP_TOP_LOOP2: log2 of the rows per workgroup there
+    double top_rows2 = 2048.0;                                      // JTP_TOP_ROWS2: ... and exactly 2^top_loop2 rows (the ring's depth) on levels of at most this many rows in all (0: off)
     double top_share = 0.12;                                        // JTP_TOP_SHARE: ... a clique holding at least this share of its level's elements
     double settle_level_elems = 8388608.0;                          // JTP_SETTLE_LEVEL_ELEMS: tasks on levels of at most this many table elements settle in place
     int no_tmix = 0;                                                // JTP_NO_TMIX: thread parts stay padded bit fields (round-2 layout)
