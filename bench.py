@@ -461,7 +461,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="size of the CPU baseline's sample: cliques of the tree (c4: default 256 = the full workload, ~4-25 s "
-                         "on one core; c2: default 100 of the 1000 cliques) or lattice columns (c3: default 60); 0 = skip")
+                         "on one core; c2: default 100 of the 1000 cliques) or lattice columns (c3: default 60); 0 = skip (and skip the sub-results "
+                         "for the other configs: measurement tools run the headline workload alone)")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the CPU port on every host core at once (independent evidence sets, SURVEY.md 8d)")
     ap.add_argument("--no-profile", action="store_true", help="no hipEvent pairs in the timed region")
@@ -795,7 +796,7 @@ def main():
                              "calibration_rel_err": worst, "tolerance": 5e-6,
                              "ok": bool(np.max(np.abs(sums - z)) <= 5e-6 * z and worst < 5e-6)}
             out["config"]["junction_tree_build_s"] = lattice["t_build"]
-        run_subs = (default_c4 and world == 1 and args.batch == 1 and not args.no_configs and not args.level_launches
+        run_subs = (default_c4 and world == 1 and args.batch == 1 and not args.no_configs and args.cpu_sample != 0 and not args.level_launches
                     and not args.split_variants and not args.per_launch and args.idle_plans == 0
                     and args.block_log2 == 0 and args.lds_budget == 0 and args.layout_policy == 0)
         if run_subs:

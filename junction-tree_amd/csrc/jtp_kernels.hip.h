@@ -172,7 +172,7 @@ __device__ __forceinline__ uint32_t jt_sub_hi(const uint32_t (&fp)[4], int nfree
     return g;
 }
 
-template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false>
+template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false, bool KEEP = false>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
                                         double *__restrict__ msg_arena, const JtFlow &fl,
@@ -276,7 +276,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // zero row; their belief stores go to the row behind it (jtp_internal.h).  The whole chunk may be such.
     const T *zero_row = psi_arena + (uint32_t)tid * VEC;
     const bool chunk_ok = !(bk.flags & JT_BLOCK_INVALID);
-    const bool keep_rows = (bk.flags & JT_BLOCK_KEEP_ROWS) != 0;     // (uniform) default cache policy for the table rows, see JtTask::keep_rows
+    // (uniform) default cache policy for the first table rows, see JtTask::keep_rows.  KEEP: only the kernel that runs both phases
+    // in one launch looks at the flag (jt_propagate_flow: the plans with a top that both passes visit close together in time) -
+    // the uniform branch around the two forms of the load cost config 2's chain kernels 1.5 % for nothing
+    const bool keep_rows = KEEP && (bk.flags & JT_BLOCK_KEEP_ROWS) != 0;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + (uint32_t)wave * (U * 1024);
     const char *ring = smem + wave * (U * 1024) + lane * 16;
     // The workgroup's iteration table (<= 64 rows of JT_NCOL ints, host built) lives in registers,
@@ -668,8 +671,11 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int inext = (i + U < total) ? i + U : total - 1;
             const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
+            // (always non-temporal here: JtTask::keep_rows is honoured by the FIRST loads only - a choice of cache policy in
+            //  this loop, a uniform branch around two forms of the load, cost config 2 3.5 % whichever way it went; the workgroups
+            //  of the levels nearest the root have four rows - all of them first loads)
             jt_dma16((xnext == JT_NO_ROW || !chunk_ok) ? zero_row : psi + (xF + xnext),
-                     __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024), keep_rows);
+                     __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
         }
         }
         const int li = i;
@@ -1131,22 +1137,22 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_propagate_flow(const JtTask 
     }
     if (tk.mode == 0) {
         switch (tk.n_in) {
-            case 0: jt_pass<T, 0, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-            case 1: jt_pass<T, 1, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-            case 2: jt_pass<T, 2, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-            default: jt_pass<T, 3, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+            case 0: jt_pass<T, 0, 1, 0, true, true, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+            case 1: jt_pass<T, 1, 1, 0, true, true, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+            case 2: jt_pass<T, 2, 1, 0, true, true, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+            default: jt_pass<T, 3, 1, 0, true, true, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
         }
         return;
     }
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
-        case 0: jt_pass<T, 0, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 1: jt_pass<T, 1, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 2: jt_pass<T, 2, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 3: jt_pass<T, 3, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 4: jt_pass<T, 1, 0, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 5: jt_pass<T, 2, 1, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        case 6: jt_pass<T, 3, 2, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
-        default: jt_pass<T, 4, 3, 1, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 0: jt_pass<T, 0, 0, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 1: jt_pass<T, 1, 1, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 2, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 3: jt_pass<T, 3, 3, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 4: jt_pass<T, 1, 0, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 5: jt_pass<T, 2, 1, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        case 6: jt_pass<T, 3, 2, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
+        default: jt_pass<T, 4, 3, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
     }
 }
 
