@@ -68,14 +68,24 @@ note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over
         "over all launches of the kernel (one launch per phase)")
 traffic = all_traffic.get("single", {})
 json.dump({"source_id": source_id, "git_head_at_build": git_head, "note": note, "kernels": traffic}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-json.dump({"source_id": source_id, "git_head_at_build": git_head, "note": note + "; cases: single = the default bench (one evidence set); share16 = 16 sets, one copy of the tables, "
-           "one pass per set (round 1); multiset16/64 = 16/64 sets, one pass per group of eight sets; c2 / c3 = bench.py --config c2 / c3", "cases": all_traffic},
+json.dump({"source_id": source_id, "git_head_at_build": git_head, "note": note + "; cases: single = the default bench (one evidence set); multiset64 = 64 sets, one pass per group of eight sets; "
+           "c2 / c3 = bench.py --config c2 / c3", "cases": all_traffic},
           open(os.path.join(dst, "hbm_traffic_cases.json"), "w"), indent=1)
 valu = defaultdict(list)
 for r in rows("valu_*/**/*counter_collection.csv"):
     if "jt_" in r.get("Kernel_Name", ""):
         valu[r["Kernel_Name"].split("(")[0] + " " + r["Counter_Name"]].append(float(r["Counter_Value"]))
-json.dump(dict({k: sum(v) / len(v) for k, v in valu.items()}, source_id=source_id), open(os.path.join(dst, "valu_multiset16.json"), "w"), indent=1)
+json.dump(dict({k: sum(v) / len(v) for k, v in valu.items()}, source_id=source_id,
+               note="rocprofv3 --pmc passes (a few counters each) over bench.py --steps 3 --warmup 1 --batch 64 --multiset; means over the kernel's launches"),
+          open(os.path.join(dst, "counters_multiset64.json"), "w"), indent=1)
+# kernel stats of the whole API call on config 3 (tools/run_c3.py under rocprofv3 --kernel-trace --stats)
+stats3 = [r for r in rows("kt_c3api/**/*kernel_stats.csv") if "jt_" in r.get("Name", "")]
+if stats3:
+    with open(os.path.join(dst, "c3_api_kernel_stats.csv"), "w", newline="") as fh:
+        fh.write("# library build: %s git %s (rocprofv3 --kernel-trace --stats -- python3 tools/run_c3.py)\n" % (source_id, git_head))
+        w = csv.DictWriter(fh, fieldnames=list(stats3[0].keys()))
+        w.writeheader()
+        w.writerows(stats3)
 json.dump(dict(trace, source_id=source_id), open(os.path.join(dst, "kernel_trace_summary.json"), "w"), indent=1)
 print(json.dumps(trace, indent=1))
 print(json.dumps(all_traffic, indent=1))
