@@ -61,7 +61,7 @@ def multiset_roofline(stats, ms, alg_bytes):
             "pipe_occupancy_note": "float64 vector instructions (a multiplication holds the pipe as long as a fused multiply-add) / %.1f T lane instructions/s measured" % F64_PEAK_TINSTS,
             "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps": alg_bytes / (ms * 1e-3) / 1e9, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --batch 64 --multiset)"}}
-TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
 REF_OVER_PORT_FILE = os.path.join("tests", "golden", "ref_over_port.json")
 
 
@@ -560,8 +560,7 @@ def main():
         node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in tree.separators]
         plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", device=device, block_log2=args.block_log2,
                            lds_budget=args.lds_budget, layout_policy=args.layout_policy, level_launches=args.level_launches)
-        for c, members in enumerate(ct._members()):
-            plan.set_potential_product(c, jt.take(values, members), jt.take(factors, members))
+        plan.stage_factors(factors, ct.factor_to_maxclique, values)      # evaluate: every clique in one call, one launch
         plan.sync()
         n = len(ct.maxcliques)
         tables = sum(int(np.prod([sizes[v] for v in c])) for c in ct.maxcliques) * 4

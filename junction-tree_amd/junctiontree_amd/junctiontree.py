@@ -143,16 +143,28 @@ class JunctionTree:
     separators: Any
     clique_tree: Any
     _opts: dict = field(default_factory=dict, compare=False, repr=False)
+    _memo: dict = field(default_factory=dict, compare=False, repr=False)
 
     def plan(self, dtype="f64"):
         """The device plan for the current variable sizes (sizes are read at call time, as
         `junctiontree.py:311` does: the reference's tests condition on evidence by setting
         a size to 1, `tests/test_junctiontree.py:393-411`)."""
+        import weakref
         from . import engine
 
+        # the plan cache's key names the whole structure (1-2 ms to build for a thousand cliques): a tree remembers the key
+        # and a weak reference to the plan it was last given for (dtype, the sizes as they are NOW, its options)
+        sizes = self.clique_tree.factor_graph.sizes
+        mark = (dtype, tuple(sizes.items()), tuple(sorted(self._opts.items())))
+        hit = self._memo.get("plan")
+        if hit is not None and hit[0] == mark:
+            plan = engine.cached_plan(hit[1], hit[2]())
+            if plan is not None:
+                return plan
         node_vars = [list(c) for c in self.clique_tree.maxcliques] + [list(s) for s in self.separators]
-        return engine.plan_for(self.tree, node_vars, self.clique_tree.factor_graph.sizes, dtype,
-                               **self._opts)
+        plan, key = engine.plan_for(self.tree, node_vars, sizes, dtype, return_key=True, **self._opts)
+        self._memo["plan"] = (mark, key, weakref.ref(plan))
+        return plan
 
     def propagate(self, xs):
         """Belief propagation: factor values in, unnormalised factor marginals out (same
