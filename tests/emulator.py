@@ -149,7 +149,7 @@ class Emulator:
 
         chunk_ok = exists(lxF, fmask)
         if record is not None:      # the host-decoded workgroup record must agree with the bit decode
-            assert record[20] == lxF and record[21] == (0 if chunk_ok else 1)
+            assert record[20] == lxF and (record[21] & 1) == (0 if chunk_ok else 1)       # (bit 1: JT_BLOCK_KEEP_ROWS, a cache-policy hint)
             if chunk_ok:
                 assert record[0] == xF and record[11] == tk["psi_off"] + xF
                 assert list(record[12:20]) == list(tk["first_x"])
