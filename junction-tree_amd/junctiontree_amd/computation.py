@@ -67,8 +67,10 @@ def compute_beliefs(tree, potentials, clique_vars, dl=sum_product):
     # The reference's own call form - `compute_beliefs(tree, potentials, clique_vars, SumProduct(numpy.einsum))`,
     # `tests/test_computation.py:46-48` - names exactly the law the device implements, so it is accepted and runs on
     # the GPU like the default; any OTHER callable could be a different semiring and is refused (no host path here).
+    # (`optimize=...`, the one switch the reference's source mentions - `SumProduct(np.einsum, optimize=True)`, commented out at
+    #  `computation.py:4-9` - chooses numpy's contraction order, not the law: accepted and ignored)
     plain_numpy = (type(dl).__name__ == "SumProduct" and getattr(dl, "func", None) is np.einsum
-                   and not getattr(dl, "args", ()) and not getattr(dl, "kwargs", {}))
+                   and not getattr(dl, "args", ()) and set(getattr(dl, "kwargs", {})) <= {"optimize"})
     if not isinstance(dl, HipSumProduct) and not plain_numpy:
         raise TypeError(
             "this build runs the sum-product law on the GPU only; pass "

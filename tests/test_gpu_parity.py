@@ -331,6 +331,12 @@ def test_the_reference_call_form_with_numpy_einsum_runs_on_the_device():
     want = oracle.beliefs_exact(tree, pots, node_vars)
     for g, w in zip(got, want):
         close(g, w, rtol=RTOL64)
+    # the one switch the reference's source mentions (`SumProduct(np.einsum, optimize=True)`, computation.py:4-9): numpy's
+    # contraction order, not another law - accepted; a dtype or an out argument would change what is computed - refused
+    for g, w in zip(comp.compute_beliefs(tree, pots, node_vars, SumProduct(np.einsum, optimize=True)), want):
+        close(g, w, rtol=RTOL64)
+    with pytest.raises(TypeError):
+        comp.compute_beliefs(tree, pots, node_vars, SumProduct(np.einsum, dtype=np.float32))
 
 
 @pytest.mark.parametrize("nv,card,dt", [(7, 3, np.float64), (5, 5, np.float64), (6, 5, np.float32), (8, 3, np.float64), (6, 6, np.float32),
