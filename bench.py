@@ -354,6 +354,38 @@ def sub_c5(device, spec, n_sets=64, steps=10, oracle_sets=1):
         plan.close()
 
 
+def sub_rank_share(device, spec, world=8, steps=30):
+    """What one GPU can say about the 8-GPU run of configs[3] (no 8-GPU node has been available to the driver): every rank's share
+    of the partitioned tree timed ALONE on this GPU, the exchange at the cuts replaced by fills of the receive buffers
+    (JTP_FAKE_COMM).  A projection aid - the slowest share bounds the sharded step from below, the RCCL exchange comes on top -
+    not a multi-GPU measurement; `value` of a real `--gpus 8` run is what counts."""
+    from junctiontree_amd import engine, partition
+    n = spec["n_cliques"]
+    root, _, owner = partition.partition_tree(spec["parent"], [1.0] * n, world, replicate_top=True)
+    old = os.environ.get("JTP_FAKE_COMM")
+    os.environ["JTP_FAKE_COMM"] = "1"
+    per_rank = []
+    try:
+        for rank in range(world):
+            plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", device=device, n_ranks=world, rank=rank,
+                               owner=owner, root=root)
+            try:
+                plan.fill_synthetic(1, spec["scales"])
+                wall, dev = _timed(plan, steps)
+                per_rank.append(dev * 1e3)
+            finally:
+                plan.close()
+    finally:
+        if old is None:
+            os.environ.pop("JTP_FAKE_COMM", None)
+        else:
+            os.environ["JTP_FAKE_COMM"] = old
+    return {"workload": "BASELINE.json configs[3] cut for %d ranks (top part replicated): each rank's share run alone on ONE GPU, exchanges "
+                        "replaced by fills (JTP_FAKE_COMM) - a projection aid, not a multi-GPU measurement" % world,
+            "device_us_per_rank_share": per_rank, "slowest_share_us": max(per_rank), "steps": steps,
+            "cliques_per_rank": [sum(1 for o in owner if o in (r, world)) for r in range(world)]}
+
+
 def sub_configs(device, spec_c4):
     """Run the sub-configs one after the other; a failure is recorded in its place, never raised (the headline line stands)."""
     out = {}
@@ -377,7 +409,8 @@ def sub_configs(device, spec_c4):
 
     secs = {"c2": guard("c2", lambda: sub_c2(device)),
             "c3": guard(("c3", "c3_api_end_to_end"), lambda: sub_c3(device)),
-            "c5_multiset64": guard("c5_multiset64", lambda: sub_c5(device, spec_c4))}
+            "c5_multiset64": guard("c5_multiset64", lambda: sub_c5(device, spec_c4)),
+            "c4_rank_share_of_8": guard("c4_rank_share_of_8", lambda: sub_rank_share(device, spec_c4))}
     out["wall_s"] = dict(secs, total=time.perf_counter() - t_all)
     return out
 

@@ -25,6 +25,12 @@ for rank in range(world):
     for _ in range(3):
         plan.propagate(sync=False)
     plan.sync()
+    # (a) the steps between ONE event pair (what bench.py's `c4_rank_share_of_8` reports); (b) with the three phase events per
+    #     propagate that split collect from distribute (2-3 us of idle GPU each: the per-propagate figure of rounds 1-3)
+    plan.region_begin()
+    for _ in range(steps):
+        plan.propagate(sync=False)
+    region_us = plan.region_end() / steps * 1e3
     plan.set_profiling(steps)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -33,7 +39,7 @@ for rank in range(world):
     dt = (time.perf_counter() - t0) / steps
     st = plan.stats()
     d = plan.describe()
-    print("rank %d: %3d cliques  %2d launches  %d exchange groups  %.1f us/propagate (collect %.1f, distribute %.1f)  share %.0f MB" % (
+    print("rank %d: %3d cliques  %2d launches  %d exchange groups  %.1f us/propagate (collect %.1f, distribute %.1f)  share %.0f MB  | between one event pair: %.1f us/propagate" % (
         rank, sum(1 for o in owner if o in (rank, world)), st["n_launches"], sum(1 for k, _, _ in d["flow_steps"] if k == 1),
-        dt * 1e6, st["collect_ms"] * 1e3, st["distribute_ms"] * 1e3, st["algorithmic_bytes"] / 1e6))
+        dt * 1e6, st["collect_ms"] * 1e3, st["distribute_ms"] * 1e3, st["algorithmic_bytes"] / 1e6, region_us))
     plan.close()
