@@ -591,8 +591,10 @@ def main():
         t_build = time.perf_counter() - t0
         ct = tree.clique_tree
         node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in tree.separators]
+        # (cover: which variables of each clique its factors cover - the others are never materialised, junctiontree.py:52-61)
         plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", device=device, block_log2=args.block_log2,
-                           lds_budget=args.lds_budget, layout_policy=args.layout_policy, level_launches=args.level_launches)
+                           lds_budget=args.lds_budget, layout_policy=args.layout_policy, level_launches=args.level_launches,
+                           cover=None if os.environ.get("JTP_BENCH_NO_COVER") else tree.cover())
         plan.stage_factors(factors, ct.factor_to_maxclique, values)      # evaluate: every clique in one call, one launch
         plan.sync()
         n = len(ct.maxcliques)

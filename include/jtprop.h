@@ -91,6 +91,16 @@ typedef struct jtp_tree_desc {
                                        its messages), 1 = host axis order, 2 = variables of the fewest messages
                                        lowest (least message traffic), 3 = message variables in the thread part
                                        (cheapest reduction)                                   */
+    /* Which variables of each clique its potential DEPENDS on (NULL: all of them).  The reference leaves every
+     * variable of a clique that none of its assigned factors covers as a length-1 axis and never materialises it
+     * (junctiontree/junctiontree.py:52-61, evaluate :203-226).  A clique that lists only some of its variables here
+     * keeps NO full-size table on the device: its potential is stored at the covered shape and broadcast inside the
+     * passes, its belief is formed on demand (jtp_get_belief / jtp_get_marginals), a clique that lists none is all
+     * ones and stores nothing.  jtp_set_potential / jtp_set_potential_product(s) of such a clique take arrays whose
+     * axes of the other variables have length 1.  (The engine may still materialise a clique whose covered part is
+     * most of it; jtp_plan_describe says which.)  Ignored by JTP_MULTISET plans. */
+    const int32_t *cover_off;       /* [n_cliques+1] CSR offsets into cover_ids, or NULL          */
+    const int32_t *cover_ids;       /* covered variable ids of each clique (a subset of its own)  */
 } jtp_tree_desc;
 
 /* Counters of the last jtp_propagate (device time needs jtp_set_profiling(plan, 1)). */
@@ -121,6 +131,13 @@ typedef struct jtp_stats {
                                        epilogues not counted): the kernel jt_multi_flow is bound by them, not by HBM; else 0 */
     double  f64_insts;              /* ... and the float64 vector instructions (per lane) that stands for: a multiplication
                                        occupies the pipe as long as a fused multiply-add does                              */
+    double  algorithmic_bytes_full; /* algorithmic bytes with EVERY clique counted at its full shape, read in both passes and its
+                                       belief written (SURVEY.md 8d to the letter).  `algorithmic_bytes` counts a clique that keeps
+                                       no table (jtp_tree_desc.cover_*) as what its potential is: the table over the covered
+                                       variables, read once per pass, no belief                                            */
+    double  fixed_bytes;            /* bytes of the static tables of such cliques (per evidence set, or shared)            */
+    int32_t n_unit_cliques;         /* cliques of the caller's tree that keep no table on the device                       */
+    int32_t n_static_tables;        /* ... of which hold factors: their product is a static table over the covered variables */
 } jtp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

@@ -191,6 +191,7 @@ struct BatchBuffers {
     void *psi = nullptr;
     void *bel = nullptr;
     double *msg = nullptr;
+    double *fix = nullptr;          // fixed arena: the static tables of unit cliques (HostPlan::statics; shared like psi)
     uint32_t *ev = nullptr;         // hard evidence: (mask, value) per planner node, or null (jtp_set_evidence)
     uint32_t *sync = nullptr;       // dataflow launches: abort flag and ticket counters
     uint32_t epoch = 0;             // propagates enqueued so far; its parity selects the message arena half
@@ -200,6 +201,8 @@ struct BatchBuffers {
                                     // plans come and go)
     bool unchecked = false;         // a dataflow propagate was enqueued and its abort flag not looked at yet
     int64_t cur_off(int64_t half) const { return (epoch & 1u) ? half : 0; }     // half in use by the last propagate
+    // JtFlow::fix_shift of a launch that reads this propagate's half: fixed arena - (message arena + cur_off), in doubles
+    int64_t fix_shift(int64_t cur) const { return fix ? (int64_t)(((intptr_t)fix - (intptr_t)msg) / 8) - cur : 0; }
 };
 
 // device tables of one list of marginal requests (jtp_get_marginals), kept for the next call
@@ -211,6 +214,9 @@ struct MargBatch {
     JtMargDesc *d_descs = nullptr;
     double *scratch = nullptr, *stage = nullptr;
     int n = 0, nblocks = 0, lds = 0, max_grid_x = 1;
+    // requests on UNIT cliques (no belief table): psi x every incoming table marginalised directly (kernel jt_single); their
+    // workgroup records follow the others' in d_blocks
+    int unit_nblocks = 0, unit_lds = 0;
     int64_t total_out = 0;
     std::vector<int64_t> elems;          // host entries of each request
     void release() {
@@ -306,6 +312,7 @@ struct jtp_plan {
     char *eval_stage = nullptr;          // device
     char *eval_host = nullptr;           // pinned mirror: the caller's tables are copied here before the call returns
     size_t eval_bytes = 0, eval_cursor = 0;
+    void *unit_scratch = nullptr;        // scratch arena in which the belief of a unit clique is formed on demand (jtp_get_belief)
     hipStream_t eval_stream = nullptr;   // stream whose kernels may still read the buffer
     bool eval_pending = false;
     int esize = 4;
@@ -504,20 +511,21 @@ void jtp_plan_destroy(jtp_plan *pl) {
             if (pl->msg_all) (void)hipFree(pl->msg_all);
             if (pl->ev_all) (void)hipFree(pl->ev_all);
             if (pl->sync_all) (void)hipFree(pl->sync_all);
-            for (auto &bt : pl->belief_tasks) {
-                if (bt.d_task) (void)hipFree(bt.d_task);
-                if (bt.d_blk) (void)hipFree(bt.d_blk);
-                if (bt.d_tab) (void)hipFree(bt.d_tab);
-            }
         } else
         for (auto &b : pl->bufs) {
             if (b.psi && (&b == &pl->bufs[0] || b.psi != pl->bufs[0].psi)) (void)hipFree(b.psi);
             if (b.bel) (void)hipFree(b.bel);
             if (b.msg) (void)hipFree(b.msg);
+            if (b.fix && (&b == &pl->bufs[0] || b.fix != pl->bufs[0].fix)) (void)hipFree(b.fix);
             if (b.ev) (void)hipFree(b.ev);
             if (b.sync) (void)hipFree(b.sync);
         }
         if (pl->host_abort) (void)hipHostFree(pl->host_abort);
+        for (auto &bt : pl->belief_tasks) {
+            if (bt.d_task) (void)hipFree(bt.d_task);
+            if (bt.d_blk) (void)hipFree(bt.d_blk);
+            if (bt.d_tab) (void)hipFree(bt.d_tab);
+        }
         for (MargBatch *mb : pl->marg_cache) {
             mb->release();
             delete mb;
@@ -532,6 +540,7 @@ void jtp_plan_destroy(jtp_plan *pl) {
         }
         if (pl->eval_stage) (void)hipFree(pl->eval_stage);
         if (pl->eval_host) (void)hipHostFree(pl->eval_host);
+        if (pl->unit_scratch) (void)hipFree(pl->unit_scratch);
         for (auto e : pl->ev) (void)hipEventDestroy(e);
         for (auto e : pl->region_ev)
             if (e) (void)hipEventDestroy(e);
@@ -587,6 +596,17 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             if (rc2 == JTP_OK) rc = rc2, pl->widened = true;
             else if (rc2 != JTP_EUNSUPPORTED) rc = rc2, err = err2;
         }
+    }
+    //  - a clique that keeps no table stages the product of its factors like one more message: where that does not fit (or the
+    //    tighter layout rules of such cliques cannot be met) the tree is planned with every table materialised, as rounds 1-4 did
+    if (rc == JTP_EUNSUPPORTED && desc && desc->cover_off && !(desc->flags & JTP_MULTISET)) {
+        jtp_tree_desc again = *desc;
+        again.cover_off = again.cover_ids = nullptr;
+        jtp_plan *fresh = nullptr;
+        const int rc2 = jtp_plan_create(&again, &fresh);
+        delete pl;
+        if (rc2 == JTP_OK) *out = fresh;
+        return rc2;
     }
     if (rc != JTP_OK) {
         delete pl;
@@ -680,6 +700,13 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         else CREATE_TRY(hipMalloc(&b.psi, abytes));
         CREATE_TRY(hipMalloc(&b.bel, abytes));
         CREATE_TRY(hipMalloc((void **)&b.msg, mbytes));
+        if (hp.fix_doubles > 0) {
+            if (share_psi && &b != &pl->bufs[0]) b.fix = pl->bufs[0].fix;
+            else {
+                CREATE_TRY(hipMalloc((void **)&b.fix, (size_t)hp.fix_doubles * 8));
+                CREATE_TRY(hipMemsetAsync(b.fix, 0, (size_t)hp.fix_doubles * 8, pl->streams[0]));
+            }
+        }
         CREATE_TRY(hipMemsetAsync(b.psi, 0, abytes, pl->streams[0]));
         CREATE_TRY(hipMemsetAsync(b.bel, 0, abytes, pl->streams[0]));
         CREATE_TRY(hipMemsetD32Async((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), mbytes / 4, pl->streams[0]));
@@ -737,7 +764,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             b = 2.0 * abytes + (double)mbytes * nsets + (double)pl->ev_stride * 4 * nsets + (double)hp.sync_words * 4 * pl->n_groups;
         } else {
             const size_t npsi = share_psi ? 1 : pl->bufs.size();
-            b = (double)abytes * (npsi + pl->bufs.size()) + ((double)mbytes + (double)hp.sync_words * 4) * pl->bufs.size();
+            b = (double)abytes * (npsi + pl->bufs.size()) + ((double)mbytes + (double)hp.sync_words * 4) * pl->bufs.size() + (double)hp.fix_doubles * 8 * npsi;
         }
         b += (double)hp.tasks.size() * sizeof(JtTask) + (double)hp.blocks.size() * sizeof(JtBlock) + (double)hp.itab.size() * 4;
         pl->device_bytes = b;
@@ -781,12 +808,27 @@ int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *hos
     if (node < 0 || node >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", node);
     if (!(hp.pn[node].owner == hp.rank || hp.pn[node].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", node, hp.pn[node].owner);
     if (host_dtype != JTP_F32 && host_dtype != JTP_F64) return set_err(JTP_EINVAL, "bad host dtype");
-    JtPackDesc d = hp.pack[node];
+    // a unit clique (jtp_tree_desc.cover_*) keeps its potential as a static table over the covered variables: the other axes
+    // of the host array must have length 1, as the reference's evaluate leaves them (junctiontree.py:52-61)
+    const bool unit = hp.pn[node].unit;
+    if (unit && hp.pn[node].stat < 0) {
+        bool one = true;
+        for (size_t i = 0; i < hp.node_vars[node].size(); ++i) one = one && (!shape || shape[i] == 1 || hp.card[hp.node_vars[node][i]] == 1);
+        if (!shape) for (int v : hp.node_vars[node]) one = one && hp.card[v] == 1;
+        const double v = !host ? 0.0 : (host_dtype == JTP_F32 ? (double)*(const float *)host : *(const double *)host);
+        if (!one || v != 1.0)
+            return set_err(JTP_EINVAL, "clique %d was described as depending on none of its variables (jtp_tree_desc.cover_*): its potential is 1", node);
+        return JTP_OK;
+    }
+    JtPackDesc d = unit ? hp.stat_pack[node] : hp.pack[node];
     int64_t stride = 1;
     for (int i = d.nvars - 1; i >= 0; --i) {
         const int64_t len = shape ? shape[i] : d.card[i];
-        if (len != d.card[i] && len != 1)
+        if (len != d.card[i] && len != 1) {
+            if (unit && len == hp.card[hp.node_vars[node][i]])
+                return set_err(JTP_EINVAL, "clique %d axis %d has length %lld, but the clique was described as not depending on that variable (jtp_tree_desc.cover_*)", node, i, (long long)len);
             return set_err(JTP_EINVAL, "clique %d axis %d has length %lld, expected %d or 1", node, i, (long long)len, d.card[i]);
+        }
         d.hstride[i] = (len == 1) ? 0 : stride;
         stride *= len;
     }
@@ -811,7 +853,10 @@ int jtp_set_potential(jtp_plan *pl, int32_t batch, int32_t node, const void *hos
     //  memory - jtp_host_alloc - it is asynchronous and the caller must keep the array alive until jtp_sync)
     HIP_TRY(hipMemcpyAsync(stage, host, hbytes, hipMemcpyHostToDevice, s));
     BatchBuffers &b = pl->bufs[batch];
-    if (hp.dtype == JTP_F32) {
+    if (unit) {
+        if (host_dtype == JTP_F32) launch_pack<double, float>(d, (const float *)stage, b.fix, s);
+        else launch_pack<double, double>(d, (const double *)stage, b.fix, s);
+    } else if (hp.dtype == JTP_F32) {
         if (host_dtype == JTP_F32) launch_pack<float, float>(d, (const float *)stage, (float *)b.psi, s);
         else launch_pack<float, double>(d, (const double *)stage, (float *)b.psi, s);
     } else {
@@ -864,8 +909,15 @@ int jtp_set_potential_products(jtp_plan *pl, int32_t batch, int32_t n, const int
                 if (!found) return set_err(JTP_EINVAL, "factor %d: variable %d is not in clique %d", fi, v, clique);
                 const int64_t len = ft.shape ? ft.shape[j] : hp.card[v];
                 if (len != hp.card[v] && len != 1) return set_err(JTP_EINVAL, "factor %d axis %d has length %lld, expected %d or 1", fi, j, (long long)len, hp.card[v]);
+                if (hp.pn[clique].unit && len != 1) {
+                    bool covered = false;
+                    for (int cv : hp.pn[clique].cover) covered = covered || cv == v;
+                    if (!covered) return set_err(JTP_EINVAL, "factor %d: clique %d was described as not depending on variable %d (jtp_tree_desc.cover_*)", fi, clique, v);
+                }
                 ne *= len;
             }
+            if (hp.pn[clique].unit && hp.pn[clique].stat < 0)
+                return set_err(JTP_EINVAL, "clique %d was described as depending on none of its variables (jtp_tree_desc.cover_*): it takes no factor", clique);
             elems[f - f0] = ne;
             offs[f - f0] = (int64_t)(tbytes / 8);
             tbytes += (size_t)((ne * (ft.dtype == JTP_F32 ? 4 : 8) + 7) / 8) * 8;
@@ -876,7 +928,9 @@ int jtp_set_potential_products(jtp_plan *pl, int32_t batch, int32_t n, const int
     hipStream_t s = pl->streams[batch % pl->streams.size()];
     BatchBuffers &b = pl->bufs[batch];
     // the kernel's records: per pass the clique records, then the workgroup prefix sums
-    std::vector<std::vector<JtEvalTask>> tasks((size_t)npass);
+    // (lists [0, npass): cliques that keep a table, formed in the potential arena in its storage type; [npass, 2 npass): static
+    //  tables of unit cliques, plain bit fields of doubles in the fixed arena)
+    std::vector<std::vector<JtEvalTask>> tasks((size_t)npass * 2);
     std::vector<JtEvalVar> fvars;
     int lds_doubles = 0;
     for (int i = 0; i < n; ++i) {
@@ -885,10 +939,12 @@ int jtp_set_potential_products(jtp_plan *pl, int32_t batch, int32_t n, const int
         const PNode &p = hp.pn[clique];
         const int nfc = factor_off[i + 1] - factor_off[i];
         int done = 0, pass = 0;
+        if (p.unit && p.stat < 0) continue;                 // all ones, nothing stored
         do {
             JtEvalTask tk;
             memset(&tk, 0, sizeof tk);
-            tk.clique = hp.pack[clique];
+            tk.clique = p.unit ? hp.stat_pack[clique] : hp.pack[clique];
+            if (p.unit) tk.clique.low_bits = std::min(tk.clique.nbits, 9);      // (rows of at most 512 doubles: a 16-byte vector per thread)
             tk.accumulate = done > 0;
             tk.nf = std::min(nfc - done, JT_EVAL_MAX_F);
             tk.row_len = tk.clique.row_elems > 0 ? tk.clique.row_elems : 1 << tk.clique.low_bits;
@@ -929,15 +985,16 @@ int jtp_set_potential_products(jtp_plan *pl, int32_t batch, int32_t n, const int
                 }
             }
             lds_doubles = std::max(lds_doubles, used);
-            tasks[pass].push_back(tk);
+            tasks[(p.unit ? npass : 0) + pass].push_back(tk);
             done += tk.nf;
             ++pass;
         } while (done < nfc);
         (void)p;
     }
-    std::vector<size_t> task_at((size_t)npass), blk_at((size_t)npass);
+    const int nlists = 2 * npass;
+    std::vector<size_t> task_at((size_t)nlists), blk_at((size_t)nlists);
     size_t bytes = 0;
-    for (int k = 0; k < npass; ++k) {
+    for (int k = 0; k < nlists; ++k) {
         task_at[k] = bytes;
         bytes += (tasks[k].size() * sizeof(JtEvalTask) + 255) & ~(size_t)255;
         blk_at[k] = bytes;
@@ -975,8 +1032,8 @@ int jtp_set_potential_products(jtp_plan *pl, int32_t batch, int32_t n, const int
     for (int f = 0; f < nfact; ++f)
         memcpy(hstage + tables_at + offs[f] * 8, factors[f0 + f].host, (size_t)elems[f] * (factors[f0 + f].dtype == JTP_F32 ? 4 : 8));
     if (!fvars.empty()) memcpy(hstage + fvars_at, fvars.data(), fvars.size() * sizeof(JtEvalVar));
-    std::vector<int> grid((size_t)npass, 0);
-    for (int k = 0; k < npass; ++k) {
+    std::vector<int> grid((size_t)nlists, 0);
+    for (int k = 0; k < nlists; ++k) {
         memcpy(hstage + task_at[k], tasks[k].data(), tasks[k].size() * sizeof(JtEvalTask));
         int32_t *bs = reinterpret_cast<int32_t *>(hstage + blk_at[k]);
         int64_t at = 0;
@@ -990,12 +1047,13 @@ int jtp_set_potential_products(jtp_plan *pl, int32_t batch, int32_t n, const int
     }
     HIP_TRY(hipMemcpyAsync(stage, hstage, bytes, hipMemcpyHostToDevice, s));
     const int lds = lds_doubles * 8;
-    for (int k = 0; k < npass; ++k) {
+    for (int k = 0; k < nlists; ++k) {
         if (grid[k] == 0) continue;
         const JtEvalTask *dt = reinterpret_cast<const JtEvalTask *>(stage + task_at[k]);
         const int32_t *bs = reinterpret_cast<const int32_t *>(stage + blk_at[k]);
         const JtEvalVar *fvp = reinterpret_cast<const JtEvalVar *>(stage + fvars_at);
-        if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_batch<float>), dim3(grid[k]), dim3(256), lds, s, dt, bs, (int)tasks[k].size(), fvp, (const char *)(stage + tables_at), (float *)b.psi);
+        if (k >= npass) hipLaunchKernelGGL((jt_eval_batch<double>), dim3(grid[k]), dim3(256), lds, s, dt, bs, (int)tasks[k].size(), fvp, (const char *)(stage + tables_at), b.fix);
+        else if (hp.dtype == JTP_F32) hipLaunchKernelGGL((jt_eval_batch<float>), dim3(grid[k]), dim3(256), lds, s, dt, bs, (int)tasks[k].size(), fvp, (const char *)(stage + tables_at), (float *)b.psi);
         else hipLaunchKernelGGL((jt_eval_batch<double>), dim3(grid[k]), dim3(256), lds, s, dt, bs, (int)tasks[k].size(), fvp, (const char *)(stage + tables_at), (double *)b.psi);
     }
     HIP_TRY(hipGetLastError());
@@ -1027,12 +1085,15 @@ int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double 
     BatchBuffers &b = pl->bufs[batch];
     for (int c = 0; c < hp.n_cliques; ++c) {
         if (!(hp.pn[c].owner == hp.rank || hp.pn[c].owner == hp.n_ranks)) continue;
-        const JtPackDesc &d = hp.pack[c];
+        if (hp.pn[c].unit && hp.pn[c].stat < 0) continue;          // all ones, nothing stored
+        const JtPackDesc &d = hp.pn[c].unit ? hp.stat_pack[c] : hp.pack[c];
         const uint64_t key = host_splitmix64(seed * 0x100000001B3ull + (uint64_t)c);
         const double sc = scale ? scale[c] : 1.0;
         const int64_t n = d.phys_elems;
         const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
-        if (hp.dtype == JTP_F32)
+        if (hp.pn[c].unit)       // (the static table: the same counter-based values over the covered shape)
+            hipLaunchKernelGGL((jt_pack<double, double, 1>), dim3(grid), dim3(256), 0, s, d, (const double *)nullptr, b.fix, key, sc);
+        else if (hp.dtype == JTP_F32)
             hipLaunchKernelGGL((jt_pack<float, float, 1>), dim3(grid), dim3(256), 0, s, d, (const float *)nullptr, (float *)b.psi, key, sc);
         else
             hipLaunchKernelGGL((jt_pack<double, double, 1>), dim3(grid), dim3(256), 0, s, d, (const double *)nullptr, (double *)b.psi, key, sc);
@@ -1335,6 +1396,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         fl.oth_off = pl->flow ? half - fl.cur_off : -1;
         fl.dbg = pl->flow_debug;
         fl.ev = bb.ev;
+        fl.fix_shift = bb.fix_shift(fl.cur_off);
         if (flow) {
             bb.flow_runs++;
             bb.unchecked = true;
@@ -1438,9 +1500,20 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
         const JtPackDesc &d = hp.pack[node];
         rc = ensure_stage(pl, (size_t)d.host_elems * hsz);
         if (rc) return rc;
-        if (pl->multiset) {
+        const bool unit = hp.pn[node].unit;
+        void *bel_src = b.bel;
+        if (unit) {
+            // a unit clique keeps no belief table either: formed now, into a scratch arena laid out as its table would be
+            if (!pl->unit_scratch) {
+                HIP_TRY(hipMalloc(&pl->unit_scratch, (size_t)hp.scratch_elems * pl->esize));
+                HIP_TRY(hipMemsetAsync(pl->unit_scratch, 0, (size_t)hp.scratch_elems * pl->esize, s));
+            }
+            bel_src = pl->unit_scratch;
+        }
+        if (pl->multiset || unit) {
             // no belief tables are kept: form this clique's belief for this evidence set now, from the shared
             // table and the set's final messages (computation.py:216-224), into the scratch arena
+            if (pl->belief_tasks.size() < hp.pn.size()) pl->belief_tasks.resize(hp.pn.size());
             jtp_plan::BeliefTask &bt = pl->belief_tasks[node];
             if (!bt.d_task) {
                 JtTask tk;
@@ -1463,17 +1536,18 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
             one.cur_off = b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));
             one.oth_off = -1;
             one.ev = b.ev;
+            one.fix_shift = b.fix_shift(one.cur_off);
             HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE, hp.tmix) : (const void *)KernelTable<double>::get(JT_K_SINGLE, hp.tmix), bt.lds));
-            launch_variant(pl, JT_K_SINGLE, bt.nblocks, bt.lds, s, bt.d_task, bt.d_blk, bt.d_tab, b.psi, b.bel, b.msg, one);
+            launch_variant(pl, JT_K_SINGLE, bt.nblocks, bt.lds, s, bt.d_task, bt.d_blk, bt.d_tab, b.psi, bel_src, b.msg, one);
             HIP_TRY(hipGetLastError());
         }
         const int grid = (int)std::min<int64_t>((d.host_elems + 255) / 256, 4096);
         if (hp.dtype == JTP_F32) {
-            if (host_dtype == JTP_F32) hipLaunchKernelGGL((jt_unpack<float, float>), dim3(grid), dim3(256), 0, s, d, (const float *)b.bel, (float *)pl->stage);
-            else hipLaunchKernelGGL((jt_unpack<float, double>), dim3(grid), dim3(256), 0, s, d, (const float *)b.bel, (double *)pl->stage);
+            if (host_dtype == JTP_F32) hipLaunchKernelGGL((jt_unpack<float, float>), dim3(grid), dim3(256), 0, s, d, (const float *)bel_src, (float *)pl->stage);
+            else hipLaunchKernelGGL((jt_unpack<float, double>), dim3(grid), dim3(256), 0, s, d, (const float *)bel_src, (double *)pl->stage);
         } else {
-            if (host_dtype == JTP_F32) hipLaunchKernelGGL((jt_unpack<double, float>), dim3(grid), dim3(256), 0, s, d, (const double *)b.bel, (float *)pl->stage);
-            else hipLaunchKernelGGL((jt_unpack<double, double>), dim3(grid), dim3(256), 0, s, d, (const double *)b.bel, (double *)pl->stage);
+            if (host_dtype == JTP_F32) hipLaunchKernelGGL((jt_unpack<double, float>), dim3(grid), dim3(256), 0, s, d, (const double *)bel_src, (float *)pl->stage);
+            else hipLaunchKernelGGL((jt_unpack<double, double>), dim3(grid), dim3(256), 0, s, d, (const double *)bel_src, (double *)pl->stage);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)d.host_elems * hsz, hipMemcpyDeviceToHost, s));
@@ -1572,12 +1646,12 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         }
     if (!mb) {
         std::vector<JtTask> tasks;
-        std::vector<JtBlock> blocks;
+        std::vector<JtBlock> blocks, ublocks;              // passes over belief tables; passes of cliques that keep none
         std::vector<int32_t> itab;
         std::vector<JtMargDesc> descs((size_t)n);
         std::vector<int64_t> elems((size_t)n);
         int64_t scratch_doubles = 0, total_out = 0;
-        int lds = 0;
+        int lds = 0, ulds = 0;
         // Requests on ONE clique share passes over its belief table, JT_MAX_OUT of them per pass (a pairwise model asks a
         // clique for two or three factor marginals: round 3 read the table once per request - config 3: 1831 reads of 878
         // tables, 2.1 x the bytes).  Multi-set plans marginalise psi x messages directly and keep one request per task.
@@ -1589,6 +1663,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
                 if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "request %d: node %d is not a clique", i, clique);
                 if (!(hp.pn[clique].owner == hp.rank || hp.pn[clique].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
                 auto it = open.find(clique);
+                // (multi-set plans: one request per pass; unit cliques of single-set plans share passes like everybody else)
                 if (pl->multiset || it == open.end() || (int)groups[it->second].size() >= hp.knobs.marg_group) {
                     open[clique] = (int)groups.size();
                     groups.push_back(std::vector<int>());
@@ -1615,16 +1690,18 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
             std::vector<JtBlock> blk;
             std::vector<int32_t> tab;
             std::string err;
-            rc = jtp_plan_marginal_task(hp, clique, ovs, tk, tab, out_bits, npart, blk, err, pl->multiset);
+            const bool direct = pl->multiset || hp.pn[clique].unit;     // psi x incoming tables marginalised directly
+            rc = jtp_plan_marginal_task(hp, clique, ovs, tk, tab, out_bits, npart, blk, err, direct);
             if (rc) return set_err(rc, "request %d: %s", grp[0], err.c_str());
             tk.itab_off = (int64_t)itab.size();
             if (tk.tmap_off >= 0) tk.tmap_off += tk.itab_off;      // (the clique's thread map travels behind the task's rows)
             itab.insert(itab.end(), tab.begin(), tab.end());
             for (JtBlock &bk : blk) {
                 bk.task = (uint32_t)tasks.size();
-                blocks.push_back(bk);
+                (direct ? ublocks : blocks).push_back(bk);
             }
-            lds = std::max(lds, tk.lds_bytes);
+            if (direct) ulds = std::max(ulds, tk.lds_bytes);
+            else lds = std::max(lds, tk.lds_bytes);
             for (size_t j = 0; j < grp.size(); ++j) {
                 const int i = grp[j];
                 const std::vector<int> &ov = ovs[j];
@@ -1668,6 +1745,9 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         mb->n = n;
         mb->nblocks = (int)blocks.size();
         mb->lds = lds;
+        mb->unit_nblocks = (int)ublocks.size();
+        mb->unit_lds = ulds;
+        blocks.insert(blocks.end(), ublocks.begin(), ublocks.end());
         mb->total_out = total_out;
         mb->elems = elems;
         int64_t biggest = 1;
@@ -1695,23 +1775,27 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         }
         pl->marg_cache.push_back(mb);
     }
-    {   // the kernel that is actually launched below must be allowed this much dynamic LDS
-        const int v = pl->multiset ? JT_K_SINGLE : JT_K_MARGINALS;
-        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v, hp.tmix) : (const void *)KernelTable<double>::get(v, hp.tmix), mb->lds));
-    }
-    // marginalise the BELIEF tables: each is the "potential" argument of a childless collect
+    // the kernels that are actually launched below must be allowed this much dynamic LDS
+    if (mb->nblocks > 0)
+        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_MARGINALS, hp.tmix) : (const void *)KernelTable<double>::get(JT_K_MARGINALS, hp.tmix), mb->lds));
+    if (mb->unit_nblocks > 0)
+        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE, hp.tmix) : (const void *)KernelTable<double>::get(JT_K_SINGLE, hp.tmix), mb->unit_lds));
     JtFlow plain;
     memset(&plain, 0, sizeof plain);
     plain.oth_off = -1;
-    if (pl->multiset) {
-        // psi * (the set's incoming messages) marginalised directly: inputs from the set's message arena,
-        // outputs into the request list's scratch buffer (JtFlow::out_shift)
+    // marginalise the BELIEF tables: each is the "potential" argument of a childless collect
+    if (mb->nblocks > 0)
+        launch_variant(pl, JT_K_MARGINALS, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.bel, b.bel, mb->scratch, plain);
+    if (mb->unit_nblocks > 0) {
+        // cliques that keep no belief table (multi-set plans: all; else the unit cliques): psi * (the incoming tables)
+        // marginalised directly - inputs from the set's message arena (and the fixed arena), outputs into the request list's
+        // scratch buffer (JtFlow::out_shift)
         plain.cur_off = b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));
         plain.ev = b.ev;
-        plain.out_shift = (int64_t)(mb->scratch - (b.msg + plain.cur_off));
-        launch_variant(pl, JT_K_SINGLE, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.psi, b.bel, b.msg, plain);
-    } else
-        launch_variant(pl, JT_K_MARGINALS, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.bel, b.bel, mb->scratch, plain);
+        plain.fix_shift = b.fix_shift(plain.cur_off);
+        plain.out_shift = (int64_t)(((intptr_t)mb->scratch - (intptr_t)(b.msg + plain.cur_off)) / 8);
+        launch_variant(pl, JT_K_SINGLE, mb->unit_nblocks, mb->unit_lds, s, mb->d_tasks, mb->d_blocks + mb->nblocks, mb->d_itab, b.psi, b.bel, b.msg, plain);
+    }
     hipLaunchKernelGGL(jt_marg_unpack, dim3(mb->max_grid_x, mb->n), dim3(256), 0, s, mb->d_descs, mb->scratch, mb->stage);
     HIP_TRY(hipGetLastError());
     bool packed = true;
@@ -1812,6 +1896,12 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     st->device_bytes = pl->device_bytes;
     st->storage_dtype = hp.dtype;
     st->foreign_seen = pl->foreign_seen;
+    st->algorithmic_bytes_full = hp.alg_bytes_full;
+    st->fixed_bytes = (double)hp.fix_doubles * 8;
+    for (int c = 0; c < hp.n_cliques; ++c) {
+        st->n_unit_cliques += hp.pn[c].unit ? 1 : 0;
+        st->n_static_tables += hp.pn[c].unit && hp.pn[c].stat >= 0 ? 1 : 0;
+    }
     if (pl->multiset) {
         const int groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS;
         // float64 operations of the element loop of jt_mpass, per thread and table row (VEC elements), G = JT_MSETS sets:

@@ -77,7 +77,9 @@ struct JtMsg {
     int32_t e_dep;             // incoming: 1 if the message depends on any e bit
     int32_t same_launch;       // incoming: 1 if a dataflow launch may run its producer concurrently (then entries
                                // are read through to memory and checked for the unwritten marker)
-    int32_t pad1;
+    int32_t fixed;             // incoming: 1 = a STATIC table (the potential of a unit clique at the shape its factors cover,
+                               // PNode::stat): it lives in the plan's fixed arena, outside the two alternating halves of the message
+                               // arena - its address is msg_arena + JtFlow::fix_shift + off - it is never "unwritten" and has one copy
     int32_t f_w[JT_MAX_HI];    // weight of F bit j in the message's global index
     int32_t f_p[JT_MAX_HI];    // outgoing: weight of F bit j in the partial-copy number
     uint8_t free_pos[16];      // global-index bit of each sub-box index bit
@@ -109,6 +111,13 @@ struct JtTask {
                                // bit) observes a variable on the element bits of this task's clique: that group sums the four
                                // elements first (round 3 kept ONE flag per task - esum bit 1 - for all groups: with 64 sets of
                                // 16 observations more than half of the tasks lost it for everybody).  Engine, jtp_set_evidence.
+    int32_t unit;              // 1: a UNIT clique - no table is stored, every entry that exists counts as 1 (a clique no factor is
+                               // assigned to, a virtual clique of the binarisation, or a clique whose factors cover only some of its
+                               // variables: their product then enters as one more incoming message, JtMsg::fixed).  The pass loads no
+                               // table row: which entries of a row exist comes from the clique's thread map (tmap_off, always set for
+                               // such a task), which rows exist from the iteration table (JT_NO_ROW); a belief is stored only when
+                               // bel_off >= 0 (read-out tasks: into a scratch arena).  Kernels: jt_pass<..., UNIT = true>.
+    int32_t pad_unit;
     int32_t keep_rows;         // 1: the table rows are loaded with the default cache policy instead of non-temporal - this pass
                                // and the next over the same table are close enough in time for the second to find the rows in
                                // the Infinity Cache (the top of a tree: read last by collect, first by distribute; a plan whose
@@ -154,6 +163,8 @@ struct JtFlow {
     uint32_t n_blocks;         // ... and workgroup records per group
     int64_t out_shift;         // added to the address of every outgoing entry (doubles): read-out tasks of multi-set
                                // plans read one set's message arena and write into a scratch buffer elsewhere
+    int64_t fix_shift;         // static tables (JtMsg::fixed): offset (doubles) of the plan's fixed arena from the base of THIS
+                               // propagate's half of the message arena (the consumer adds it to the message's offset)
 };
 
 // one workgroup: which task, and the chunk's decoded bases (so the kernel does no bit decode)

@@ -172,7 +172,12 @@ __device__ __forceinline__ uint32_t jt_sub_hi(const uint32_t (&fp)[4], int nfree
     return g;
 }
 
-template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false, bool KEEP = false>
+// UNIT (JtTask::unit): the clique keeps NO table - every entry that exists counts as 1 (a clique without factors, a virtual
+// clique of the binarisation, or a clique whose factors cover few of its variables: their product is then one of the incoming
+// tables, JtMsg::fixed, staged like a message).  No row is loaded and no element ring is kept: which entries of a row exist
+// says the clique's thread map (read once), which rows exist the iteration table; the belief is stored only where the task
+// names a place for it (read-out tasks).  The reference never materialises such axes either (junctiontree.py:52-61).
+template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false, bool KEEP = false, bool UNIT = false>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
                                         double *__restrict__ msg_arena, const JtFlow &fl,
@@ -212,7 +217,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         const JtMsg &m = tk.msg[k];
         const uint32_t *fpw = reinterpret_cast<const uint32_t *>(m.free_pos);
         const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
-        sm_off[k] = m.off + bk.gbase[k];
+        sm_off[k] = m.off + bk.gbase[k] + (m.fixed ? fl.fix_shift : 0);
         sm_ps[k] = m.pstride;
         sm_npart[k] = m.npart;
         sm_nfree[k] = m.nfree;
@@ -260,6 +265,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 #pragma unroll
     for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) loop_pos[t] = t < tk.nA + tk.nR ? tk.loop_pos[t] : 31u;
     T *junk_row = bel_arena + ((size_t)1 << (EB + 8)) + (uint32_t)tid * VEC;
+    const bool wr_bel = MODE == 1 && tk.bel_off >= 0;      // (unit tasks: a belief is stored by read-out tasks only)
 
     // ---- element loads run U iterations ahead of their use.  Iteration i's offsets are row i of
     //      the task's iteration table (host built, held in registers below): the loops do no index
@@ -307,7 +313,11 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         }
     };
     auto issue_tables = [&]() {
-        if constexpr (TMIX) {
+        if constexpr (UNIT) {
+            const int *tm = itab + tk.tmap_off + tid * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tpo[e] = tm[e];
+        } else if constexpr (TMIX) {
             const int *tm = itab + tk.tmap_off + tid * VEC;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) tpo[e] = tm[e];
@@ -650,7 +660,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int YOUNGER = decltype(younger_tag)::value;
         double p[VEC];
-        if constexpr (TMIX) {
+        if constexpr (UNIT) {
+            // (filled in below, once the row is known to exist)
+        } else if constexpr (TMIX) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) p[e] = tpo[e] >= 0 ? (double)tbuf[SLOT][e] : 0.0;
             const int inext = (i + U < total) ? i + U : total - 1;
@@ -685,6 +697,11 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         // messages' runs come with it (jtp_plan.cpp, plan_loops)
         const uint32_t rowinfo = TMIX ? (uint32_t)__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], li) : 0u;
         const uint32_t inest = TMIX ? (rowinfo >> 16) & 63u : (uint32_t)i;
+        if constexpr (UNIT) {
+            const double one = row_ok ? 1.0 : 0.0;             // (uniform)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) p[e] = tpo[e] >= 0 ? one : 0.0;
+        }
         if (ev_mask != 0) {                                // (uniform: no vector instruction is spent without evidence)
             // LOGICAL index of this thread's first element (evidence masks are over index bits, element offsets are
             // physical): chunk bits + the row's loop bits + thread part
@@ -747,7 +764,8 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 }
                 b[e] = pref;
             }
-            {   // beliefs are written once and not read again by this propagate: a streaming store
+            if (!UNIT || wr_bel) {
+                // beliefs are written once and not read again by this propagate: a streaming store
                 // keeps them from sitting dirty in the last-level cache, where the next collect's
                 // reads would have to push them out (measured: collect 0.25 -> 0.22 ms)
                 typedef T ext_t __attribute__((ext_vector_type(VEC)));
@@ -1019,6 +1037,76 @@ __global__ __launch_bounds__(JT_THREADS) void jt_reduce_level(const JtTask *__re
     jt_reduce<false>(tasks[bk.task], bk, msg, fl);
 }
 
+// Unit tasks (JtTask::unit): their shapes differ from the table-keeping tasks' - the static table is one more incoming one
+// (collect: up to three children, or the static table and two; distribute: the parent's message and / or the static table, then
+// up to three children) - so they are dispatched here, by every kernel that may meet one.
+#define JT_UNIT_PASS(NIN, NOUT, MODE) jt_pass<T, NIN, NOUT, MODE, FLOW, true, TMIX, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry)
+template <typename T, bool FLOW, bool TMIX>
+__device__ __forceinline__ void jt_unit_collect(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
+                                                T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
+                                                uint32_t *flow_ctl, uint64_t t_entry) {
+    switch (tk.n_in) {
+        case 0: JT_UNIT_PASS(0, 1, 0); break;
+        case 1: JT_UNIT_PASS(1, 1, 0); break;
+        case 2: JT_UNIT_PASS(2, 1, 0); break;
+        default: JT_UNIT_PASS(3, 1, 0); break;
+    }
+}
+template <typename T, bool FLOW, bool TMIX>
+__device__ __forceinline__ void jt_unit_distribute(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
+                                                   T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
+                                                   uint32_t *flow_ctl, uint64_t t_entry) {
+    switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {        // (inputs that are not children) x children
+        case 0: JT_UNIT_PASS(0, 0, 1); break;
+        case 1: JT_UNIT_PASS(1, 1, 1); break;
+        case 2: JT_UNIT_PASS(2, 2, 1); break;
+        case 3: JT_UNIT_PASS(3, 3, 1); break;
+        case 4: JT_UNIT_PASS(1, 0, 1); break;
+        case 5: JT_UNIT_PASS(2, 1, 1); break;
+        case 6: JT_UNIT_PASS(3, 2, 1); break;
+        case 7: JT_UNIT_PASS(4, 3, 1); break;
+        case 8: JT_UNIT_PASS(2, 0, 1); break;
+        case 9: JT_UNIT_PASS(3, 1, 1); break;
+        default: JT_UNIT_PASS(4, 2, 1); break;
+    }
+}
+// read-out tasks of unit cliques (no launch waits on anything): one to three marginals of psi x every incoming table per pass,
+// or the belief itself into the scratch arena
+template <typename T, bool TMIX>
+__device__ __forceinline__ void jt_unit_single(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
+                                               T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex) {
+    constexpr bool FLOW = false;
+    uint32_t *flow_ctl = nullptr;
+    const uint64_t t_entry = 0;
+    if (tk.mode == 0) {
+        switch (tk.n_out * 8 + tk.n_in) {
+            case 8: JT_UNIT_PASS(0, 1, 0); break;
+            case 9: JT_UNIT_PASS(1, 1, 0); break;
+            case 10: JT_UNIT_PASS(2, 1, 0); break;
+            case 11: JT_UNIT_PASS(3, 1, 0); break;
+            case 12: JT_UNIT_PASS(4, 1, 0); break;
+            case 16: JT_UNIT_PASS(0, 2, 0); break;
+            case 17: JT_UNIT_PASS(1, 2, 0); break;
+            case 18: JT_UNIT_PASS(2, 2, 0); break;
+            case 19: JT_UNIT_PASS(3, 2, 0); break;
+            case 20: JT_UNIT_PASS(4, 2, 0); break;
+            case 24: JT_UNIT_PASS(0, 3, 0); break;
+            case 25: JT_UNIT_PASS(1, 3, 0); break;
+            case 26: JT_UNIT_PASS(2, 3, 0); break;
+            case 27: JT_UNIT_PASS(3, 3, 0); break;
+            default: JT_UNIT_PASS(4, 3, 0); break;
+        }
+    } else {
+        switch (tk.n_in) {
+            case 0: JT_UNIT_PASS(0, 0, 1); break;
+            case 1: JT_UNIT_PASS(1, 0, 1); break;
+            case 2: JT_UNIT_PASS(2, 0, 1); break;
+            case 3: JT_UNIT_PASS(3, 0, 1); break;
+            default: JT_UNIT_PASS(4, 0, 1); break;
+        }
+    }
+}
+
 // Entry points (these names appear in rocprofv3 traces).  One launch covers every clique of
 // one tree level, whatever its number of neighbours: the workgroup dispatches on its task.
 template <typename T>
@@ -1028,6 +1116,10 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_collect_level(const JtTask *
                                                                double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
+    if (tk.unit) {
+        jt_unit_collect<T, false, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+        return;
+    }
     switch (tk.n_in) {
         case 0: jt_pass<T, 0, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
         case 1: jt_pass<T, 1, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
@@ -1043,6 +1135,10 @@ __global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_level(const JtTas
                                                                   double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
+    if (tk.unit) {
+        jt_unit_distribute<T, false, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+        return;
+    }
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
         case 0: jt_pass<T, 0, 0, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
         case 1: jt_pass<T, 1, 1, 1>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
@@ -1084,6 +1180,10 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_collect_flow(const JtTask *_
         jt_reduce<true>(tk, bk, msg, fl);
         return;
     }
+    if (tk.unit) {
+        jt_unit_collect<T, true, false>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
+        return;
+    }
     switch (tk.n_in) {
         case 0: jt_pass<T, 0, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
         case 1: jt_pass<T, 1, 1, 0, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
@@ -1102,6 +1202,10 @@ __device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
         jt_reduce<true>(tk, bk, msg, fl);
+        return;
+    }
+    if (tk.unit) {
+        jt_unit_distribute<T, true, false>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
         return;
     }
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
@@ -1133,6 +1237,11 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_propagate_flow(const JtTask 
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
         jt_reduce<true>(tk, bk, msg, fl);
+        return;
+    }
+    if (tk.unit) {
+        if (tk.mode == 0) jt_unit_collect<T, true, false>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
+        else jt_unit_distribute<T, true, false>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
         return;
     }
     if (tk.mode == 0) {
@@ -1706,6 +1815,10 @@ __global__ __launch_bounds__(JT_THREADS) void jt_single(const JtTask *__restrict
                                                         T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
+    if (tk.unit) {
+        jt_unit_single<T, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x);
+        return;
+    }
     if (tk.mode == 0) {
         switch (tk.n_in) {
             case 0: jt_pass<T, 0, 1, 0>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x); break;
@@ -1750,6 +1863,11 @@ template <typename T, bool FLOW>
 __device__ __forceinline__ void jt_collect_mix(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                uint32_t *flow_ctl, uint64_t t_entry) {
+    if (tk.unit) {
+        if constexpr (FLOW) jt_unit_collect<T, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
+        else jt_unit_single<T, true>(tk, bk, itab, psi, bel, msg, fl, bindex);      // (level launches and read-out lists)
+        return;
+    }
     if (tk.n_out > 1) {                        // read-out tasks: several marginals of one belief table per pass
         if (tk.n_out == 2) jt_pass<T, 0, 2, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
         else jt_pass<T, 0, 3, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
@@ -1767,6 +1885,11 @@ template <typename T, bool FLOW>
 __device__ __forceinline__ void jt_distribute_mix(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                   T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                   uint32_t *flow_ctl, uint64_t t_entry) {
+    if (tk.unit) {
+        if (tk.n_out == 0 && !FLOW) jt_unit_single<T, true>(tk, bk, itab, psi, bel, msg, fl, bindex);       // (read-out: up to four incoming tables)
+        else jt_unit_distribute<T, FLOW, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
+        return;
+    }
     if (tk.n_out == 0) {                       // belief only (leaves, and the read-out of multi-neighbour cliques)
         switch (tk.n_in) {
             case 0: jt_pass<T, 0, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;

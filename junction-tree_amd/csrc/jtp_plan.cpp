@@ -66,6 +66,23 @@ MsgView make_view(const PNode &p, const PSep &s, int psep, bool up) {
     return mv;
 }
 
+// the static table of a unit clique, seen from the clique: one more incoming message (JtMsg::fixed)
+MsgView make_view(const PNode &p, const PStatic &s) {
+    MsgView mv;
+    mv.psep = -1;
+    mv.up = true;
+    mv.msg_bits = s.nbits;
+    for (int i = 0; i < 32; ++i) mv.dst[i] = -1;
+    for (size_t i = 0; i < s.vars.size(); ++i) {
+        int j = find_var(p.vars, s.vars[i]);
+        for (int t = 0; t < s.nb[i]; ++t) {
+            mv.dst[p.pos[j] + t] = (int8_t)(s.pos[i] + t);
+            mv.mask |= 1u << (p.pos[j] + t);
+        }
+    }
+    return mv;
+}
+
 // ---- layout policy 4: a cost model of one task, searched over loop sets (and, in layouts(), over thread parts) -----
 // Made for cliques whose messages are not small beside the table (config 3: 2 MiB messages, 8-64 MiB tables), where
 // the greedy F/A/R split below ends at 8 iterations per workgroup under 50-70 KiB of sub-boxes and 8-16 partial
@@ -115,6 +132,7 @@ const CostK &cost_k() {
 struct CostEnv {
     int TB = 10, EB = 2, nbits = 0;
     bool dist = false;           // distribute pass: the table is written as well as read
+    bool unit = false;           // unit clique: no table rows are loaded or stored, no element ring in LDS
     int max_iter_log2 = JT_MAX_ITER_LOG2;
     double share = 1.0;          // part of the chip this clique can count on (its share of the level's elements)
     double fill = 1.0;           // rows that exist / rows of the index space (variables stored at their true cardinality)
@@ -134,7 +152,7 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
     const int nL = popc(L);
     if (nL < e.min_loop_log2 || nL > e.max_iter_log2 || popc(F) > JT_MAX_HI) return 1e30;
     const double nwg = std::max(1.0, std::ldexp(e.fill, popc(F))), iters = std::ldexp(1.0, nL);
-    long lds = JT_RING_BYTES;
+    long lds = e.unit ? 0 : JT_RING_BYTES;
     double stage = 0, flush = 0, red_bytes = 0, epi = 0;
     int n_red = 0;
     for (uint32_t m : ins) {
@@ -185,7 +203,7 @@ double task_cost_us(const CostEnv &e, const std::vector<uint32_t> &ins, const st
     const int per_cu = (int)std::min((long)K.max_cu, std::max(1L, 160L * 1024 / (lds + 128)));
     const double conc = std::max(1.0, 256.0 * per_cu * e.share);
     const double t_lat = std::max(t_wg, nwg * t_wg / conc);
-    const double bytes = nwg * (iters * 4096.0 * (e.dist ? 2.0 : 1.0) + 0.5 * stage + flush);
+    const double bytes = nwg * (e.unit ? 0.0 : iters * 4096.0 * (e.dist ? 2.0 : 1.0)) + nwg * (0.5 * stage + flush);
     // (neither bound hides the other completely: a workgroup's start-up and epilogues issue no loads)
     const double t_bw = bytes / (K.bw * e.share);
     double t = std::max(t_lat, t_bw) + K.overlap * std::min(t_lat, t_bw);
@@ -310,7 +328,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
     if (p.layout == 4 && strict_budget == 0) {
         // searched split (cost model above): every loop set the iteration cap allows
         CostEnv e;
-        e.TB = TB, e.EB = hp.EB, e.nbits = nbits, e.dist = tk.mode == 1, e.share = share;
+        e.TB = TB, e.EB = hp.EB, e.nbits = nbits, e.dist = tk.mode == 1, e.share = share, e.unit = tk.unit != 0;
         e.red_log2 = hp.knobs.reduce_min >= 0 ? std::max(0, ceil_log2(std::max(hp.knobs.reduce_min, 1))) : (hp.chain_plan ? 3 : 6);
         e.chain = hp.chain_plan;
         e.min_loop_log2 = hp.chain_plan ? JT_MIN_LOOP_LOG2 : JT_MIN_ITER_LOG2;
@@ -336,7 +354,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
                 e.max_iter_log2 = std::max(hp.knobs.top_loop2, JT_MIN_LOOP_LOG2);
             }
         }
-        if (hp.lds_budget > 0) e.lds_cap = JT_RING_BYTES + hp.lds_budget + JT_STAGE_SCRATCH * (long)ins.size();
+        if (hp.lds_budget > 0) e.lds_cap = (tk.unit ? 0 : JT_RING_BYTES) + hp.lds_budget + JT_STAGE_SCRATCH * (long)ins.size();
         uint32_t seen = 0;
         for (int b = TB; b < nbits; ++b)
             if (!(seen >> b & 1)) e.units.push_back(unit(b)), seen |= unit(b);
@@ -375,7 +393,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
             // static words - stays inside the CU's 160 KiB (150 KiB of sub-boxes alone, the bound of rounds 1-2, did not:
             // hipFuncSetAttribute refused 170 KiB on a random factor graph, tools/gpu_fuzz_api.py)
             // (4 KiB for the static words: the reduce path's 2 KiB of partial sums and the dataflow control words are in the same kernels)
-            if (lds_of(F) + JT_RING_BYTES + JT_STAGE_SCRATCH * (long)ins.size() + 4096 <= 160 * 1024 && max_free(F) <= JT_MAX_FREE) break;
+            if (lds_of(F) + (tk.unit ? 0 : JT_RING_BYTES) + JT_STAGE_SCRATCH * (long)ins.size() + 4096 <= 160 * 1024 && max_free(F) <= JT_MAX_FREE) break;
             // (a marginal onto nearly all variables of a clique of few rows - a factor as wide as its clique, 3^8 entries:
             //  four rows per workgroup before giving up)
             if (!down_to_four) {
@@ -435,7 +453,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         order_a_bits(Ab, om);
     }
     tk.nbits = nbits;
-    tk.tmap_off = hp.tmix ? p.tmap_off : -1;
+    tk.tmap_off = (hp.tmix || tk.unit) ? p.tmap_off : -1;      // (unit tasks: which entries of a row exist)
     tk.real_bits = real_bits;
     tk.debug = hp.knobs.debug;
     tk.nF = (int)Fb.size();
@@ -463,7 +481,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
     for (int b : Rb) loopmask |= 1u << b;
     for (int b : Ab) loopmask |= 1u << b;
 
-    int lds = JT_RING_BYTES;                    // the element ring sits at LDS offset 0
+    int lds = tk.unit ? 0 : JT_RING_BYTES;      // the element ring sits at LDS offset 0 (unit tasks load no rows: no ring)
     // per-message tables
     std::vector<std::vector<int>> slotw;      // [msg][clique bit] -> sub-box slot weight
     auto fill_msg = [&](JtMsg &jm, const MsgView &mv, bool is_out) {
@@ -653,6 +671,8 @@ PlanKnobs jtp_read_knobs() {
     k.esum_always = geti("JTP_EXPERIMENT_ESUM_ALWAYS", 0);
     k.marg_group = std::max(1, std::min(geti("JTP_MARG_GROUP", JT_MAX_OUT), JT_MAX_OUT));
     k.marg_block_log2 = geti("JTP_MARG_BLOCK_LOG2", 0);
+    k.no_unit = geti("JTP_NO_UNIT", 0);
+    k.unit_ratio = getd("JTP_UNIT_RATIO", 4.0);
     return k;
 }
 
@@ -676,10 +696,12 @@ struct PlanBuilder {
     int read_description();      // validate and copy the caller's description
     int link_nodes();            // cliques, separators, reachability, replicated part
     int reroot();                // single rank: root at the tree's centre
+    int decide_units();          // which cliques keep no table (all ones, or their factors' product as a static table)
     int binarise();              // at most three children per node (virtual all-ones cliques)
     int depths();
     int layouts();               // bit order of every clique and separator table
     bool searched_order(int c, const std::vector<int> &host, const std::vector<int> &seps, std::vector<int> &order);   // layout policy 4
+    bool wants_static(const PNode &p) const { return p.unit && p.real >= 0 && !p.cover.empty(); }
     int arenas();                // table offsets, host<->device conversion records
     int level_work();
     int make_tasks();            // one task per (clique, phase) - multi-set plans: per (clique, child) in distribute
@@ -688,7 +710,7 @@ struct PlanBuilder {
     int finish();                // dataflow segments, sync words, time-stamp region
     int run() {
         int (PlanBuilder::*stages[])() = {&PlanBuilder::read_description, &PlanBuilder::link_nodes, &PlanBuilder::reroot,
-                                          &PlanBuilder::binarise, &PlanBuilder::depths, &PlanBuilder::layouts,
+                                          &PlanBuilder::decide_units, &PlanBuilder::binarise, &PlanBuilder::depths, &PlanBuilder::layouts,
                                           &PlanBuilder::arenas, &PlanBuilder::level_work, &PlanBuilder::make_tasks,
                                           &PlanBuilder::messages, &PlanBuilder::schedule, &PlanBuilder::finish};
         for (auto stage : stages) {
@@ -788,6 +810,23 @@ int PlanBuilder::read_description() {
             if (v < 0 || v >= d->n_vars) FAIL(JTP_EINVAL, "node %d: unknown variable %d", n, v);
             if (find_var(hp.node_vars[n], v) >= 0) FAIL(JTP_EINVAL, "node %d: variable %d listed twice", n, v);
             hp.node_vars[n].push_back(v);
+        }
+    }
+    hp.lean = d->cover_off != nullptr && !hp.multiset;
+    if (d->cover_off) {
+        // (validated for every plan that passes them, used by single-set plans)
+        if (d->cover_off[0] != 0) FAIL(JTP_EINVAL, "cover_off[0] must be 0 (got %d)", d->cover_off[0]);
+        if (d->cover_off[N] > 0 && !d->cover_ids) FAIL(JTP_EINVAL, "null array in the description");
+        hp.cover.assign(N, std::vector<int>());
+        for (int c = 0; c < N; ++c) {
+            const int a = d->cover_off[c], b = d->cover_off[c + 1];
+            if (a < 0 || b < a || b - a > JT_MAX_VARS) FAIL(JTP_EINVAL, "cover_off decreases at clique %d (%d, %d)", c, a, b);
+            for (int i = a; i < b; ++i) {
+                const int v = d->cover_ids[i];
+                if (v < 0 || v >= d->n_vars || find_var(hp.node_vars[c], v) < 0) FAIL(JTP_EINVAL, "clique %d: covered variable %d is not one of its variables", c, v);
+                if (find_var(hp.cover[c], v) >= 0) FAIL(JTP_EINVAL, "clique %d: covered variable %d listed twice", c, v);
+                hp.cover[c].push_back(v);
+            }
         }
     }
     hp.parent_clique.assign(d->parent_clique, d->parent_clique + N);
@@ -908,10 +947,32 @@ int PlanBuilder::reroot() {
     return JTP_OK;
 }
 
+int PlanBuilder::decide_units() {
+    // ---- unit cliques (JtTask::unit): no table, no belief table.  A clique becomes one when the description says its
+    //      potential depends on few of its variables: on none (no factor assigned: 365 of the 878 cliques of the config-3
+    //      lattice, 98 % of its table bytes), or on a part at most 1 / unit_ratio of the table - the product of its factors
+    //      then travels as a static table over the covered variables.  The reference leaves such axes at length 1
+    //      (junctiontree.py:52-61); rounds 1-4 of this engine materialised them, and streamed 9 GiB of ones three times per
+    //      propagate on that lattice.  A clique covered (nearly) whole keeps its table: streaming it costs less than staging it.
+    if (!hp.lean || hp.knobs.no_unit) return JTP_OK;
+    for (int c = 0; c < N; ++c) {
+        PNode &p = hp.pn[c];
+        p.cover = hp.cover[c];
+        double full = 1, part = 1;
+        for (int v : hp.node_vars[c]) full *= hp.card[v];
+        for (int v : p.cover) part *= hp.card[v];
+        p.unit = p.cover.size() < hp.node_vars[c].size() && part * hp.knobs.unit_ratio <= full;
+    }
+    return JTP_OK;
+}
+
 int PlanBuilder::binarise() {
     // ---- binarise: at most 3 children per node, via virtual all-ones cliques ---------------
+    // (a unit clique with a static table stages it like one more incoming message: JT_MAX_IN = 4 then leaves room for the
+    //  parent's message and TWO children)
     for (int c = 0; c < (int)hp.pn.size(); ++c) {
-        while (hp.pn[c].children.size() > 3) {
+        const size_t lim = (wants_static(hp.pn[c]) && hp.pn[c].parent >= 0) ? 2 : 3;
+        while (hp.pn[c].children.size() > lim) {
             std::vector<int> old = hp.pn[c].children, fresh;
             for (size_t g = 0; g < old.size(); g += 3) {
                 size_t ge = std::min(old.size(), g + 3);
@@ -921,6 +982,7 @@ int PlanBuilder::binarise() {
                 }
                 PNode v;
                 v.real = -1;
+                v.unit = !hp.multiset && !hp.knobs.no_unit;     // (all ones: nothing to store)
                 v.owner = hp.pn[c].owner;
                 v.parent = c;
                 for (size_t i = g; i < ge; ++i) {
@@ -979,8 +1041,10 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
     const int n = (int)host.size(), TB = hp.TB;
     if (n == 0 || n > 31) return false;
     std::vector<int> cnt(n, 0), canon(n), rank_of(n);
+    const bool has_static = wants_static(p);
     for (int i = 0; i < n; ++i) {
         for (int sp : seps) cnt[i] += find_var(hp.ps[sp].vars, host[i]) >= 0;
+        if (has_static) cnt[i] += find_var(p.cover, host[i]) >= 0;
         canon[i] = i;
     }
     auto waste = [&](int i) { return (double)(1 << hp.vbits[host[i]]) / hp.card[host[i]]; };
@@ -1018,13 +1082,14 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
         for (int i : idx) pos[i] = bit, bit += hp.vbits[host[i]];
         CostEnv e;
         e.TB = TB, e.EB = hp.EB, e.nbits = std::max(bit, TB + JT_MIN_ITER_LOG2);
+        e.unit = p.unit;
         e.red_log2 = hp.knobs.reduce_min >= 0 ? std::max(0, ceil_log2(std::max(hp.knobs.reduce_min, 1))) : (hp.chain_plan ? 3 : 6);
         e.chain = hp.chain_plan;
         e.min_loop_log2 = hp.chain_plan ? JT_MIN_LOOP_LOG2 : JT_MIN_ITER_LOG2;
         uint32_t grouped = 0;
         for (int i : idx) {
             const int card = hp.card[host[i]], nb = hp.vbits[host[i]];
-            if (pos[i] >= TB && hp.compact && (card & (card - 1)) != 0) {
+            if (pos[i] >= TB && (hp.compact || p.unit) && (card & (card - 1)) != 0) {
                 const uint32_t g = ((1u << nb) - 1u) << pos[i];
                 e.units.push_back(g), grouped |= g;
                 e.fill *= (double)card / (double)(1 << nb);
@@ -1032,9 +1097,15 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
         }
         for (int b = TB; b < e.nbits; ++b)
             if (!(grouped >> b & 1)) e.units.push_back(1u << b);
-        if (hp.compact) e.fill = std::ldexp(e.fill, -(e.nbits - std::max(bit, TB)));
+        if (hp.compact || p.unit) e.fill = std::ldexp(e.fill, -(e.nbits - std::max(bit, TB)));
         std::sort(e.units.begin(), e.units.end());
-        if (hp.lds_budget > 0) e.lds_cap = JT_RING_BYTES + hp.lds_budget + JT_STAGE_SCRATCH * 4L;
+        if (hp.lds_budget > 0) e.lds_cap = (p.unit ? 0 : JT_RING_BYTES) + hp.lds_budget + JT_STAGE_SCRATCH * 4L;
+        uint32_t stat_mask = 0;
+        if (has_static)
+            for (int v : p.cover) {
+                const int i = find_var(host, v);
+                if (i >= 0) stat_mask |= ((1u << hp.vbits[v]) - 1u) << pos[i];
+            }
         auto mask_of = [&](int sp) {
             uint32_t m = 0;
             for (int v : hp.ps[sp].vars) {
@@ -1051,7 +1122,9 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
             e.dist = false;
             e.max_iter_log2 = std::min(std::max(block_log2_for(0, p.depth, p.owner, false) - TB, JT_MIN_ITER_LOG2), JT_MAX_ITER_LOG2);
             e.share = std::min(1.0, elems / std::max(elems, lvl_elems[0][p.owner][p.depth]));
-            LoopChoice ch = search_loops(e, kids, {mask_of(p.psep)}, false);
+            std::vector<uint32_t> cin = kids;
+            if (has_static) cin.push_back(stat_mask);
+            LoopChoice ch = search_loops(e, cin, {mask_of(p.psep)}, false);
             ev.us += ch.us, ev.Lc = ch.L;
         }
         {
@@ -1060,6 +1133,7 @@ bool PlanBuilder::searched_order(int c, const std::vector<int> &host, const std:
             e.share = std::min(1.0, elems / std::max(elems, lvl_elems[1][p.owner][p.depth]));
             std::vector<uint32_t> ins;
             if (p.psep >= 0) ins.push_back(mask_of(p.psep));
+            if (has_static) ins.push_back(stat_mask);
             ins.insert(ins.end(), kids.begin(), kids.end());
             LoopChoice ch = search_loops(e, ins, kids, false);
             ev.us += ch.us, ev.Ld = ch.L;
@@ -1152,6 +1226,11 @@ int PlanBuilder::layouts() {
             for (int sp : seps) {
                 int sb = 0;
                 for (int v : hp.ps[sp].vars) sb += hp.vbits[v];
+                msg_bytes += 8.0 * (double)((int64_t)1 << sb);
+            }
+            if (wants_static(p)) {
+                int sb = 0;
+                for (int v : p.cover) sb += hp.vbits[v];
                 msg_bytes += 8.0 * (double)((int64_t)1 << sb);
             }
             int cb = 0;
@@ -1281,7 +1360,9 @@ int PlanBuilder::layouts() {
                 if (b + hp.vbits[v] <= hp.TB) fill *= (double)hp.card[v] / (double)(1 << hp.vbits[v]);
                 b += hp.vbits[v];
             }
-            p.tmix = fill < hp.knobs.tmix_fill && hp.compact && !hp.multiset && !hp.knobs.no_tmix;
+            // (a unit clique stores nothing: no rows to pack - it keeps the bit-field thread part, whose entries that name
+            //  no table entry its thread map marks)
+            p.tmix = fill < hp.knobs.tmix_fill && hp.compact && !hp.multiset && !hp.knobs.no_tmix && !p.unit;
         }
         int bit = 0;
         p.tpad_mask = 0;
@@ -1300,11 +1381,18 @@ int PlanBuilder::layouts() {
                     bit = hp.TB;
                 }
             }
+            if (p.unit && bit < hp.TB && bit + hp.vbits[v] > hp.TB && (hp.card[v] & (hp.card[v] - 1)) != 0) {
+                // A unit clique has no table whose zeros could mark the entries that do not exist: which entries of a ROW exist must
+                // depend on the thread alone (PNode::tmap) and which rows exist on the row alone (JT_NO_ROW).  A variable across bit
+                // TB whose cardinality is no power of two would tie the two together: it moves above bit TB whole.
+                for (int b = bit; b < hp.TB; ++b) p.tpad_mask |= 1u << b;
+                bit = hp.TB;
+            }
             p.pos.push_back(bit);
             p.nb.push_back(hp.vbits[v]);
             bit += hp.vbits[v];
         }
-        if (p.tmix)
+        if (p.tmix || p.unit)
             for (int b = bit; b < hp.TB; ++b) p.tpad_mask |= 1u << b;
         hp.tmix = hp.tmix || p.tmix;
         if (bit > JT_MAX_BITS) FAIL(JTP_EUNSUPPORTED, "clique %d needs %d index bits (max %d)", p.real, bit, JT_MAX_BITS);
@@ -1355,7 +1443,9 @@ int PlanBuilder::layouts() {
         for (size_t i = 0; i < p.vars.size(); ++i) {
             const int pos = p.pos[i], nb = p.nb[i], card = hp.card[p.vars[i]];
             if (pos + nb <= hp.TB) continue;
-            const bool whole = pos >= hp.TB && hp.compact && (card & (card - 1)) != 0;
+            // (a unit clique has no table whose zeros could stand for a digit beyond the cardinality: its rows are always counted at
+            //  the true cardinalities, JTP_NO_COMPACT or not)
+            const bool whole = pos >= hp.TB && (hp.compact || p.unit) && (card & (card - 1)) != 0;
             // (the variable across TB of a mixed-radix clique: its high bits are a digit of ceil(card / 2^lb) values)
             const int hi = (int)i == p.tsplit ? (card + (1 << p.tsplit_lb) - 1) >> p.tsplit_lb : 0;
             const bool split_group = hi > 0 && (hi & (hi - 1)) != 0;
@@ -1376,18 +1466,28 @@ int PlanBuilder::layouts() {
             }
         }
         for (int b = std::max(bit, hp.TB); b < p.nbits; ++b) {
-            if (hp.compact) p.pad_mask |= 1u << b;           // weight 0, exists only when clear
+            if (hp.compact || p.unit) p.pad_mask |= 1u << b; // weight 0, exists only when clear
             else p.bitw[b] = mult, mult <<= 1;
         }
         p.phys_elems = mult;
         if (mult > ((int64_t)1 << 31)) FAIL(JTP_EUNSUPPORTED, "clique %d too large", p.real);
     }
-    if (hp.tmix)
-        for (PNode &p : hp.pn)
-            if (!p.tmix) {            // bit-field rows: the identity map, so that one kernel family serves every task of the plan
-                p.tmap.resize((size_t)1 << hp.TB);
-                for (uint32_t x = 0; x < (1u << hp.TB); ++x) p.tmap[x] = (int32_t)x;
+    for (PNode &p : hp.pn)
+        if (!p.tmix && (hp.tmix || p.unit)) {
+            // bit-field rows: the identity map, so that one kernel family serves every task of a plan with mixed-radix rows; a unit
+            // clique's map says which entries of a row EXIST (-1: a thread-part variable's digit beyond its cardinality, an index bit
+            // below TB that no variable owns) - the zeros a stored table would hold there
+            p.tmap.resize((size_t)1 << hp.TB);
+            for (uint32_t x = 0; x < (1u << hp.TB); ++x) {
+                bool ok = true;
+                if (p.unit) {
+                    ok = !(x & p.tpad_mask);
+                    for (size_t i = 0; i < p.vars.size() && ok; ++i)
+                        if (p.pos[i] + p.nb[i] <= hp.TB) ok = (int)((x >> p.pos[i]) & ((1u << p.nb[i]) - 1u)) < hp.card[p.vars[i]];
+                }
+                p.tmap[x] = ok ? (int32_t)x : -1;
             }
+        }
     for (size_t s = 0; s < hp.ps.size(); ++s) {
         PSep &sp = hp.ps[s];
         const PNode &ch = hp.pn[sp.child];
@@ -1405,6 +1505,25 @@ int PlanBuilder::layouts() {
         }
         sp.nbits = bit;
         if (bit > 28) FAIL(JTP_EUNSUPPORTED, "separator with %d index bits", bit);
+    }
+    // static tables of unit cliques: the covered variables in the clique's device order, a plain bit field like a message
+    for (int c = 0; c < NP; ++c) {
+        PNode &p = hp.pn[c];
+        if (!wants_static(p)) continue;
+        PStatic st;
+        st.pnode = c;
+        int bit = 0;
+        for (int v : p.vars)
+            if (find_var(p.cover, v) >= 0) {
+                st.vars.push_back(v);
+                st.pos.push_back(bit);
+                st.nb.push_back(hp.vbits[v]);
+                bit += hp.vbits[v];
+            }
+        st.nbits = bit;
+        if (bit > 28) FAIL(JTP_EUNSUPPORTED, "static table with %d index bits", bit);
+        p.stat = (int)hp.statics.size();
+        hp.statics.push_back(st);
     }
 
     return JTP_OK;
@@ -1465,23 +1584,78 @@ int PlanBuilder::arenas() {
         }
         return pd;
     };
+    std::map<std::vector<int32_t>, int64_t> map_at;          // thread maps already in the table buffer (unit cliques: mostly one)
+    hp.fix_doubles = 0;
+    hp.scratch_elems = 0;
     for (int c = 0; c < NP; ++c) {
         PNode &p = hp.pn[c];
         if (!mine(c)) continue;
-        p.arena_off = hp.arena_elems;
-        hp.arena_elems += p.phys_elems;
-        hp.arena_elems = (hp.arena_elems + 255) & ~(int64_t)255;
-        double he = 1;
-        for (int v : p.vars) he *= hp.card[v];
-        hp.host_table_elems += he;
-        if (p.real < 0) hp.virtual_fills.push_back({pack_of(p, p.vars)});     // virtual clique: a resident 0/1 table
-        if (hp.tmix) {
-            p.tmap_off = (int64_t)hp.itab.size();
-            hp.itab.insert(hp.itab.end(), p.tmap.begin(), p.tmap.end());
+        if (p.unit) {
+            // no table: the passes make up the ones (jt_pass<..., UNIT>); beliefs on demand, into a scratch arena laid out like
+            // the table would be (rows 0 and 1 shared, as in the arenas)
+            p.arena_off = (int64_t)2 << hp.TB;
+            hp.scratch_elems = std::max(hp.scratch_elems, p.arena_off + p.phys_elems);
+            hp.has_unit = true;
+            double he = 1;
+            for (int v : p.cover) he *= hp.card[v];
+            if (p.stat >= 0) hp.host_table_elems += he;
+        } else {
+            p.arena_off = hp.arena_elems;
+            hp.arena_elems += p.phys_elems;
+            hp.arena_elems = (hp.arena_elems + 255) & ~(int64_t)255;
+            double he = 1;
+            for (int v : p.vars) he *= hp.card[v];
+            hp.host_table_elems += he;
+            if (p.real < 0) hp.virtual_fills.push_back({pack_of(p, p.vars)});     // virtual clique: a resident 0/1 table
+        }
+        if (hp.tmix || p.unit) {
+            auto it = p.unit ? map_at.find(p.tmap) : map_at.end();
+            if (it != map_at.end()) p.tmap_off = it->second;
+            else {
+                p.tmap_off = (int64_t)hp.itab.size();
+                hp.itab.insert(hp.itab.end(), p.tmap.begin(), p.tmap.end());
+                if (p.unit) map_at[p.tmap] = p.tmap_off;
+            }
+        }
+        if (p.stat >= 0) {
+            // (16-byte aligned and at least two doubles: the kernels that fill it store 16-byte vectors)
+            PStatic &st = hp.statics[p.stat];
+            st.off = hp.fix_doubles;
+            hp.fix_doubles += std::max<int64_t>((int64_t)1 << st.nbits, 2);
+            hp.fix_doubles = (hp.fix_doubles + 1) & ~(int64_t)1;
         }
     }
     hp.pack.assign(N, JtPackDesc());
-    for (int c = 0; c < N; ++c) hp.pack[c] = pack_of(hp.pn[c], hp.node_vars[c]);
+    hp.stat_pack.assign(N, JtPackDesc());
+    for (int c = 0; c < N; ++c) {
+        hp.pack[c] = pack_of(hp.pn[c], hp.node_vars[c]);
+        memset(&hp.stat_pack[c], 0, sizeof(JtPackDesc));
+        const PNode &p = hp.pn[c];
+        if (p.stat < 0) continue;
+        // host array of the clique (its uncovered axes have length 1) <-> the static table
+        const PStatic &st = hp.statics[p.stat];
+        JtPackDesc &pd = hp.stat_pack[c];
+        pd.dev_off = st.off;
+        pd.nbits = st.nbits;
+        pd.nvars = (int)hp.node_vars[c].size();
+        int64_t stride = 1;
+        for (int i = pd.nvars - 1; i >= 0; --i) {
+            const int v = hp.node_vars[c][i];
+            const int j = find_var(st.vars, v);
+            pd.pos[i] = j >= 0 ? (uint8_t)st.pos[j] : 0;
+            pd.nb[i] = j >= 0 ? (uint8_t)st.nb[j] : 0;
+            pd.card[i] = j >= 0 ? hp.card[v] : 1;
+            pd.hstride[i] = j >= 0 ? stride : 0;
+            pd.dstride[i] = j >= 0 && st.nb[j] > 0 ? 1u << st.pos[j] : 0u;
+            pd.dmod[i] = j >= 0 ? 1 << st.nb[j] : 1;
+            if (j >= 0) stride *= hp.card[v];
+        }
+        pd.host_elems = stride;
+        pd.phys_elems = (int64_t)1 << st.nbits;
+        pd.low_bits = st.nbits;
+        pd.row_elems = 0;
+        pd.split_var = -1;
+    }
     return JTP_OK;
 }
 
@@ -1554,11 +1728,15 @@ int PlanBuilder::make_tasks() {
             memset(&tk, 0, sizeof tk);
             tk.pnode = c;
             tk.mode = phase;
-            tk.psi_off = mine(c) ? p.arena_off : 0;          // other ranks' tasks are not executed here
-            tk.bel_off = phase == 1 ? (mine(c) ? p.arena_off : 0) : -1;   // virtual cliques too (scratch)
+            tk.psi_off = mine(c) && !p.unit ? p.arena_off : 0;          // other ranks' tasks are not executed here
+            tk.bel_off = phase == 1 && !p.unit ? (mine(c) ? p.arena_off : 0) : -1;   // virtual cliques that keep a table too (scratch)
+            tk.unit = p.unit ? 1 : 0;
             std::vector<MsgView> ins, outs;
+            // (distribute: the inputs that are not children come first - the parent's message, the clique's static table)
             if (phase == 1 && p.psep >= 0) ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
+            if (p.stat >= 0) ins.push_back(make_view(p, hp.statics[p.stat]));
             for (int k : p.children) ins.push_back(make_view(p, hp.ps[hp.pn[k].psep], hp.pn[k].psep, true));
+            if ((int)ins.size() > JT_MAX_IN) FAIL(JTP_EUNSUPPORTED, "internal: clique %d has %zu incoming tables", p.real, ins.size());
             if (phase == 0) outs.push_back(make_view(p, hp.ps[p.psep], p.psep, true));
             else for (int k : p.children) outs.push_back(make_view(p, hp.ps[hp.pn[k].psep], hp.pn[k].psep, false));
             int real_bits = 0;
@@ -1586,11 +1764,18 @@ int PlanBuilder::make_tasks() {
                 for (int j = 0; j < nch; ++j) hp.ps[hp.pn[p.children[j]].psep].dn_npart = tk.msg[JT_MAX_IN + j].npart;
                 hp.task_variant.push_back(JT_K_DIST_P0C0 + 4 * (p.psep >= 0 ? 1 : 0) + nch);
             }
-            // algorithmic bytes: clique table read (+ belief written), messages
-            double b = 0;
-            if (p.real >= 0) b += host_elems(hp.node_vars[p.real]) * esize * (phase == 1 ? 2 : 1);
-            for (auto &m : ins) if (hp.ps[m.psep].node >= 0) b += host_elems(hp.ps[m.psep].vars) * 8;
-            for (auto &m : outs) if (hp.ps[m.psep].node >= 0) b += host_elems(hp.ps[m.psep].vars) * 8 * (phase == 1 ? 2 : 1);
+            // algorithmic bytes: clique table read (+ belief written), messages.  A unit clique counts what its
+            // potential IS - the static table (doubles), read once per pass, and no belief; `full` counts every clique at its
+            // full shape in the storage type, read and belief written (8d to the letter)
+            double b = 0, full = 0;
+            if (p.real >= 0) full += host_elems(hp.node_vars[p.real]) * esize * (phase == 1 ? 2 : 1);
+            if (p.real >= 0 && !p.unit) b += host_elems(hp.node_vars[p.real]) * esize * (phase == 1 ? 2 : 1);
+            if (p.stat >= 0) b += host_elems(p.cover) * 8;
+            double mb = 0;
+            for (auto &m : ins) if (m.psep >= 0 && hp.ps[m.psep].node >= 0) mb += host_elems(hp.ps[m.psep].vars) * 8;
+            for (auto &m : outs) if (hp.ps[m.psep].node >= 0) mb += host_elems(hp.ps[m.psep].vars) * 8 * (phase == 1 ? 2 : 1);
+            b += mb;
+            if (mine(c)) hp.alg_bytes_full += full + mb;
             task_bytes.push_back(b);
             if (hp.multiset) {
                 const double tb = p.real >= 0 ? host_elems(hp.node_vars[p.real]) * esize : 0.0;
@@ -1692,6 +1877,7 @@ int PlanBuilder::messages() {
                 for (size_t j = 0; j < p.down_tasks.size(); ++j)
                     if (p.down_tasks[j] == (int)t) skip = j;
             if (!collect_task && p.psep >= 0) prod.push_back(dn_producer(hp.ps[p.psep]));
+            if (p.stat >= 0) prod.push_back(-1);                 // the static table: nobody's product
             for (size_t i = 0; i < p.children.size(); ++i)
                 if (i != skip) prod.push_back(up_producer(hp.ps[hp.pn[p.children[i]].psep]));
         }
@@ -1728,6 +1914,13 @@ int PlanBuilder::messages() {
             tk.msg[k].same_launch = hp.pn[p.parent].owner == p.owner || hp.pn[p.parent].owner == ALL;
             ++k;
         }
+        if (p.stat >= 0) {
+            tk.msg[k].off = std::max<int64_t>(hp.statics[p.stat].off, 0);
+            tk.msg[k].npart = 1;
+            tk.msg[k].same_launch = 0;
+            tk.msg[k].fixed = 1;
+            ++k;
+        }
         for (int ch : p.children) {
             const PSep &s = hp.ps[hp.pn[ch].psep];
             tk.msg[k].off = s.up_roff;
@@ -1752,7 +1945,7 @@ int PlanBuilder::schedule() {
     if (!hp.multiset && hp.knobs.keep_rows_mb > 0) {
         std::vector<double> level_bytes(maxdepth + 1, 0.0);
         for (int c = 0; c < NP; ++c)
-            if (mine(c)) level_bytes[hp.pn[c].depth] += (double)hp.pn[c].phys_elems * esize;
+            if (mine(c) && !hp.pn[c].unit) level_bytes[hp.pn[c].depth] += (double)hp.pn[c].phys_elems * esize;
         double cum = 0;
         int keep_depth = -1;
         for (int d = 0; d <= maxdepth; ++d) {
@@ -1761,7 +1954,7 @@ int PlanBuilder::schedule() {
             keep_depth = d;
         }
         for (JtTask &tk : hp.tasks)
-            if (tk.kind == 0 && hp.pn[tk.pnode].depth <= keep_depth) tk.keep_rows = 1;
+            if (tk.kind == 0 && !tk.unit && hp.pn[tk.pnode].depth <= keep_depth) tk.keep_rows = 1;
     }
     // ---- launches, blocks, exchange schedule -----------------------------------------------------
     hp.alg_bytes = 0;
@@ -1806,7 +1999,8 @@ int PlanBuilder::schedule() {
             int t = phase == 0 ? p.collect_task : p.distribute_task;
             if (t < 0) continue;
             int key = hp.task_variant[t];
-            if (!(hp.flags & JTP_SPLIT_VARIANTS)) key = phase == 0 ? JT_K_COLLECT_LEVEL : JT_K_DISTRIBUTE_LEVEL;
+            // (per-shape launches are a profiling aid of plans whose cliques all keep tables: unit tasks have shapes of their own)
+            if (!(hp.flags & JTP_SPLIT_VARIANTS) || hp.has_unit) key = phase == 0 ? JT_K_COLLECT_LEVEL : JT_K_DISTRIBUTE_LEVEL;
             groups[key].push_back(t);
         }
         if (!groups.empty()) flush_comm();
@@ -1834,7 +2028,7 @@ int PlanBuilder::schedule() {
                 L.lds_bytes = std::max(L.lds_bytes, tk.lds_bytes);
                 L.alg_bytes += task_bytes[t];
                 for (int k = 0; k < tk.n_in; ++k) hp.staging_bytes += (double)(1u << tk.nF) * (8.0 * (1 << tk.msg[k].nfree)) * tk.msg[k].npart;
-                hp.table_bytes += (double)hp.pn[tk.pnode].phys_elems * esize * (phase == 1 && !hp.multiset ? 2 : 1);
+                if (!tk.unit) hp.table_bytes += (double)hp.pn[tk.pnode].phys_elems * esize * (phase == 1 && !hp.multiset ? 2 : 1);
             }
             L.nblocks = (int)(hp.blocks.size() - L.blk_off);
             hp.max_lds = std::max(hp.max_lds, L.lds_bytes);
@@ -2022,10 +2216,15 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
 
 // incoming messages of a clique for the read-out tasks: the parent's final downward message, every child's
 // final upward message (what consumers read: the reduced sum where a reduce task exists)
+// (a unit clique's static table comes with them: src.second = -1 marks it, JtMsg::fixed)
 static void neighbour_inputs(const HostPlan &hp, const PNode &p, std::vector<MsgView> &ins, std::vector<std::pair<int64_t, int>> &src) {
     if (p.psep >= 0) {
         ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
         src.push_back({hp.ps[p.psep].dn_roff, hp.ps[p.psep].dn_rnpart});
+    }
+    if (p.stat >= 0) {
+        ins.push_back(make_view(p, hp.statics[p.stat]));
+        src.push_back({hp.statics[p.stat].off, -1});
     }
     for (int k : p.children) {
         const PSep &sp = hp.ps[hp.pn[k].psep];
@@ -2039,7 +2238,8 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<std:
                            std::vector<JtBlock> &blocks, std::string &err, bool with_neighbours) {
     const PNode &p = hp.pn[pnode];
     if (out_vars.empty() || (int)out_vars.size() > JT_MAX_OUT) FAIL(JTP_EINVAL, "internal: %zu marginals in one task", out_vars.size());
-    if (with_neighbours && out_vars.size() != 1) FAIL(JTP_EINVAL, "internal: several marginals in one task of a multi-set plan");
+    if (with_neighbours && out_vars.size() != 1 && !p.unit) FAIL(JTP_EINVAL, "internal: several marginals in one task of a multi-set plan");
+    if (p.unit && !with_neighbours) FAIL(JTP_EINVAL, "internal: a unit clique keeps no belief table to marginalise");
     std::vector<PSep> seps(out_vars.size());
     out_bits.clear();
     for (size_t j = 0; j < out_vars.size(); ++j) {
@@ -2058,8 +2258,9 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<std:
     }
     memset(&tk, 0, sizeof tk);
     tk.pnode = pnode;
-    tk.psi_off = p.arena_off;
+    tk.psi_off = p.unit ? 0 : p.arena_off;
     tk.bel_off = -1;
+    tk.unit = p.unit ? 1 : 0;
     tk.mode = 0;                                 // (several outputs: every one of them the sum over its own complement)
     std::vector<MsgView> ins, outs;
     std::vector<std::pair<int64_t, int>> src;
@@ -2073,13 +2274,14 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<std:
     int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, with_neighbours ? 14 : (hp.knobs.marg_block_log2 > 0 ? hp.knobs.marg_block_log2 : hp.TB + JT_MAX_ITER_LOG2), err);
     tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
-    if (hp.tmix) {                               // the task travels with its own table buffer: the clique's thread map behind its rows
+    if (hp.tmix || p.unit) {                     // the task travels with its own table buffer: the clique's thread map behind its rows
         tk.tmap_off = (int64_t)itab.size();
         itab.insert(itab.end(), p.tmap.begin(), p.tmap.end());
     }
     for (size_t k = 0; k < src.size(); ++k) {
         tk.msg[k].off = src[k].first;
-        tk.msg[k].npart = src[k].second;
+        tk.msg[k].npart = src[k].second < 0 ? 1 : src[k].second;
+        tk.msg[k].fixed = src[k].second < 0 ? 1 : 0;
         tk.msg[k].same_launch = 0;
     }
     npart.clear();
@@ -2094,8 +2296,9 @@ int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<
     const PNode &p = hp.pn[pnode];
     memset(&tk, 0, sizeof tk);
     tk.pnode = pnode;
-    tk.psi_off = p.arena_off;
-    tk.bel_off = p.arena_off;
+    tk.psi_off = p.unit ? 0 : p.arena_off;
+    tk.bel_off = p.arena_off;                    // (a unit clique: its place in the scratch arena, PlanBuilder::arenas)
+    tk.unit = p.unit ? 1 : 0;
     tk.mode = 1;
     std::vector<MsgView> ins, outs;
     std::vector<std::pair<int64_t, int>> src;
@@ -2106,13 +2309,14 @@ int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<
     int rc = plan_loops(hp, p, tk, itab, p.nbits, real_bits, ins, outs, 14, err);
     tk.itab_off = 0;
     if (rc != JTP_OK) return rc;
-    if (hp.tmix) {
+    if (hp.tmix || p.unit) {
         tk.tmap_off = (int64_t)itab.size();
         itab.insert(itab.end(), p.tmap.begin(), p.tmap.end());
     }
     for (size_t k = 0; k < src.size(); ++k) {
         tk.msg[k].off = src[k].first;
-        tk.msg[k].npart = src[k].second;
+        tk.msg[k].npart = src[k].second < 0 ? 1 : src[k].second;
+        tk.msg[k].fixed = src[k].second < 0 ? 1 : 0;
         tk.msg[k].same_launch = 0;
     }
     blocks.clear();
@@ -2142,7 +2346,7 @@ void json_msg(std::ostringstream &o, const JtMsg &m, int nF) {
     o << ",\"t_w\":";
     json_list(o, m.t_w, m.t_w + 8);
     o << ",\"red_e\":" << m.red_e << ",\"red_lane\":" << m.red_lane << ",\"red_wave\":" << m.red_wave
-      << ",\"e_dep\":" << m.e_dep << ",\"same_launch\":" << m.same_launch << ",\"f_w\":";
+      << ",\"e_dep\":" << m.e_dep << ",\"same_launch\":" << m.same_launch << ",\"fixed\":" << m.fixed << ",\"f_w\":";
     json_list(o, m.f_w, m.f_w + nF);
     o << ",\"f_p\":";
     json_list(o, m.f_p, m.f_p + nF);
@@ -2163,17 +2367,33 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
       << ",\"multiset\":" << (hp.multiset ? 1 : 0) << ",\"alg_table_bytes\":" << (long long)hp.alg_table_bytes
       << ",\"alg_msg_bytes\":" << (long long)hp.alg_msg_bytes
       << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
-      << ",\"n_blocks\":" << hp.blocks.size();
-    o << ",\"pnodes\":[";
+      << ",\"n_blocks\":" << hp.blocks.size() << ",\"lean\":" << (hp.lean ? 1 : 0) << ",\"has_unit\":" << (hp.has_unit ? 1 : 0)
+      << ",\"fix_doubles\":" << hp.fix_doubles << ",\"scratch_elems\":" << hp.scratch_elems << ",\"alg_bytes_full\":" << (long long)hp.alg_bytes_full;
+    o << ",\"statics\":[";
+    for (size_t i = 0; i < hp.statics.size(); ++i) {
+        const PStatic &st = hp.statics[i];
+        if (i) o << ",";
+        o << "{\"pnode\":" << st.pnode << ",\"nbits\":" << st.nbits << ",\"off\":" << st.off << ",\"vars\":";
+        json_vec(o, st.vars);
+        o << ",\"pos\":";
+        json_vec(o, st.pos);
+        o << ",\"nb\":";
+        json_vec(o, st.nb);
+        o << "}";
+    }
+    o << "],\"pnodes\":[";
     for (size_t i = 0; i < hp.pn.size(); ++i) {
         const PNode &p = hp.pn[i];
         if (i) o << ",";
         o << "{\"real\":" << p.real << ",\"parent\":" << p.parent << ",\"psep\":" << p.psep << ",\"depth\":" << p.depth
           << ",\"owner\":" << p.owner << ",\"nbits\":" << p.nbits << ",\"arena_off\":" << p.arena_off
           << ",\"phys_elems\":" << p.phys_elems << ",\"pad_mask\":" << p.pad_mask << ",\"tmix\":" << (p.tmix ? 1 : 0) << ",\"trow\":" << p.trow
-          << ",\"tpad_mask\":" << p.tpad_mask << ",\"tsplit\":" << p.tsplit << ",\"tsplit_lb\":" << p.tsplit_lb << ",\"tmap_off\":" << p.tmap_off << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task << ",\"down_tasks\":";
+          << ",\"tpad_mask\":" << p.tpad_mask << ",\"tsplit\":" << p.tsplit << ",\"tsplit_lb\":" << p.tsplit_lb << ",\"tmap_off\":" << p.tmap_off << ",\"layout\":" << p.layout << ",\"collect_task\":" << p.collect_task << ",\"distribute_task\":" << p.distribute_task
+          << ",\"unit\":" << (p.unit ? 1 : 0) << ",\"stat\":" << p.stat << ",\"cover\":";
+        json_vec(o, p.cover);
+        o << ",\"down_tasks\":";
         json_vec(o, p.down_tasks);
-        if (hp.tmix) {
+        if (hp.tmix || p.unit) {
             o << ",\"tmap\":";
             json_vec(o, p.tmap);
         }
@@ -2275,7 +2495,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         for (size_t t = 0; t < hp.tasks.size(); ++t) {
             const JtTask &tk = hp.tasks[t];
             if (t) o << ",";
-            o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
+            o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"unit\":" << tk.unit << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
               << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"keep_rows\":" << tk.keep_rows << ",\"tmap_off\":" << tk.tmap_off << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";

@@ -40,6 +40,13 @@ struct PNode {                       // a clique of the (binarised) tree
     int64_t tmap_off = -1;           // offset (ints) of tmap in HostPlan::itab
     int collect_task = -1, distribute_task = -1;
     std::vector<int> down_tasks;     // multi-set plans: one task per child (its downward message), child order
+    // UNIT cliques (JtTask::unit): no table on the device.  Virtual cliques of the binarisation, cliques that hold no factor,
+    // and cliques whose factors cover only `cover` of their variables (jtp_tree_desc.cover_*): the product of those factors is a
+    // STATIC table over the covered variables (HostPlan::statics[stat]) that every task of the clique stages like one more
+    // incoming message; the reference never materialises the other axes either (junctiontree.py:52-61)
+    bool unit = false;
+    std::vector<int> cover;          // covered variables (real cliques of plans that were given jtp_tree_desc.cover_*)
+    int stat = -1;                   // index into HostPlan::statics, -1: all ones
 };
 
 struct PSep {                        // a separator = one message tensor per direction
@@ -93,6 +100,15 @@ struct Segment {
     int ticket_idx = 0;              // word of the sync buffer
 };
 
+// static table of a unit clique: a plain bit field over the covered variables (PNode::cover) in the clique's device order,
+// 2^nbits doubles at offset `off` of the plan's FIXED arena (one copy, outside the alternating halves of the message arena)
+struct PStatic {
+    int pnode = -1;
+    std::vector<int> vars, pos, nb;
+    int nbits = 0;
+    int64_t off = -1;                // doubles, in the fixed arena; -1: the clique is another rank's
+};
+
 struct VirtualFill { JtPackDesc d; };   // all-ones table of a virtual clique (1 where the index names an entry, else 0)
 
 struct HostPlan;
@@ -129,6 +145,8 @@ struct PlanKnobs {
     double tmix_fill = 0.6;                                         // JTP_TMIX_FILL: mixed-radix rows for cliques whose bit-field thread part would be emptier than this
     int esum_always = 0;                                            // JTP_EXPERIMENT_ESUM_ALWAYS: multi-set tasks keep summing a vector's elements first whatever the evidence (timing experiment, wrong results)
     double keep_rows_mb = 128.0;                                      // JTP_KEEP_ROWS_MB: table rows of the levels nearest the root, up to this many MiB, are loaded with the default cache policy (0: all non-temporal; A/B on one box: config 4 0.6037 -> 0.5990 ms, an 8-rank share of it 198.5 -> 195.4 us)
+    int no_unit = 0;                                                // JTP_NO_UNIT: no unit cliques - every clique (virtual ones too) keeps a full table (rounds 1-4)
+    double unit_ratio = 4.0;                                        // JTP_UNIT_RATIO: a clique becomes a unit clique when its table is at least this many times its covered part
     int marg_group = JT_MAX_OUT;                                    // JTP_MARG_GROUP: marginals of one belief table formed by one pass over it (1: a pass each, round 3)
     int marg_block_log2 = 0;                                        // JTP_MARG_BLOCK_LOG2: log2 of the elements per workgroup of a marginal pass (0: the 64 rows a workgroup can hold)
     int merge_phases = -1;                                          // JTP_MERGE_PHASES: 1 / 0 = both phases in one dataflow launch / never; -1: where messages are small
@@ -159,6 +177,16 @@ struct HostPlan {
     std::vector<int32_t> itab;           // iteration tables of all tasks (JtTask::itab_off)
     std::vector<uint32_t> block_chunk;   // chunk number of each block (description/tests)
     std::vector<VirtualFill> virtual_fills;
+    std::vector<PStatic> statics;        // static tables of unit cliques (PNode::stat)
+    int64_t fix_doubles = 0;             // size of the fixed arena (doubles)
+    std::vector<JtPackDesc> stat_pack;   // per real clique with a static table: host array of the clique (axes of uncovered variables have
+                                         // length 1) <-> the static table (dev_off = PStatic::off); nvars = 0 for the others
+    bool lean = false;                   // the description named covered variables (jtp_tree_desc.cover_*)
+    bool has_unit = false;               // some task of this rank's is a unit task
+    std::vector<std::vector<int>> cover; // per real clique (lean plans)
+    int64_t scratch_elems = 0;           // largest table of a unit clique (elements as it WOULD be stored) + the two shared rows: size of the
+                                         // scratch arena beliefs of unit cliques are formed in on demand (jtp_get_belief)
+    double alg_bytes_full = 0;           // algorithmic bytes with every clique counted at its full shape (SURVEY.md 8d to the letter)
     std::vector<CommOp> comm;
     std::vector<Step> steps;
     std::vector<Segment> segments;

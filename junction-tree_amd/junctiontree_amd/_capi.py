@@ -46,6 +46,8 @@ class TreeDesc(C.Structure):
         ("lds_budget", C.c_int32),
         ("block_log2", C.c_int32),
         ("layout_policy", C.c_int32),
+        ("cover_off", C.POINTER(C.c_int32)),
+        ("cover_ids", C.POINTER(C.c_int32)),
     ]
 
 
@@ -80,6 +82,10 @@ class Stats(C.Structure):
         ("foreign_seen", C.c_int32),
         ("f64_flops", C.c_double),
         ("f64_insts", C.c_double),
+        ("algorithmic_bytes_full", C.c_double),
+        ("fixed_bytes", C.c_double),
+        ("n_unit_cliques", C.c_int32),
+        ("n_static_tables", C.c_int32),
     ]
 
 

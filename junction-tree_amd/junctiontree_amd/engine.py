@@ -57,7 +57,7 @@ class Plan:
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
                  layout_policy=0, split_variants=False, keep_root=False, level_launches=False,
-                 flow_tickets=False, share_potentials=False, multiset=False, no_compact=False, root=None):
+                 flow_tickets=False, share_potentials=False, multiset=False, no_compact=False, root=None, cover=None):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
@@ -128,6 +128,21 @@ class Plan:
                       _int_array(psep), _int_array(self.owner)]
         d.var_card, d.node_var_off, d.node_var_ids, d.parent_clique, d.parent_sep, d.clique_owner = \
             [C.cast(a, C.POINTER(C.c_int32)) for a in self._keep]
+        # `cover`: which variables of each clique its potential depends on (the union of its factors' variables; the reference
+        # leaves the others length-1 axes and never materialises them, junctiontree.py:52-61) - {clique: labels} or a list
+        # indexed by the caller's clique index; None: every clique keeps a full table
+        self.cover = None
+        if cover is not None:
+            self.cover = {c: [lab for lab in cover[c] if lab not in self._trivial] for c in cliques}
+            coff, cids = [0], []
+            for c in cliques:
+                unknown = [lab for lab in self.cover[c] if lab not in node_vars[c]]
+                if unknown:
+                    raise ValueError("clique %r: covered variable %r is not one of its variables" % (c, unknown[0]))
+                cids += [labels[lab] for lab in self.cover[c]]
+                coff.append(len(cids))
+            self._keep += [_int_array(coff), _int_array(cids)]
+            d.cover_off, d.cover_ids = [C.cast(a, C.POINTER(C.c_int32)) for a in self._keep[-2:]]
         d.n_cliques = len(cliques)
         d.n_nodes = len(self.node_ids)
         d.dtype = self.dtype
@@ -401,7 +416,8 @@ class Plan:
                 "distribute_ms": st.distribute_ms, "kernels": kernels, "flow_fallbacks": st.flow_fallbacks,
                 "launch_mode": ("level", "flow", "flow_tickets")[st.launch_mode], "tickets_used": st.tickets_used,
                 "flow_propagates": st.flow_propagates, "device_bytes": st.device_bytes, "f64_flops": st.f64_flops, "f64_insts": st.f64_insts,
-                "foreign_seen": st.foreign_seen}
+                "foreign_seen": st.foreign_seen, "algorithmic_bytes_full": st.algorithmic_bytes_full, "fixed_bytes": st.fixed_bytes,
+                "n_unit_cliques": st.n_unit_cliques, "n_static_tables": st.n_static_tables}
 
 
 _DIGEST_LIMIT = 1 << 20          # bytes: larger factor tables are handed over again on every call rather than compared
@@ -654,9 +670,11 @@ def plan_for(tree, node_vars, sizes, dtype, return_key=False, **kwargs):
     order, parent, parent_sep, _ = flatten_tree(tree)
     used = list(order) + [parent_sep[c] for c in order if parent[c] != -1]
     labels = set(lab for n in used for lab in node_vars[n])
+    cover = kwargs.get("cover")
     key = (_freeze(tree), tuple((n, tuple(node_vars[n])) for n in used),
            tuple(sorted((repr(k), int(sizes[k])) for k in labels)),
-           dtype, tuple(sorted(kwargs.items())))
+           dtype, tuple(sorted((k, v) for k, v in kwargs.items() if k != "cover")),
+           None if cover is None else tuple(tuple(cover[c]) for c in order))
     plan = _cache.pop(key, None)
     if plan is not None:
         _cache_stats["hits"] += 1

@@ -145,6 +145,39 @@ class JunctionTree:
     _opts: dict = field(default_factory=dict, compare=False, repr=False)
     _memo: dict = field(default_factory=dict, compare=False, repr=False)
 
+    # what a tree remembers between calls (a weak reference to its device plan, derived tables) is not part of its value:
+    # a tree pickles and copies like the reference's, before and after it has been used
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_memo"] = {}
+        return state
+
+    def __setstate__(self, state):
+        for k, v in state.items():
+            object.__setattr__(self, k, v)
+
+    def cover(self):
+        """Per clique, the variables its potential depends on: the union of the variables of the factors assigned to it
+        (`junctiontree.py:203-226` - evaluate leaves every other variable of the clique a length-1 axis, `:52-61`).  The device
+        plan keeps no full-size table for a clique that is mostly such axes (`engine.Plan(cover=...)`)."""
+        ct = self.clique_tree
+        mark = (tuple(map(tuple, ct.factor_graph.factors)), tuple(ct.factor_to_maxclique))
+        hit = self._memo.get("cover")
+        if hit is not None and hit[0] == mark:
+            return hit[1]
+        cover = [[] for _ in ct.maxcliques]
+        scalar = [False] * len(ct.maxcliques)
+        for fvars, mc in zip(ct.factor_graph.factors, ct.factor_to_maxclique):
+            scalar[mc] = scalar[mc] or len(fvars) == 0
+            for v in fvars:
+                if v not in cover[mc]:
+                    cover[mc].append(v)
+        for mc, clique in enumerate(ct.maxcliques):
+            if scalar[mc]:                                   # (a factor without variables is a value no axis carries: the clique keeps its table)
+                cover[mc] = list(clique)
+        self._memo["cover"] = (mark, cover)
+        return cover
+
     def plan(self, dtype="f64"):
         """The device plan for the current variable sizes (sizes are read at call time, as
         `junctiontree.py:311` does: the reference's tests condition on evidence by setting
@@ -155,14 +188,15 @@ class JunctionTree:
         # the plan cache's key names the whole structure (1-2 ms to build for a thousand cliques): a tree remembers the key
         # and a weak reference to the plan it was last given for (dtype, the sizes as they are NOW, its options)
         sizes = self.clique_tree.factor_graph.sizes
-        mark = (dtype, tuple(sizes.items()), tuple(sorted(self._opts.items())))
+        cover = self.cover()
+        mark = (dtype, tuple(sizes.items()), tuple(sorted(self._opts.items())), id(cover))
         hit = self._memo.get("plan")
         if hit is not None and hit[0] == mark:
             plan = engine.cached_plan(hit[1], hit[2]())
             if plan is not None:
                 return plan
         node_vars = [list(c) for c in self.clique_tree.maxcliques] + [list(s) for s in self.separators]
-        plan, key = engine.plan_for(self.tree, node_vars, sizes, dtype, return_key=True, **self._opts)
+        plan, key = engine.plan_for(self.tree, node_vars, sizes, dtype, return_key=True, cover=cover, **self._opts)
         self._memo["plan"] = (mark, key, weakref.ref(plan))
         return plan
 

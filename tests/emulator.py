@@ -33,10 +33,11 @@ class Emulator:
         self.psi = np.zeros(max(desc["arena_elems"], 1), dtype=np.float64)
         self.bel = np.zeros_like(self.psi)
         self.msg = np.full(max(desc["msg_doubles"], 1), np.nan)     # NaN = never written
+        self.fix = np.zeros(max(desc.get("fix_doubles", 0), 1))     # static tables of unit cliques (one copy, outside the message arena)
         self.row = 1 << self.TB                                     # elements of one row; rows 0 / 1 of the arenas are shared:
         assert desc["arena_elems"] >= 2 * self.row                  # row 0 all zero (rows that do not exist), row 1 scratch
         for p in desc["pnodes"]:                                    # virtual cliques: resident 0/1 tables
-            if p["real"] < 0 and p["arena_off"] >= 0:
+            if p["real"] < 0 and p["arena_off"] >= 0 and not p.get("unit"):
                 cards = p["card"]
                 n = int(np.prod(cards)) if cards else 1
                 digits = np.unravel_index(np.arange(n), cards) if cards else ()
@@ -73,8 +74,36 @@ class Emulator:
         assert len(np.unique(phys)) == len(phys) and phys.max(initial=0) < p["phys_elems"]     # a table entry, a place
         return phys
 
+    def _msg_index(self, layout, host_vars, cards):
+        """index into a plain bit-field table (a message, a static table) of every C-order element over `host_vars`; variables the
+        table does not have are broadcast"""
+        pos = {v: layout["pos"][i] for i, v in enumerate(layout["vars"])}
+        n = int(np.prod(cards)) if cards else 1
+        digits = np.unravel_index(np.arange(n), cards) if cards else ()
+        x = np.zeros(n, dtype=np.int64)
+        for v, dig in zip(host_vars, digits):
+            if v in pos:
+                x += dig.astype(np.int64) << pos[v]
+        return x
+
     def set_potential(self, clique, host_vars, cards, array):
         p = self.d["pnodes"][clique]
+        if p.get("unit"):
+            # no table: the potential may only depend on the covered variables - it is the clique's static table
+            arr = np.asarray(array, dtype=np.float64)
+            arr = arr.reshape(arr.shape if arr.ndim == len(cards) else [1] * len(cards))
+            cov = [v in p["cover"] for v in host_vars]
+            assert all(arr.shape[i] == 1 or cov[i] for i in range(len(cards))), "a unit clique's potential depends on an uncovered variable"
+            if p["stat"] < 0:
+                assert arr.size == 1 and float(arr.reshape(-1)[0]) == 1.0
+                return
+            st = self.d["statics"][p["stat"]]
+            cvars = [v for v, c in zip(host_vars, cov) if c]
+            ccards = [k for k, c in zip(cards, cov) if c]
+            full = np.broadcast_to(arr.reshape([arr.shape[i] for i in range(len(cards)) if cov[i]]), ccards)
+            self.fix[st["off"]:st["off"] + (1 << st["nbits"])] = 0.0
+            self.fix[st["off"] + self._msg_index(st, cvars, ccards)] = full.ravel()
+            return
         x = self._dev_index(clique, host_vars, cards)
         lo = p["arena_off"]
         self.psi[lo:lo + p["phys_elems"]] = 0.0
@@ -82,6 +111,22 @@ class Emulator:
 
     def belief(self, clique, host_vars, cards):
         p = self.d["pnodes"][clique]
+        if p.get("unit"):
+            # no belief table is kept: psi (the static table, broadcast) x every incoming message, as the read-out tasks form it
+            size = lambda s: 1 << s["nbits"]
+            tot = np.ones(int(np.prod(cards)) if cards else 1)
+            if p["stat"] >= 0:
+                st = self.d["statics"][p["stat"]]
+                tot = tot * self.fix[st["off"] + self._msg_index(st, host_vars, cards)]
+            if p["psep"] >= 0:
+                s = self.d["pseps"][p["psep"]]
+                idx = self._msg_index(s, host_vars, cards)
+                tot = tot * sum(self.msg[s["dn_roff"] + k * size(s) + idx] for k in range(s["dn_rnpart"]))
+            for ch in p["children"]:
+                s = self.d["pseps"][self.d["pnodes"][ch]["psep"]]
+                idx = self._msg_index(s, host_vars, cards)
+                tot = tot * sum(self.msg[s["up_roff"] + k * size(s) + idx] for k in range(s["up_rnpart"]))
+            return tot.reshape(cards)
         x = self._dev_index(clique, host_vars, cards)
         return self.bel[p["arena_off"] + x].reshape(cards)
 
@@ -151,7 +196,7 @@ class Emulator:
         if record is not None:      # the host-decoded workgroup record must agree with the bit decode
             assert record[20] == lxF and (record[21] & 1) == (0 if chunk_ok else 1)       # (bit 1: JT_BLOCK_KEEP_ROWS, a cache-policy hint)
             if chunk_ok:
-                assert record[0] == xF and record[11] == tk["psi_off"] + xF
+                assert record[0] == xF and record[11] == tk["psi_off"] + xF and (not tk.get("unit") or tk["psi_off"] == 0)
                 assert list(record[12:20]) == list(tk["first_x"])
             else:
                 assert record[0] == 0 and record[11] == 0 and all(v == NO_ROW for v in record[12:20])
@@ -163,6 +208,10 @@ class Emulator:
             s = np.arange(1 << m["nfree"], dtype=np.int64)
             idx = _scatter(s, m["free_pos"])
             tot = np.zeros(len(s))
+            if m.get("fixed"):      # the clique's static table: one copy in the fixed arena, never "unwritten"
+                assert m["npart"] == 1 and not m["same_launch"] and tk["unit"]
+                subs.append(self.fix[m["off"] + gb_in[k] + idx])
+                continue
             for p in range(m["npart"]):
                 tot = tot + self.msg[m["off"] + p * m["pstride"] + gb_in[k] + idx]
             if strict:      # dataflow order: every entry read was written by an earlier workgroup
@@ -261,11 +310,19 @@ class Emulator:
             assert tk["tmap_off"] == pn["tmap_off"] or tk["tmap_off"] >= 0
         else:
             tmap = slot
+        unit = bool(tk.get("unit"))
+        assert unit == bool(pn.get("unit")) and (not unit or ("tmap" in pn and tk["tmap_off"] >= 0))
         x = (xF + xoff[:, :, None, None] + np.maximum(tmap, 0)[None, None, :, :]) & 0xFFFFFFFF
         live = np.broadcast_to(row_ok[:, :, None, None], x.shape) & np.broadcast_to((tmap >= 0)[None, None, :, :], x.shape)
         assert x[live].max(initial=0) < pn["phys_elems"]
         assert len(np.unique(x[live])) == x[live].size            # every stored element visited at most once
-        p = np.where(live, self.psi[tk["psi_off"] + np.where(live, x, 0)], 0.0)      # rows that do not exist read zeros
+        if unit:
+            # a unit clique: every entry that exists counts as 1 - and the entries that exist are exactly the clique's table
+            # (counted over the task's workgroups, checked at the end of the propagate)
+            tk["_live"] = tk.get("_live", 0) + int(live.sum())
+            p = np.where(live, 1.0, 0.0)
+        else:
+            p = np.where(live, self.psi[tk["psi_off"] + np.where(live, x, 0)], 0.0)      # rows that do not exist read zeros
         vals = []
         for k, m in enumerate(ins):
             slot = (in_off[k][:, :, None, None]
@@ -293,6 +350,7 @@ class Emulator:
             for v in vals[npar:]:
                 b = b * v
             if tk["bel_off"] >= 0:
+                assert not unit
                 self.bel[tk["bel_off"] + x[live]] = b[live]
         for j, m in enumerate(outs):
             slot = (out_off[j][:, :, None, None]
@@ -333,6 +391,13 @@ class Emulator:
                 tk = d["tasks"][blk[0]]
                 self._block(tk, blk[1], tk["mode"] == 0, blk[2:], strict=True)
         assert covered == list(range(len(d["launches"])))
+        self._check_unit_counts()
+
+    def _check_unit_counts(self):
+        for tk in self.d["tasks"]:
+            if tk["kind"] == 0 and "_live" in tk:
+                cards = self.d["pnodes"][tk["pnode"]]["card"]
+                assert tk.pop("_live") == (int(np.prod(cards)) if cards else 1), "a unit task did not visit exactly its clique's entries"
 
     def propagate(self, comm=None):
         """Run the plan's step list.  `comm(ops, msg)` executes one exchange group (a list of the
@@ -360,3 +425,4 @@ class Emulator:
                 seen.add((t, chunk))
                 self._block(tk, chunk, tk["mode"] == 0, blk[2:])
             assert len(seen) == len(blocks) == sum(1 << d["tasks"][t]["nF"] for t in launch["tasks"])
+        self._check_unit_counts()

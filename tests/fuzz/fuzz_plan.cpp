@@ -16,7 +16,8 @@
 #include "../../junction-tree_amd/csrc/jtp_plan.h"
 
 struct Desc {
-    std::vector<int32_t> card, off, ids, parent, psep, owner;
+    std::vector<int32_t> card, off, ids, parent, psep, owner, coff, cids;
+    bool with_cover = false;
     jtp_tree_desc d;
 };
 
@@ -57,6 +58,16 @@ static void build(std::mt19937 &rng, Desc &t, int n_ranks) {
     }
     t.owner.assign(N, 0);
     for (int c = 0; c < N; ++c) t.owner[c] = (int)(rng() % (unsigned)n_ranks);
+    // which variables each clique's potential depends on (jtp_tree_desc.cover_*): none, some or all of its own
+    t.with_cover = rng() % 2 == 0;
+    t.coff.assign(1, 0);
+    t.cids.clear();
+    for (int c = 0; c < N; ++c) {
+        const unsigned mode = rng() % 4;                       // 0: none, 1: all, else: a random subset
+        for (int v : cv[c])
+            if (mode == 1 || (mode >= 2 && rng() % 2)) t.cids.push_back(v);
+        t.coff.push_back((int)t.cids.size());
+    }
     memset(&t.d, 0, sizeof t.d);
     t.d.struct_size = sizeof t.d;
     t.d.n_vars = (int)t.card.size();
@@ -80,12 +91,16 @@ static void point(Desc &t) {
     t.d.parent_clique = t.parent.data();
     t.d.parent_sep = t.psep.data();
     t.d.clique_owner = t.owner.data();
+    t.d.cover_off = t.with_cover ? t.coff.data() : nullptr;
+    t.d.cover_ids = t.with_cover ? t.cids.data() : nullptr;
 }
 
 static const char *damage(std::mt19937 &rng, Desc &t) {
     const int N = t.d.n_cliques;
     auto pick = [&](int n) { return (int)(rng() % (unsigned)std::max(n, 1)); };
-    switch (rng() % 14) {
+    switch (rng() % 16) {
+        case 14: t.with_cover = true; if (!t.cids.empty()) t.cids[pick((int)t.cids.size())] = pick(t.d.n_vars + 2) - 1; return "covered variable not of the clique / unknown / twice";
+        case 15: t.with_cover = true; t.coff[pick((int)t.coff.size())] -= 1 + pick(3); return "cover offsets not monotone";
         case 0: t.parent[pick(N)] = pick(N); return "random parent (cycle / two roots / self)";
         case 1: t.parent[pick(N)] = N + 5; return "parent out of range";
         case 2: if (N > 1) t.psep[1 + pick(N - 1)] = pick(2 * N + 3) - 2; return "separator node out of range or reused";
@@ -115,7 +130,9 @@ static bool consistent(const HostPlan &hp, std::string &why) {
     for (size_t t = 0; t < hp.tasks.size(); ++t) {
         const JtTask &tk = hp.tasks[t];
         if (tk.kind != 0 || !runs[t]) continue;
-        if (tk.psi_off < 0 || tk.psi_off + hp.pn[tk.pnode].phys_elems > std::max<int64_t>(hp.arena_elems, 1) + 256) return why = "psi_off outside the arena", false;
+        if (tk.unit != (hp.pn[tk.pnode].unit ? 1 : 0)) return why = "unit task of a clique that keeps a table (or the reverse)", false;
+        if (tk.unit && (tk.psi_off != 0 || tk.bel_off >= 0)) return why = "unit task with a table", false;
+        if (!tk.unit && (tk.psi_off < 0 || tk.psi_off + hp.pn[tk.pnode].phys_elems > std::max<int64_t>(hp.arena_elems, 1) + 256)) return why = "psi_off outside the arena", false;
         {   // every row a workgroup of the task touches lies inside the table (or is marked as not existing)
             const int64_t phys = hp.pn[tk.pnode].phys_elems;
             int64_t fmax = 0;
@@ -128,7 +145,7 @@ static bool consistent(const HostPlan &hp, std::string &why) {
             (void)fmax;
         }
         if (tk.itab_off < 0 || tk.itab_off + (int64_t)tk.total * JT_NCOL > (int64_t)hp.itab.size()) return why = "iteration table outside the buffer", false;
-        if (hp.tmix) {          // every entry of the clique's thread map: -1 or an offset inside a row
+        if (hp.tmix || tk.unit) {          // every entry of the clique's thread map: -1 or an offset inside a row
             if (tk.tmap_off < 0 || tk.tmap_off + ((int64_t)1 << hp.TB) > (int64_t)hp.itab.size()) return why = "thread map outside the buffer", false;
             for (int64_t x = 0; x < ((int64_t)1 << hp.TB); ++x) {
                 const int32_t po = hp.itab[tk.tmap_off + x];
@@ -137,7 +154,8 @@ static bool consistent(const HostPlan &hp, std::string &why) {
         } else if (tk.tmap_off != -1) return why = "thread map in a plan without one", false;
         for (int k = 0; k < tk.n_in + tk.n_out; ++k) {
             const JtMsg &m = tk.msg[k < tk.n_in ? k : JT_MAX_IN + (k - tk.n_in)];
-            if (m.off < 0 || m.off + (int64_t)m.npart * m.pstride > hp.msg_doubles) return why = "message outside the arena", false;
+            if (m.fixed && (k >= tk.n_in || !tk.unit || m.npart != 1 || m.off < 0 || m.off + m.pstride > hp.fix_doubles)) return why = "static table outside the fixed arena", false;
+            if (!m.fixed && (m.off < 0 || m.off + (int64_t)m.npart * m.pstride > hp.msg_doubles)) return why = "message outside the arena", false;
             if (m.nfree < 0 || m.nfree > JT_MAX_FREE) return why = "sub-box too large", false;
         }
     }
