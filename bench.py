@@ -33,6 +33,7 @@ runtime into the process and RCCL's communicator init fails.
 """
 
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -61,7 +62,22 @@ def multiset_roofline(stats, ms, alg_bytes):
             "pipe_occupancy_note": "float64 vector instructions (a multiplication holds the pipe as long as a fused multiply-add) / %.1f T lane instructions/s measured" % F64_PEAK_TINSTS,
             "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps": alg_bytes / (ms * 1e-3) / 1e9, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --batch 64 --multiset)"}}
-TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
+TRAFFIC_CASES_FILE = os.path.join("profiles", "r05_hbm_traffic_cases.json")
+
+
+def case_traffic(case, source_id):
+    """HBM bytes per step of one of the other configs, from the committed rocprofv3 PMC passes (tools/collect_profiles.sh) - quoted
+    only when that file was measured on THIS build of the library.  (bytes or None, where from)"""
+    try:
+        with open(os.path.join(ROOT, TRAFFIC_CASES_FILE)) as fh:
+            prof = json.load(fh)
+        if prof.get("source_id") != source_id:
+            return None, "%s is of library build %s, the running one is %s: not quoted" % (TRAFFIC_CASES_FILE, prof.get("source_id"), source_id)
+        rec = prof["cases"][case]
+        return rec["hbm_bytes_per_step"], "%s, measured on library build %s (= the running one; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)" % (TRAFFIC_CASES_FILE, source_id)
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
 REF_OVER_PORT_FILE = os.path.join("tests", "golden", "ref_over_port.json")
 
 
@@ -75,6 +91,21 @@ def reference_over_port():
         return float(rec["reference_over_port_time"]), REF_OVER_PORT_FILE + " (oracle/time_reference.py, build container)"
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+class _stdout_to_stderr:
+    """RCCL prints a version banner on file descriptor 1 when a communicator is made; this process's standard output is ONE JSON
+    line - whatever a library writes to fd 1 inside this block goes to standard error instead."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def _cpu_model():
@@ -203,9 +234,11 @@ def _sub_result(workload, alg_bytes, messages, wall_ms, dev_ms, steps, parity, *
     return out
 
 
-def sub_c2(device, steps=20):
+def sub_c2(device, source_id, steps=20):
     """configs[1]: chain of 1000 cliques of 64^3 doubles.  Parity: calibration - the separator marginal of two adjacent
-    cliques agrees wherever it is taken, every belief sums to Z (five places along the chain)."""
+    cliques agrees wherever it is taken, every belief sums to Z (five places along the chain).  A single chain is a sequence of
+    dependent hand-overs (latency-bound): `four_chains_in_flight` is the same workload with the chip given
+    something to overlap - four evidence sets, one stream each, ticket order."""
     import numpy as np
     from junctiontree_amd import engine, synthetic
     spec = synthetic.chain_tree(n_cliques=1000, card=64, width=3)
@@ -219,14 +252,30 @@ def sub_c2(device, steps=20):
         for c in (0, 250, 499, 750, 998):
             a, b = plan.marginals([(c, [c + 1, c + 2]), (c + 1, [c + 1, c + 2])])
             worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(a))), abs(float(a.sum()) - z) / abs(z))
-        return _sub_result("BASELINE.json configs[1]: chain of 1000 cliques, width 3, cardinality 64, float64", alg["total"], alg["messages"],
-                           wall, dev, steps, {"kind": "calibration", "rel_err": worst, "tolerance": 1e-9, "ok": bool(worst <= 1e-9)},
-                           dtype="f64", Z=z, launches_per_step=plan.stats()["n_launches"])
+        launches = plan.stats()["n_launches"]
     finally:
         plan.close()
+    four = None
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", device=device, n_batch=4)
+    try:
+        for b in range(4):
+            plan.fill_synthetic(1 + b, spec["scales"], batch=b)
+        w4, d4 = _timed(plan, max(steps // 2, 5))
+        four = {"workload": "four such chains (evidence sets with their own tables) in flight, one HIP stream each", "ms_per_step": w4,
+                "ms_per_chain": w4 / 4, "value": 4 * alg["total"] / (w4 * 1e-3) / 1e9, "unit": "GB/s",
+                "frac": 4 * alg["total"] / (w4 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "messages_per_sec": 4 * alg["messages"] / (w4 * 1e-3)}
+    finally:
+        plan.close()
+    sample = synthetic.chain_tree(n_cliques=100, card=64, width=3)
+    traffic, src = case_traffic("c2", source_id)
+    return _sub_result("BASELINE.json configs[1]: chain of 1000 cliques, width 3, cardinality 64, float64", alg["total"], alg["messages"],
+                       wall, dev, steps, {"kind": "calibration", "rel_err": worst, "tolerance": 1e-9, "ok": bool(worst <= 1e-9)},
+                       dtype="f64", Z=z, launches_per_step=launches, four_chains_in_flight=four,
+                       cpu_baseline=cpu_baseline(sample, 8, "chain of 100 of the 1000 cliques, same clique shape"),
+                       traffic=traffic, traffic_source=src)
 
 
-def sub_c3(device, steps=10, api_calls=5, lattice_w=167):
+def sub_c3(device, source_id, steps=10, api_calls=5, lattice_w=167):
     """configs[2] as restated in SURVEY.md 8d (6 x 167 lattice MRF, cardinality 8, float32), twice: the hot path
     (collect + distribute with the clique potentials resident) and the whole API call tree.propagate(values) with every
     factor table new (H2D of the factor tables, evaluate, collect + distribute, factor marginals, D2H)."""
@@ -248,7 +297,14 @@ def sub_c3(device, steps=10, api_calls=5, lattice_w=167):
         tables = sum(int(np.prod([sizes[v] for v in c])) for c in ct.maxcliques) * 4
         seps = sum(int(np.prod([sizes[v] for v in sp])) if len(sp) else 1 for sp in tree.separators) * 8
         root_table = int(np.prod([sizes[v] for v in ct.maxcliques[plan.root]])) * 4
-        alg = 3 * tables - root_table + 5 * seps
+        # Two byte counts.  SURVEY.md 8d to the letter: every clique at its FULL shape, read in both passes and its belief written
+        # (what rounds 1-4 streamed).  And what the problem needs: a clique's potential at the shape its factors COVER (the reference
+        # never materialises the other axes, junctiontree.py:52-61; a clique without factors has none), read once per pass, no
+        # belief tables (propagate returns factor marginals, :264-274), plus the messages - the engine's own accounting
+        # (jtp_stats.algorithmic_bytes), which since round 5 is what it moves.
+        alg_full = 3 * tables - root_table + 5 * seps
+        st0 = plan.stats()
+        alg = st0["algorithmic_bytes"]
         wall, dev = _timed(plan, steps)
         z = plan.z()
         api = []
@@ -275,15 +331,37 @@ def sub_c3(device, steps=10, api_calls=5, lattice_w=167):
                   "tolerance": 5e-6, "ok": bool(sum_err <= 5e-6 and worst < 5e-6)}
         wl = ("BASELINE.json configs[2] as restated in SURVEY.md 8d: 6 x %d lattice MRF, %d pairwise factors, cardinality 8, float32; "
               "junction tree by this repo's builder: %d cliques, max width %d" % (lattice_w, len(factors), n, max(len(c) for c in ct.maxcliques)))
+        traffic, src = case_traffic("c3", source_id)
+        d = plan.describe()
         hot = _sub_result(wl, alg, 2 * (n - 1), wall, dev, steps, parity, dtype="f32", Z=z, junction_tree_build_s=t_build,
-                          first_call_s=t_first, launches_per_step=plan.stats()["n_launches"])
+                          first_call_s=t_first, launches_per_step=plan.stats()["n_launches"],
+                          bytes_definition="covered-shape potentials (static tables of the cliques that hold factors, read once per pass) + messages; no belief tables",
+                          full_shape={"algorithmic_bytes_per_step": alg_full, "value": alg_full / (wall * 1e-3) / 1e9, "unit": "GB/s",
+                                      "frac": alg_full / (wall * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                      "definition": "SURVEY.md 8d to the letter: every clique at its full shape, read in both passes, belief written"},
+                          cliques_without_table=st0["n_unit_cliques"], static_tables=st0["n_static_tables"],
+                          device_table_bytes=int(d["arena_elems"]) * 4 + int(st0["fixed_bytes"]), full_shape_table_bytes=tables,
+                          traffic=traffic, traffic_source=src, cpu_baseline=cpu_baseline_lattice(6, 20, 8))
+        # the column-sweep tree of SURVEY.md 8d beside it (one clique per eliminated variable, 2-3 of 7 variables covered)
+        try:
+            t0 = time.perf_counter()
+            sweep = jt.create_junction_tree(factors, sizes, order=synthetic.lattice_column_order(6, lattice_w))
+            sweep.propagate(values)
+            sp_plan = sweep.plan("f32")
+            sw_wall, sw_dev = _timed(sp_plan, max(steps // 2, 3))
+            sst = sp_plan.stats()
+            hot["column_sweep_tree"] = {"cliques": len(sweep.clique_tree.maxcliques), "ms_per_step": sw_wall, "device_ms_per_step": sw_dev,
+                                        "algorithmic_bytes_per_step": sst["algorithmic_bytes"], "cliques_without_table": sst["n_unit_cliques"],
+                                        "full_shape_algorithmic_bytes_per_step": sst["algorithmic_bytes_full"], "Z": sp_plan.z(),
+                                        "setup_s": time.perf_counter() - t0}
+        except Exception as exc:          # noqa: BLE001 - recorded, not raised
+            hot["column_sweep_tree"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         api_ms = min(api)
         # the API call moves, beyond the hot path's bytes: the tables of the cliques that hold factors written once more
         # (evaluate; the others stay all ones) and their beliefs read once more (marginalize: the requests on one clique
         # share the pass); the factor tables in and the factor marginals out are under 2 MB
-        held = sorted(set(ct.factor_to_maxclique))
-        factor_tables = sum(int(np.prod([sizes[v] for v in ct.maxcliques[c]])) for c in held) * 4
-        api_alg = alg + 2 * factor_tables
+        # beyond the hot path's bytes: the potentials written once (evaluate) and read once more by the marginal passes
+        api_alg = alg + 2 * (int(d["arena_elems"]) * 4 + int(st0["fixed_bytes"]))
         e2e = {"workload": wl + "; tree.propagate(values) with all %d factor tables new: H2D, evaluate (%d cliques formed), collect + "
                                  "distribute, %d factor marginals, D2H" % (len(factors), staged, len(factors)),
                "ms_per_step": api_ms, "ms_per_step_median": sorted(api)[len(api) // 2], "steps": api_calls,
@@ -295,7 +373,7 @@ def sub_c3(device, steps=10, api_calls=5, lattice_w=167):
         engine.clear_plan_cache()
 
 
-def sub_c5(device, spec, n_sets=64, steps=10, oracle_sets=1):
+def sub_c5(device, spec, source_id, n_sets=64, steps=10, oracle_sets=1):
     """configs[4] on one device = one rank's share of the 512 evidence sets: 64 sets over the shared width-20 tables
     (JTP_MULTISET).  Parity: Z of `oracle_sets` sets against the numpy oracle on indicator-multiplied potentials, and a
     marginal of every set sums to that set's Z."""
@@ -346,15 +424,22 @@ def sub_c5(device, spec, n_sets=64, steps=10, oracle_sets=1):
         st = plan.stats()
         parity = {"kind": "Z of %d evidence set(s) vs oracle (indicator-multiplied potentials, %.1f s of numpy); every set: a marginal sums to its Z" % (oracle_sets, t_oracle),
                   "Z_rel_err": zerr, "marginal_sums_rel_err": worst, "tolerance": 1e-6, "ok": bool(zerr <= 1e-6 and worst <= 1e-6)}
+        roof = multiset_roofline(st, dev, alg)
+        roof["hbm"]["traffic"], roof["hbm"]["traffic_source"] = case_traffic("multiset64", source_id)
+        # the CPU beside it: the oracle run above IS one evidence set of this workload on one host core
+        per_set = (2 * tables + 5 * seps)
+        cpu = {"value": per_set * oracle_sets / t_oracle / 1e9, "unit": "GB/s", "messages_per_sec": 2 * (n - 1) * oracle_sets / t_oracle,
+               "cores": 1, "kind": "port", "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
+               "sample": "%d evidence set(s) of this workload (oracle.beliefs_exact on indicator-multiplied potentials), %.1f s wall" % (oracle_sets, t_oracle)}
         return _sub_result("BASELINE.json configs[4], one rank's share: %d evidence sets (16 observed variables each) over the shared tables of the "
                            "width-20 tree, JTP_MULTISET" % n_sets, alg, 2 * (n - 1) * n_sets, wall, dev, steps, parity, dtype="f32",
-                           evidence_sets_per_step=n_sets, ms_per_evidence_set=wall / n_sets, roofline=multiset_roofline(st, dev, alg),
-                           engine_table_bytes_per_step=st["algorithmic_bytes"], launches_per_step=st["n_launches"])
+                           evidence_sets_per_step=n_sets, ms_per_evidence_set=wall / n_sets, roofline=roof,
+                           engine_table_bytes_per_step=st["algorithmic_bytes"], launches_per_step=st["n_launches"], cpu_baseline=cpu)
     finally:
         plan.close()
 
 
-def sub_rank_share(device, spec, world=8, steps=30):
+def sub_rank_share(device, spec, world=8, steps=30, single_ms=None):
     """What one GPU can say about the 8-GPU run of configs[3] (no 8-GPU node has been available to the driver): every rank's share
     of the partitioned tree timed ALONE on this GPU, the exchange at the cuts replaced by fills of the receive buffers
     (JTP_FAKE_COMM).  A projection aid - the slowest share bounds the sharded step from below, the RCCL exchange comes on top -
@@ -363,30 +448,69 @@ def sub_rank_share(device, spec, world=8, steps=30):
     n = spec["n_cliques"]
     root, _, owner = partition.partition_tree(spec["parent"], [1.0] * n, world, replicate_top=True)
     old = os.environ.get("JTP_FAKE_COMM")
-    os.environ["JTP_FAKE_COMM"] = "1"
-    per_rank = []
-    try:
+    per_rank, per_rank_rccl, n_ops = [], [], []
+
+    def shares(mode, out):
+        os.environ["JTP_FAKE_COMM"] = mode
         for rank in range(world):
             plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", device=device, n_ranks=world, rank=rank,
                                owner=owner, root=root)
             try:
                 plan.fill_synthetic(1, spec["scales"])
                 wall, dev = _timed(plan, steps)
-                per_rank.append(dev * 1e3)
+                out.append(dev * 1e3)
+                if mode == "2":
+                    n_ops.append((sum(1 for op in plan.describe()["comm"] if op["send"]), sum(1 for op in plan.describe()["comm"] if not op["send"])))
             finally:
                 plan.close()
+
+    loop_err = None
+    try:
+        shares("1", per_rank)
+        # ... and the same shares with the exchange step as what a sharded run issues there: ONE RCCL group of the step's
+        # ncclSend / ncclRecv calls on the plan's stream, between the collect launch and the merged launch - in loop-back (a
+        # communicator of one rank, every call addressed to this rank itself): the group's own cost on this GPU, no wire
+        import ctypes as C
+        from junctiontree_amd import _capi
+        lib = _capi.lib()
+        try:
+            buf = C.create_string_buffer(128)
+            with _stdout_to_stderr():
+                _capi.check(lib.jtp_comm_unique_id(buf))
+                _capi.check(lib.jtp_comm_init(0, 1, C.c_char_p(buf.raw), device))
+            try:
+                shares("2", per_rank_rccl)
+            finally:
+                with _stdout_to_stderr():
+                    lib.jtp_comm_destroy()
+        except Exception as exc:          # noqa: BLE001 - recorded, not raised
+            loop_err = "%s: %s" % (type(exc).__name__, exc)
     finally:
         if old is None:
             os.environ.pop("JTP_FAKE_COMM", None)
         else:
             os.environ["JTP_FAKE_COMM"] = old
-    return {"workload": "BASELINE.json configs[3] cut for %d ranks (top part replicated): each rank's share run alone on ONE GPU, exchanges "
-                        "replaced by fills (JTP_FAKE_COMM) - a projection aid, not a multi-GPU measurement" % world,
-            "device_us_per_rank_share": per_rank, "slowest_share_us": max(per_rank), "steps": steps,
-            "cliques_per_rank": [sum(1 for o in owner if o in (r, world)) for r in range(world)]}
+    out = {"workload": "BASELINE.json configs[3] cut for %d ranks (top part replicated): each rank's share run alone on ONE GPU, exchanges "
+                       "replaced by fills (JTP_FAKE_COMM=1) and by the real RCCL group in loop-back (JTP_FAKE_COMM=2) - a projection aid, not a "
+                       "multi-GPU measurement" % world,
+           "device_us_per_rank_share": per_rank, "slowest_share_us": max(per_rank), "steps": steps,
+           "cliques_per_rank": [sum(1 for o in owner if o in (r, world)) for r in range(world)]}
+    if per_rank_rccl:
+        diffs = sorted(b - a for a, b in zip(per_rank, per_rank_rccl))
+        out.update({"device_us_per_rank_share_rccl_loopback": per_rank_rccl, "slowest_share_rccl_loopback_us": max(per_rank_rccl),
+                    "rccl_group_us_loopback": diffs[len(diffs) // 2],
+                    "rccl_group_note": "median over the ranks of (share with the exchange as ONE grouped %d x ncclSend + %d x ncclRecv of 8 KiB to self on the "
+                                       "plan's stream) - (share with fills): what the group costs on this GPU; the xGMI hop of a real run comes on top"
+                                       % (n_ops[0][0], n_ops[0][1])})
+        if single_ms:
+            out["projected_speedup_at_%d_ranks" % world] = {"with_fills": single_ms * 1e3 / max(per_rank), "with_rccl_group_loopback": single_ms * 1e3 / max(per_rank_rccl),
+                                                            "single_gpu_ms_per_step": single_ms, "target": 3.5}
+    if loop_err:
+        out["rccl_loopback_error"] = loop_err
+    return out
 
 
-def sub_configs(device, spec_c4):
+def sub_configs(device, spec_c4, source_id, single_ms):
     """Run the sub-configs one after the other; a failure is recorded in its place, never raised (the headline line stands)."""
     out = {}
     t_all = time.perf_counter()
@@ -407,10 +531,10 @@ def sub_configs(device, spec_c4):
             out[name] = res
         return time.perf_counter() - t0
 
-    secs = {"c2": guard("c2", lambda: sub_c2(device)),
-            "c3": guard(("c3", "c3_api_end_to_end"), lambda: sub_c3(device)),
-            "c5_multiset64": guard("c5_multiset64", lambda: sub_c5(device, spec_c4)),
-            "c4_rank_share_of_8": guard("c4_rank_share_of_8", lambda: sub_rank_share(device, spec_c4))}
+    secs = {"c2": guard("c2", lambda: sub_c2(device, source_id)),
+            "c3": guard(("c3", "c3_api_end_to_end"), lambda: sub_c3(device, source_id)),
+            "c5_multiset64": guard("c5_multiset64", lambda: sub_c5(device, spec_c4, source_id)),
+            "c4_rank_share_of_8": guard("c4_rank_share_of_8", lambda: sub_rank_share(device, spec_c4, single_ms=single_ms))}
     out["wall_s"] = dict(secs, total=time.perf_counter() - t_all)
     return out
 
@@ -467,6 +591,7 @@ def spawn_ranks(args, argv):
 
 
 def main():
+    faulthandler.enable()              # (a fault inside the library says where, instead of ending the run without a word)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)      # 200 x 0.65 ms: the timed region is not inside box-to-box noise
@@ -528,8 +653,10 @@ def main():
         raise SystemExit("--config c3 runs on one GPU")
     if args.config == "c3" and (args.batch != 1 or args.share or args.multiset or args.split_variants or args.dtype != "f32"):
         raise SystemExit("--config c3 is one float32 evidence set: --batch / --share / --multiset / --split-variants / --dtype do not apply")
-    if (args.share or args.multiset) and world != 1:
-        raise SystemExit("evidence sets are independent: replicas only (every rank its own sets), no sharded run")
+    # Evidence sets are independent (BASELINE configs[4]: "512 sets, 8 MI355X"): with N ranks every rank takes ITS OWN --batch
+    # sets over its own copy of the tables - replicas only, no exchange on the data path; the line's value is the sum over the
+    # ranks and "scaling" is weak (per-GPU work fixed).
+    replicas = (args.share or args.multiset) and world > 1
 
     # host-only work that starts processes: before this process makes its first HIP call
     all_cores = None
@@ -565,10 +692,12 @@ def main():
         uid = None
         if rank == 0:
             buf = C.create_string_buffer(128)
-            _capi.check(lib.jtp_comm_unique_id(buf))
+            with _stdout_to_stderr():
+                _capi.check(lib.jtp_comm_unique_id(buf))
             uid = buf.raw
         uid = rdzv.broadcast(uid)
-        _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid), device))
+        with _stdout_to_stderr():
+            _capi.check(lib.jtp_comm_init(rank, world, C.c_char_p(uid), device))
 
     def barrier():
         rdzv.barrier()
@@ -601,9 +730,13 @@ def main():
         tables = sum(int(np.prod([sizes[v] for v in c])) for c in ct.maxcliques) * 4
         seps = sum(int(np.prod([sizes[v] for v in s])) if len(s) else 1 for s in tree.separators) * 8
         root_table = int(np.prod([sizes[v] for v in ct.maxcliques[plan.root]])) * 4
-        alg = {"read": 2 * tables - root_table + 2 * seps, "write": tables + 3 * seps, "messages": 2 * (n - 1)}
-        alg["total"] = alg["read"] + alg["write"]
-        lattice = {"tree": tree, "factors": factors, "values": values, "t_build": t_build,
+        alg_full = 3 * tables - root_table + 5 * seps        # SURVEY.md 8d to the letter: every clique at its full shape, belief written
+        st0 = plan.stats()
+        # what the problem needs (and the engine moves): potentials at the shape their factors cover, no belief tables, the messages
+        alg = {"total": st0["algorithmic_bytes"], "write": 3 * seps, "messages": 2 * (n - 1)} if plan.cover is not None else \
+              {"total": alg_full, "write": tables + 3 * seps, "messages": 2 * (n - 1)}
+        alg["read"] = alg["total"] - alg["write"]
+        lattice = {"tree": tree, "factors": factors, "values": values, "t_build": t_build, "alg_full": alg_full, "stats": st0,
                    "max_width": max(len(c) for c in ct.maxcliques)}
         spec = None
     else:
@@ -621,9 +754,11 @@ def main():
         # (re-rooted at the weighted centroid first, SURVEY.md 8e: the balanced tree of config 4 is rooted there already,
         #  a chain handed over with its end as the root is hung from its middle)
         part_root, _, owner = partition.partition_tree(spec["parent"], [1.0] * n, world, replicate_top=not args.no_replicate_top)
+        if replicas:
+            part_root, owner = None, None
         plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=args.dtype,
-                           device=device, n_ranks=world, rank=rank, owner=owner, n_batch=args.batch,
-                           root=part_root if world > 1 else None,
+                           device=device, n_ranks=1 if replicas else world, rank=0 if replicas else rank, owner=owner, n_batch=args.batch,
+                           root=part_root if world > 1 and not replicas else None,
                            block_log2=args.block_log2, lds_budget=args.lds_budget,
                            layout_policy=args.layout_policy, split_variants=args.split_variants,
                            level_launches=args.level_launches, share_potentials=args.share, multiset=args.multiset)
@@ -631,7 +766,7 @@ def main():
             plan.fill_synthetic(1, spec["scales"])
             labels = sorted(spec["sizes"])
             for b in range(args.batch):
-                rng = np.random.default_rng(1000 + b + 64 * rank)
+                rng = np.random.default_rng(1000 + b + args.batch * rank)          # (rank r of N holds sets r * batch .. of the N * batch)
                 plan.set_evidence({labels[i]: int(rng.integers(0, spec["sizes"][labels[i]]))
                                    for i in rng.choice(len(labels), size=16, replace=False)}, batch=b)
         else:
@@ -680,7 +815,22 @@ def main():
     stats = plan.stats()
     z = plan.z() if plan.owns(plan.root) else None
     belief_dev = None
-    if world > 1:                                    # the rank holding the root clique knows Z: share it
+    rccl_info = per_rank_ms = None
+    if world > 1:
+        # what RCCL itself says about the communicator, and every rank's own step time, gathered on rank 0
+        import ctypes as C2
+        nr, ur, cd = C2.c_int32(-1), C2.c_int32(-1), C2.c_int32(-1)
+        lib.jtp_comm_info(C2.byref(nr), C2.byref(ur), C2.byref(cd))
+        mine_rec = json.dumps({"rank": rank, "device": device, "ncclCommCount": nr.value, "ncclCommUserRank": ur.value, "ncclCommCuDevice": cd.value,
+                               "ms_per_step": region_ms / args.steps}).encode()
+        recs = [json.loads(x.decode()) for x in rdzv.allgather(mine_rec)]
+        rccl_info = {"ncclCommCount": sorted({r["ncclCommCount"] for r in recs}), "ranks": [{k: r[k] for k in ("rank", "device", "ncclCommUserRank", "ncclCommCuDevice")} for r in recs]}
+        per_rank_ms = [r["ms_per_step"] for r in recs]
+    if replicas:
+        # replicas: every rank checks its own first evidence set (a marginal sums to that set's Z), the worst goes into the line
+        m = plan.marginals([(n - 1, [spec["node_vars"][n - 1][0]])], batch=0)[0]
+        belief_dev = rdzv.allreduce_max(abs(float(m.sum()) - z) / abs(z))
+    elif world > 1:                                  # the rank holding the root clique knows Z: share it
         z = rdzv.allreduce_max(z if z is not None else -1.0e300)
         # ... and every rank checks the DISTRIBUTE side of the sharded run on cliques of its own (Z only proves the
         # collect side): a clique belief sums to Z whatever the clique.  First, middle and last clique a rank owns, one
@@ -701,7 +851,8 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        gbps = alg["total"] * args.batch * args.steps / elapsed / 1e9
+        nrep = world if replicas else 1                    # replicas: every rank ran the whole batch of ITS sets
+        gbps = alg["total"] * args.batch * nrep * args.steps / elapsed / 1e9
         if args.config == "c2":
             workload = "BASELINE.json configs[1]: chain of %d cliques, width 3, cardinality 64, float64" % n
         elif args.config == "c3":
@@ -715,19 +866,20 @@ def main():
             "metric": "clique-potential GB/s (algorithmic bytes per propagate / time; messages/sec alongside), "
                       + ("synthetic width-%d tree" % args.width if args.config == "c4" else "config %s" % args.config),
             "value": gbps, "unit": "GB/s",
-            "messages_per_sec": alg["messages"] * args.batch * args.steps / elapsed,
-            "read_GBps": alg["read"] * args.batch * args.steps / elapsed / 1e9,
+            "messages_per_sec": alg["messages"] * args.batch * nrep * args.steps / elapsed,
+            "read_GBps": alg["read"] * args.batch * nrep * args.steps / elapsed / 1e9,
             "frac_of_hbm_roofline": gbps / (HBM_PEAK_GBPS * world),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
                 "workload": workload,
-                "algorithmic_bytes_per_step": alg["total"] * args.batch, "messages_per_step": alg["messages"] * args.batch,
-                "evidence_sets_per_step": args.batch, "shared_potentials": bool(args.share or args.multiset),
+                "algorithmic_bytes_per_step": alg["total"] * args.batch * nrep, "messages_per_step": alg["messages"] * args.batch * nrep,
+                "evidence_sets_per_step": args.batch * nrep, "evidence_sets_per_rank": args.batch, "shared_potentials": bool(args.share or args.multiset),
                 "multiset": bool(args.multiset),
                 "engine_table_bytes_per_step": stats["algorithmic_bytes"] if args.multiset else None,
-                "parallelism": "1 GPU" if world == 1 else "subtree-sharded x%d, RCCL send/recv at cuts%s" % (world, "" if args.no_replicate_top else ", top part replicated"),
+                "parallelism": "1 GPU" if world == 1 else ("replicas x%d: every rank its own %d evidence sets over its own copy of the tables, no exchange" % (world, args.batch) if replicas else
+                                                          "subtree-sharded x%d, RCCL send/recv at cuts%s" % (world, "" if args.no_replicate_top else ", top part replicated")),
                 "launches_per_step": stats["n_launches"], "launch_mode": stats["launch_mode"],
                 "idle_plans": args.idle_plans, "Z": z, "library": version,
             },
@@ -806,6 +958,12 @@ def main():
             out["config"]["Z_expected"] = Z_DEFAULT_C4
             out["config"]["Z_rel_err"] = abs(z - Z_DEFAULT_C4) / Z_DEFAULT_C4
         if world > 1:
+            out["config"]["rccl"] = rccl_info
+            out["config"]["ms_per_step_per_rank"] = per_rank_ms
+        if replicas:
+            out["config"]["replica_marginal_sums_rel_err"] = belief_dev       # (every rank: a marginal of its first evidence set vs that set's Z)
+            out["config"]["multi_gpu_note"] = "replicas only: RCCL is initialised (the communicator's size is in config.rccl) and carries no data"
+        elif world > 1:
             out["config"]["sharded_belief_sums_rel_err"] = belief_dev      # (three cliques per rank: sum of the belief vs Z)
             out["config"]["multi_gpu_note"] = ("transport: %s" % os.environ["JTP_RCCL_LIB"] if os.environ.get("JTP_RCCL_LIB")
                                                else "transport: RCCL (librccl.so.1), ncclSend/ncclRecv grouped per cut level")
@@ -830,12 +988,18 @@ def main():
                              "calibration_rel_err": worst, "tolerance": 5e-6,
                              "ok": bool(np.max(np.abs(sums - z)) <= 5e-6 * z and worst < 5e-6)}
             out["config"]["junction_tree_build_s"] = lattice["t_build"]
+            out["config"]["bytes_definition"] = ("covered-shape potentials + messages, no belief tables (what the reference's evaluate / propagate leave, "
+                                                 "junctiontree.py:52-61, 264-274)" if plan.cover is not None else "SURVEY.md 8d: every clique at its full shape")
+            out["config"]["full_shape"] = {"algorithmic_bytes_per_step": lattice["alg_full"], "value": lattice["alg_full"] * args.steps / elapsed / 1e9, "unit": "GB/s",
+                                           "frac": lattice["alg_full"] * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS,
+                                           "definition": "SURVEY.md 8d to the letter: every clique at its full shape, read in both passes, belief written"}
+            out["config"]["cliques_without_table"] = lattice["stats"]["n_unit_cliques"]
         run_subs = (default_c4 and world == 1 and args.batch == 1 and not args.no_configs and args.cpu_sample != 0 and not args.level_launches
                     and not args.split_variants and not args.per_launch and args.idle_plans == 0
                     and args.block_log2 == 0 and args.lds_budget == 0 and args.layout_policy == 0)
         if run_subs:
             plan.close()                 # (its 2 GiB of arenas are not needed any more; config 3 wants 18)
-            out["configs"] = sub_configs(device, spec)
+            out["configs"] = sub_configs(device, spec, source_id, ms_per_step)
         print(json.dumps(out), flush=True)
 
     for p in idle:

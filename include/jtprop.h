@@ -276,6 +276,9 @@ int jtp_comm_unique_id(void *id128);
 /* Collective: every rank calls it once before creating plans with n_ranks > 1. */
 int jtp_comm_init(int32_t rank, int32_t n_ranks, const void *id128, int32_t device);
 int jtp_comm_destroy(void);
+/* What the communicator itself reports: ncclCommCount, ncclCommUserRank, ncclCommCuDevice (-1 where the loaded library lacks
+ * the entry point).  A multi-rank benchmark line quotes it, so that its reader sees RCCL saw N ranks. */
+int jtp_comm_info(int32_t *n_ranks, int32_t *rank, int32_t *device);
 /* Diagnostic: send `n` doubles from this rank to itself through the communicator (grouped
  * ncclSend + ncclRecv on a private stream) and verify them.  Exercises the RCCL binding on a
  * single GPU, where no second rank can exist. */

@@ -65,13 +65,35 @@ def build(force=False, verbose=True, extra=(), out=None, jobs=None):
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
              '-DJTP_SOURCE_ID="%s"' % sid] + list(extra)
     objdir = tempfile.mkdtemp(prefix="jtprop_build_")
+    # objects of translation units whose sources did not change are taken from a cache beside the library (git-ignored):
+    # a planner-only change recompiles jtp_plan.cpp and the engine, not the twelve kernel instantiation units
+    cache = os.path.join(LIBDIR, "objcache")
+    os.makedirs(cache, exist_ok=True)
+    import hashlib
+    headers = {"jtp_plan.cpp": ["jtp_plan.h", "jtp_internal.h", os.path.join("..", "..", "include", "jtprop.h")],
+               "jtp_engine.hip": ["jtp_plan.h", "jtp_internal.h", "jtp_kernels.hip.h", os.path.join("..", "..", "include", "jtprop.h")]}
     try:
         def compile_one(src):
             obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-            cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            h = hashlib.sha256()
+            for d in [src] + headers.get(src, ["jtp_internal.h", "jtp_kernels.hip.h"]):
+                with open(os.path.join(CSRC, d), "rb") as fh:
+                    h.update(d.encode() + b"\0" + fh.read())
+            # (the source id is compiled into the engine only: the other units do not change with it)
+            tu_flags = [f for f in flags if not f.startswith("-DJTP_SOURCE_ID") or src == "jtp_engine.hip"]
+            h.update(" ".join(tu_flags).encode())
+            kept = os.path.join(cache, os.path.splitext(src)[0] + "." + h.hexdigest()[:16] + ".o")
+            if os.path.exists(kept):
+                shutil.copy(kept, obj)
+                return obj
+            cmd = [hipcc] + tu_flags + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            for old in os.listdir(cache):               # one object per unit and flag set is enough
+                if old.startswith(os.path.splitext(src)[0] + ".") and len(os.listdir(cache)) > 64:
+                    os.remove(os.path.join(cache, old))
+            shutil.copy(obj, kept)
             return obj
         # (the template translation units take 1-2 GiB of compiler each: at most eight at once, JTP_BUILD_JOBS overrides)
         jobs = jobs or int(os.environ.get("JTP_BUILD_JOBS", 0)) or max(1, min(len(SOURCES), os.cpu_count() or 2, 8))

@@ -59,6 +59,7 @@ typedef int (*Send_t)(const void *, size_t, int, int, ncclComm_t, hipStream_t);
 typedef int (*Recv_t)(void *, size_t, int, int, ncclComm_t, hipStream_t);
 typedef int (*Group_t)(void);
 typedef const char *(*ErrStr_t)(int);
+typedef int (*CommQuery_t)(const ncclComm_t, int *);
 
 static void *lib = nullptr;
 static GetUniqueId_t GetUniqueId;
@@ -68,6 +69,7 @@ static Send_t Send;
 static Recv_t Recv;
 static Group_t GroupStart, GroupEnd;
 static ErrStr_t GetErrorString;
+static CommQuery_t CommCount = nullptr, CommUserRank = nullptr, CommCuDevice = nullptr;      // (optional: what the communicator itself says)
 static ncclComm_t comm = nullptr;
 static int comm_rank = 0, comm_size = 1;
 
@@ -93,6 +95,9 @@ static int load() {
     SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    CommCount = (CommQuery_t)dlsym(lib, "ncclCommCount");
+    CommUserRank = (CommQuery_t)dlsym(lib, "ncclCommUserRank");
+    CommCuDevice = (CommQuery_t)dlsym(lib, "ncclCommCuDevice");
     return JTP_OK;
 }
 }  // namespace rccl
@@ -303,7 +308,9 @@ struct jtp_plan {
     bool chain = false;             // the plan is made of latency-bound levels (JtTask::settle): distribute runs the build without spills
     uint32_t *host_abort = nullptr; // pinned: set by a workgroup that gave up waiting
     int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
-    bool fake_comm = false;         // JTP_FAKE_COMM
+    int fake_comm = 0;              // JTP_FAKE_COMM: 1 = what a rank would receive is filled with ones, what it would send goes nowhere;
+                                    // 2 = the exchange steps run as REAL RCCL groups in loop-back (every ncclSend / ncclRecv of the step
+                                    // addressed to this rank itself, on the plan's stream, between the launches as in a sharded run)
     bool esum_dirty = false;        // multi-set plans: JtTask::esum_groups changed on the host since the last upload
     bool psi_dirty = false;         // shared potentials were written (on stream 0) since the last propagate
     std::vector<MargBatch *> marg_cache;
@@ -632,7 +639,11 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     }
     // JTP_FAKE_COMM=1 (development aid): run ONE rank's share of a multi-rank plan on its own; what
     // it would receive is filled with ones, what it would send goes nowhere.  Timing only.
-    pl->fake_comm = hp.n_ranks > 1 && hp.knobs.fake_comm != 0;
+    pl->fake_comm = hp.n_ranks > 1 ? hp.knobs.fake_comm : 0;
+    if (pl->fake_comm == 2 && (!rccl::comm || rccl::comm_size != 1)) {
+        delete pl;
+        return set_err(JTP_ECOMM, "JTP_FAKE_COMM=2 (exchange steps as RCCL groups in loop-back) needs a communicator of ONE rank: jtp_comm_init(0, 1, ...)");
+    }
     if (hp.n_ranks > 1 && !pl->fake_comm && (!rccl::comm || rccl::comm_size != hp.n_ranks || rccl::comm_rank != hp.rank)) {
         delete pl;
         return set_err(JTP_ECOMM, "n_ranks=%d but jtp_comm_init was not called with a matching communicator", hp.n_ranks);
@@ -1443,6 +1454,29 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 fl.blk_base = (uint32_t)L.blk_off;
                 launch_variant(pl, L.variant, L.nblocks, L.lds_bytes, s, pl->d_tasks, pl->d_blocks + L.blk_off, pl->d_itab, bb.psi, bb.bel, bb.msg, fl);
                 if (per_launch) HIP_TRY(hipEventRecord(pl->ev[ev_base + 2 * st.first + 1], s));
+            } else if (pl->fake_comm == 2) {
+                // loop-back: the step's sends and receives as one RCCL group addressed to this rank itself (RCCL pairs the k-th
+                // send to a peer with the k-th receive from it: a receive without a send of its own takes this rank's first
+                // outgoing message, a send without a receive lands in a spare buffer) - the real cost of the group on this GPU,
+                // without the wire
+                std::vector<const CommOp *> sends, recvs;
+                for (int i = st.first; i < st.first + st.count; ++i) (hp.comm[i].send ? sends : recvs).push_back(&hp.comm[i]);
+                const size_t n = std::max(sends.size(), recvs.size());
+                int64_t most = 0;
+                for (int i = st.first; i < st.first + st.count; ++i) most = std::max(most, hp.comm[i].count);
+                const int rc2 = ensure_stage(pl, (size_t)most * 8 * 2);
+                if (rc2) return rc2;
+                double *spare = (double *)pl->stage;
+                NCCL_TRY(rccl::GroupStart());
+                for (size_t k = 0; k < n; ++k) {
+                    const CommOp *sd = k < sends.size() ? sends[k] : nullptr, *rv = k < recvs.size() ? recvs[k] : nullptr;
+                    const int64_t cnt = rv ? rv->count : sd->count;
+                    const double *src = sd && sd->count >= cnt ? bb.msg + fl.cur_off + sd->off : spare + most;
+                    double *dst = rv ? bb.msg + fl.cur_off + rv->off : spare;
+                    NCCL_TRY(rccl::Send(src, (size_t)cnt, rccl::ncclFloat64, rccl::comm_rank, rccl::comm, s));
+                    NCCL_TRY(rccl::Recv(dst, (size_t)cnt, rccl::ncclFloat64, rccl::comm_rank, rccl::comm, s));
+                }
+                NCCL_TRY(rccl::GroupEnd());
             } else if (pl->fake_comm) {
                 for (int i = st.first; i < st.first + st.count; ++i) {
                     const CommOp &op = hp.comm[i];
@@ -2061,6 +2095,19 @@ int jtp_comm_init(int32_t rank, int32_t n_ranks, const void *id128, int32_t devi
     NCCL_TRY(rccl::CommInitRank(&rccl::comm, n_ranks, id, rank));
     rccl::comm_rank = rank;
     rccl::comm_size = n_ranks;
+    return JTP_OK;
+}
+
+// What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 where the library has no such
+// entry point): a multi-rank benchmark line carries it, so that the reader sees RCCL saw N ranks.
+int jtp_comm_info(int32_t *n_ranks, int32_t *rank, int32_t *device) {
+    if (!rccl::comm) return set_err(JTP_ECOMM, "communicator not initialised");
+    int v = -1;
+    if (n_ranks) *n_ranks = (rccl::CommCount && rccl::CommCount(rccl::comm, &v) == rccl::ncclSuccess) ? v : -1;
+    v = -1;
+    if (rank) *rank = (rccl::CommUserRank && rccl::CommUserRank(rccl::comm, &v) == rccl::ncclSuccess) ? v : -1;
+    v = -1;
+    if (device) *device = (rccl::CommCuDevice && rccl::CommCuDevice(rccl::comm, &v) == rccl::ncclSuccess) ? v : -1;
     return JTP_OK;
 }
 

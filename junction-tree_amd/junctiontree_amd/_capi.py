@@ -132,6 +132,7 @@ SYMBOLS = {
     "jtp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "jtp_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "jtp_comm_destroy": (C.c_int, []),
+    "jtp_comm_info": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "jtp_comm_selftest": (C.c_int, [C.c_int32]),
     "jtp_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
     "jtp_device_memory": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -122,6 +122,25 @@ class Rendezvous:
         _send_msg(self.sock, struct.pack("<d", value))
         return struct.unpack("<d", _recv_msg(self.sock))[0]
 
+    def allgather(self, payload):
+        """bytes from every rank -> the list of all ranks' payloads (rank order), on every rank."""
+        if self.world <= 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(p) for p in self.peers]
+            blob = b"".join(struct.pack("<I", len(x)) + x for x in parts)
+            for p in self.peers:
+                _send_msg(p, blob)
+        else:
+            _send_msg(self.sock, payload)
+            blob = _recv_msg(self.sock)
+        out, at = [], 0
+        while at < len(blob):
+            (n,) = struct.unpack("<I", blob[at:at + 4])
+            out.append(blob[at + 4:at + 4 + n])
+            at += 4 + n
+        return out
+
     def barrier(self):
         self.allreduce_max(0.0)
 

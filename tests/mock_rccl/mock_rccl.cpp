@@ -162,6 +162,8 @@ int ncclCommDestroy(MockComm *c) {
     delete c;
     return bad;
 }
+int ncclCommCount(const MockComm *c, int *n) { *n = c->size; return 0; }
+int ncclCommUserRank(const MockComm *c, int *r) { *r = c->rank; return 0; }
 int ncclGroupStart(void) { ++depth; return 0; }
 int ncclGroupEnd(void) { return --depth == 0 ? flush() : 0; }
 int ncclSend(const void *buf, size_t count, int dtype, int peer, MockComm *c, hipStream_t s) {

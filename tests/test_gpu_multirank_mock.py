@@ -170,6 +170,29 @@ def test_bench_starts_its_own_ranks(gpus):
     assert out["value"] > 0 and out["ms_per_step"] > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", ["--multiset", "--share"])
+def test_bench_replicas_of_evidence_sets_over_two_ranks(flag):
+    """BASELINE configs[4] at N > 1 ("512 observation sets, 8 MI355X") is replicas only: `bench.py --gpus 2 --batch 8 --multiset`
+    gives every rank its own eight evidence sets over its own copy of the tables, no exchange; rank 0's line sums the ranks
+    (scaling "weak") and says what the communicator reports.  Here the two ranks share the box's one GPU (mock transport)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["JTP_RCCL_LIB"] = _build_mock()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-sample", "0",
+                          "--batch", "8", flag, "--cliques", "63", "--width", "16", "--sep", "8"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout.decode()
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and cfg["evidence_sets_per_step"] == 16 and cfg["evidence_sets_per_rank"] == 8
+    assert cfg["rccl"]["ncclCommCount"] == [2] and sorted(r["ncclCommUserRank"] for r in cfg["rccl"]["ranks"]) == [0, 1]
+    assert len(cfg["ms_per_step_per_rank"]) == 2 and cfg["replica_marginal_sums_rel_err"] <= 1e-6
+    assert "replicas" in cfg["parallelism"] and out["value"] > 0
+
+
 def test_bench_rank_failure_is_an_error():
     """Ranks that fail (here: a configuration the rank processes refuse) must fail the whole run with a non-zero
     exit code and no result line, not hang the parent.  Needs no GPU: the ranks exit before they load the library."""

@@ -12,9 +12,11 @@ for i in range(H):
         if i + 1 < H: factors.append([names[i, j], names[i + 1, j]])
         if j + 1 < W: factors.append([names[i, j], names[i, j + 1]])
 sizes = {v: K for v in names.values()}
-tree = jt.create_junction_tree(factors, sizes)
+order = [names[i, j] for j in range(W) for i in range(H)] if os.environ.get("C3_SWEEP") else None      # the column-sweep tree of SURVEY.md 8d
+tree = jt.create_junction_tree(factors, sizes, order=order)
 node_vars = [list(c) for c in tree.clique_tree.maxcliques] + [list(s) for s in tree.separators]
-plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32")
+# (C3_NO_COVER=1: every clique keeps a full table, as in rounds 1-4)
+plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", cover=None if os.environ.get("C3_NO_COVER") else tree.cover())
 plan.fill_synthetic(1, [8.0 ** -(len(c) - 1) for c in tree.clique_tree.maxcliques])
 for _ in range(2):
     plan.propagate()

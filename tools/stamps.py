@@ -16,9 +16,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "c3":
             if i + 1 < H: factors.append([names[i, j], names[i + 1, j]])
             if j + 1 < W: factors.append([names[i, j], names[i, j + 1]])
     sizes = {v: K for v in names.values()}
-    tree = jt.create_junction_tree(factors, sizes)
+    order = [names[i, j] for j in range(W) for i in range(H)] if os.environ.get("STAMPS_SWEEP") else None
+    tree = jt.create_junction_tree(factors, sizes, order=order)
     node_vars = [list(c) for c in tree.clique_tree.maxcliques] + [list(s) for s in tree.separators]
-    plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32")
+    # (STAMPS_NO_COVER=1: every clique keeps a full table, as in rounds 1-4)
+    plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", cover=None if os.environ.get("STAMPS_NO_COVER") else tree.cover())
     spec = {"scales": [8.0 ** -(len(c) - 1) for c in tree.clique_tree.maxcliques]}
 elif len(sys.argv) > 1 and sys.argv[1] == "c2":
     spec = synthetic.chain_tree(n_cliques=int(sys.argv[2]) if len(sys.argv) > 2 else 64, card=64, width=3)
