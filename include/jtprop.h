@@ -138,6 +138,11 @@ typedef struct jtp_stats {
     double  fixed_bytes;            /* bytes of the static tables of such cliques (per evidence set, or shared)            */
     int32_t n_unit_cliques;         /* cliques of the caller's tree that keep no table on the device                       */
     int32_t n_static_tables;        /* ... of which hold factors: their product is a static table over the covered variables */
+    int32_t flight_board;           /* 1: this process publishes its in-flight dataflow propagates on the device's shared-memory board
+                                       (/dev/shm/jtprop_flight_<PCI bus id>) and sees other processes'; 0: the board could not be opened
+                                       (another user's file, no /dev/shm): other PROCESSES on the device are then only noticed by the
+                                       2 s time-out; -1: no dataflow propagate has asked for it yet                              */
+    int32_t pad_stats;
 } jtp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -188,7 +193,8 @@ int jtp_set_potential_product(jtp_plan *plan, int32_t batch, int32_t clique, int
 
 /* The same for a LIST of cliques - all of CliqueGraph.evaluate (junctiontree.py:203-226: one helper einsum per clique)
  * as ONE host-to-device copy of every factor table and ONE kernel launch over all the listed cliques.  Clique cliques[i]
- * receives the product of factors[factor_off[i] .. factor_off[i+1]); a clique may be listed with no factors (all ones).
+ * receives the product of factors[factor_off[i] .. factor_off[i+1]); a clique may be listed with no factors (all ones),
+ * no clique may be listed twice (JTP_EINVAL).
  * The tables are copied before the call returns.  A caller that knows which factor tables changed since the last call
  * lists only their cliques (junctiontree_amd/junctiontree.py does). */
 int jtp_set_potential_products(jtp_plan *plan, int32_t batch, int32_t n_cliques, const int32_t *cliques,

@@ -333,7 +333,11 @@ struct jtp_plan {
 namespace board {
 struct Slot { std::atomic<int32_t> pid, count; };
 constexpr int SLOTS = 64;
-struct Board { Slot *slots = nullptr; int mine = -1; bool tried = false; };
+// Trust model: the board is advisory.  It is world-writable (any local user's process on the device must be able to publish), so
+// a hostile local user could pin every process to ticket order (10 % slower) or hide itself - never corrupt a result: a process that
+// is not seen falls under the 2 s time-out and its fall-back to level launches.  Liveness is `kill(pid, 0)`: processes in different
+// PID namespaces that share /dev/shm cannot check each other and treat every published count as live.
+struct Board { Slot *slots = nullptr; int mine = -1; bool tried = false; int32_t owner_pid = 0; };
 static Board g_board[64];
 static std::mutex g_mutex;
 
@@ -342,23 +346,36 @@ static bool alive(int32_t pid) { return pid > 0 && (kill((pid_t)pid, 0) == 0 || 
 static Board &open_board(int device) {
     Board &b = g_board[device & 63];
     std::lock_guard<std::mutex> lock(g_mutex);
-    if (b.tried) return b;
+    if (b.tried && b.owner_pid == (int32_t)getpid()) return b;
+    if (b.tried) {                                      // a forked child: the parent's mapping is there, its SLOT is not ours
+        b.mine = -1;
+        b.owner_pid = (int32_t)getpid();
+        if (!b.slots) return b;
+    } else {
     b.tried = true;
+    b.owner_pid = (int32_t)getpid();
     char bus[64] = "unknown";
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return b;
     for (char *c = bus; *c; ++c)
         if (*c == ':' || *c == '.') *c = '_';
     char name[128];
     snprintf(name, sizeof name, "/jtprop_flight_%s", bus);
-    const mode_t old = umask(0);
-    const int fd = shm_open(name, O_RDWR | O_CREAT, 0666);
-    umask(old);
+    // an existing board is opened as it is (O_CREAT on another user's file fails under fs.protected_regular); a new one is made
+    // exclusively and opened up with fchmod - the process umask is never touched (other threads may be creating files)
+    int fd = shm_open(name, O_RDWR, 0);
+    if (fd < 0 && errno == ENOENT) {
+        fd = shm_open(name, O_RDWR | O_CREAT | O_EXCL, 0600);
+        if (fd >= 0) (void)fchmod(fd, 0666);
+        else if (errno == EEXIST) fd = shm_open(name, O_RDWR, 0);          // (somebody else was first)
+    }
     if (fd < 0) return b;
-    if (ftruncate(fd, sizeof(Slot) * SLOTS) != 0) { close(fd); return b; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || ((size_t)sb.st_size < sizeof(Slot) * SLOTS && ftruncate(fd, sizeof(Slot) * SLOTS) != 0)) { close(fd); return b; }
     void *m = mmap(nullptr, sizeof(Slot) * SLOTS, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return b;
     b.slots = static_cast<Slot *>(m);
+    }
     const int32_t me = (int32_t)getpid();
     for (int pass = 0; pass < 2 && b.mine < 0; ++pass)
         for (int i = 0; i < SLOTS && b.mine < 0; ++i) {
@@ -383,10 +400,9 @@ static bool publish(int device, int n) {
         if (i == b.mine || b.slots[i].count.load() <= 0) continue;
         const int32_t owner = b.slots[i].pid.load();
         if (alive(owner)) others = true;
-        else {                                             // left behind by a process that died in flight
-            b.slots[i].count.store(0);
-            int32_t expect = owner;
-            b.slots[i].pid.compare_exchange_strong(expect, 0);
+        else {                                             // left behind by a process that died in flight: release the slot FIRST, and
+            int32_t expect = owner;                        // clear its count only if that release was ours (a new owner may have published)
+            if (owner != 0 && b.slots[i].pid.compare_exchange_strong(expect, 0)) b.slots[i].count.store(0);
         }
     }
     return others;
@@ -899,9 +915,13 @@ int jtp_set_potential_products(jtp_plan *pl, int32_t batch, int32_t n, const int
     std::vector<int64_t> offs((size_t)nfact), elems((size_t)nfact);
     size_t tbytes = 0;
     int npass = 1;
+    std::vector<char> listed((size_t)hp.n_cliques, 0);
     for (int i = 0; i < n; ++i) {
         const int clique = cliques[i];
         if (clique < 0 || clique >= hp.n_cliques) return set_err(JTP_EINVAL, "node %d is not a clique", clique);
+        // (every listed clique is formed by workgroups of ONE launch: a clique listed twice would be written by two of them)
+        if (listed[clique]) return set_err(JTP_EINVAL, "clique %d is listed twice", clique);
+        listed[clique] = 1;
         if (!(hp.pn[clique].owner == hp.rank || hp.pn[clique].owner == hp.n_ranks)) return set_err(JTP_EINVAL, "clique %d belongs to rank %d", clique, hp.pn[clique].owner);
         if (factor_off[i + 1] < factor_off[i]) return set_err(JTP_EINVAL, "bad factor list");
         const std::vector<int> &cvars = hp.node_vars[clique];
@@ -1930,6 +1950,10 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     st->device_bytes = pl->device_bytes;
     st->storage_dtype = hp.dtype;
     st->foreign_seen = pl->foreign_seen;
+    {
+        const board::Board &bd = board::g_board[hp.device & 63];
+        st->flight_board = !bd.tried ? -1 : (bd.slots && bd.mine >= 0 ? 1 : 0);
+    }
     st->algorithmic_bytes_full = hp.alg_bytes_full;
     st->fixed_bytes = (double)hp.fix_doubles * 8;
     for (int c = 0; c < hp.n_cliques; ++c) {

@@ -86,6 +86,8 @@ class Stats(C.Structure):
         ("fixed_bytes", C.c_double),
         ("n_unit_cliques", C.c_int32),
         ("n_static_tables", C.c_int32),
+        ("flight_board", C.c_int32),
+        ("pad_stats", C.c_int32),
     ]
 
 

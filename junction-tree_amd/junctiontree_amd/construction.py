@@ -63,7 +63,10 @@ def triangulate(factors, sizes, order=None):
     if len(set(forced)) != len(forced):
         raise ValueError("the elimination order lists a variable twice")
     forced.reverse()                                  # (popped from the end)
-    cost = {v: (fill_of(v), weight_of(v), rank[v]) for v in adj} if len(forced) < len(adj) else {}
+    # (costs are only looked at once the given order is used up: built then, for the variables that are left, and kept up to date
+    #  for the touched ones from there on - a partial order of k variables used to recompute every remaining variable's cost on
+    #  each of its k steps)
+    cost = {v: (fill_of(v), weight_of(v), rank[v]) for v in adj} if not forced else None
     remaining = set(adj)
     cliques, member_of = [], {v: [] for v in adj}
     while remaining:
@@ -86,8 +89,12 @@ def triangulate(factors, sizes, order=None):
             touched |= adj[a]
         remaining.discard(v)
         del adj[v]
-        if len(forced) < len(remaining):              # (costs are only looked at once the given order is used up)
-            for u in (touched if not forced else remaining):
+        if forced or not remaining:
+            continue
+        if cost is None:                              # the given order has just run out
+            cost = {u: (fill_of(u), weight_of(u), rank[u]) for u in remaining}
+        else:
+            for u in touched:
                 if u in remaining:
                     cost[u] = (fill_of(u), weight_of(u), rank[u])
 

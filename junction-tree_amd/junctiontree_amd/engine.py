@@ -417,7 +417,7 @@ class Plan:
                 "launch_mode": ("level", "flow", "flow_tickets")[st.launch_mode], "tickets_used": st.tickets_used,
                 "flow_propagates": st.flow_propagates, "device_bytes": st.device_bytes, "f64_flops": st.f64_flops, "f64_insts": st.f64_insts,
                 "foreign_seen": st.foreign_seen, "algorithmic_bytes_full": st.algorithmic_bytes_full, "fixed_bytes": st.fixed_bytes,
-                "n_unit_cliques": st.n_unit_cliques, "n_static_tables": st.n_static_tables}
+                "n_unit_cliques": st.n_unit_cliques, "n_static_tables": st.n_static_tables, "flight_board": st.flight_board}
 
 
 _DIGEST_LIMIT = 1 << 20          # bytes: larger factor tables are handed over again on every call rather than compared

@@ -1,6 +1,7 @@
 """Host-side functions of the drop-in API that need neither GPU nor libjtprop compute: checked against
 outputs captured from the unmodified reference (tests/golden/apply_evidence.npz, oracle/gen_golden.py)."""
 import numpy as np
+import pytest
 
 from junctiontree_amd import computation as comp
 
@@ -61,3 +62,25 @@ def test_elimination_order_gives_valid_junction_trees():
             assert set(seps[parent_sep[c] - len(cliques)]) == set(cliques[c]) & set(cliques[parent[c]])
     cliques, _ = cons.triangulate(factors, sizes, order=synthetic.lattice_column_order(4, 9))
     assert len(cliques) == 36 - 4 and max(len(c) for c in cliques) == 5
+
+
+def test_partial_elimination_orders_continue_with_min_fill():
+    """`triangulate(order=...)` with an order that names only some variables: those are eliminated first, greedy min-fill takes over
+    from there (the costs are built once when the given order runs out, not on every forced step)."""
+    from junctiontree_amd import construction as cons
+    rng = np.random.default_rng(3)
+    names = list(range(14))
+    factors = [[int(v) for v in rng.choice(14, size=int(rng.integers(2, 4)), replace=False)] for _ in range(20)]
+    sizes = {v: 2 for v in names}
+    used = sorted({v for f in factors for v in f})
+    full, _ = cons.triangulate(factors, sizes)
+    for k in (0, 1, 5, len(used)):
+        partial = [int(v) for v in rng.permutation(used)[:k]]
+        cliques, f2c = cons.triangulate(factors, sizes, order=partial)
+        for f, c in zip(factors, f2c):
+            assert set(f) <= set(cliques[c])
+        # the given prefix is honoured: eliminating it by hand and handing the whole order over gives the same cliques
+        if k == 0:
+            assert cliques == full
+    with pytest.raises(ValueError):
+        cons.triangulate(factors, sizes, order=[used[0], used[0]])
