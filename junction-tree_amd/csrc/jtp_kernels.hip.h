@@ -177,7 +177,9 @@ __device__ __forceinline__ uint32_t jt_sub_hi(const uint32_t (&fp)[4], int nfree
 // tables, JtMsg::fixed, staged like a message).  No row is loaded and no element ring is kept: which entries of a row exist
 // says the clique's thread map (read once), which rows exist the iteration table; the belief is stored only where the task
 // names a place for it (read-out tasks).  The reference never materialises such axes either (junctiontree.py:52-61).
-template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false, bool KEEP = false, bool UNIT = false>
+// BEL (unit tasks only): the belief is stored - by read-out tasks; the passes of a propagate leave it out at compile time (the
+// conversions and the store were a tenth of the distribute step's vector instructions).
+template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false, bool KEEP = false, bool UNIT = false, bool BEL = !UNIT>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
                                         double *__restrict__ msg_arena, const JtFlow &fl,
@@ -764,7 +766,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 }
                 b[e] = pref;
             }
-            if (!UNIT || wr_bel) {
+            if constexpr (BEL) if (!UNIT || wr_bel) {
                 // beliefs are written once and not read again by this propagate: a streaming store
                 // keeps them from sitting dirty in the last-level cache, where the next collect's
                 // reads would have to push them out (measured: collect 0.25 -> 0.22 ms)
@@ -1040,7 +1042,8 @@ __global__ __launch_bounds__(JT_THREADS) void jt_reduce_level(const JtTask *__re
 // Unit tasks (JtTask::unit): their shapes differ from the table-keeping tasks' - the static table is one more incoming one
 // (collect: up to three children, or the static table and two; distribute: the parent's message and / or the static table, then
 // up to three children) - so they are dispatched here, by every kernel that may meet one.
-#define JT_UNIT_PASS(NIN, NOUT, MODE) jt_pass<T, NIN, NOUT, MODE, FLOW, true, TMIX, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry)
+#define JT_UNIT_PASS(NIN, NOUT, MODE) jt_pass<T, NIN, NOUT, MODE, FLOW, true, TMIX, false, true, false>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry)
+#define JT_UNIT_BELIEF(NIN) jt_pass<T, NIN, 0, 1, FLOW, true, TMIX, false, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry)
 template <typename T, bool FLOW, bool TMIX>
 __device__ __forceinline__ void jt_unit_collect(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                 T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
@@ -1097,12 +1100,12 @@ __device__ __forceinline__ void jt_unit_single(const JtTask &tk, const JtBlock &
             default: JT_UNIT_PASS(4, 3, 0); break;
         }
     } else {
-        switch (tk.n_in) {
-            case 0: JT_UNIT_PASS(0, 0, 1); break;
-            case 1: JT_UNIT_PASS(1, 0, 1); break;
-            case 2: JT_UNIT_PASS(2, 0, 1); break;
-            case 3: JT_UNIT_PASS(3, 0, 1); break;
-            default: JT_UNIT_PASS(4, 0, 1); break;
+        switch (tk.n_in) {            // (the belief itself, into the scratch arena)
+            case 0: JT_UNIT_BELIEF(0); break;
+            case 1: JT_UNIT_BELIEF(1); break;
+            case 2: JT_UNIT_BELIEF(2); break;
+            case 3: JT_UNIT_BELIEF(3); break;
+            default: JT_UNIT_BELIEF(4); break;
         }
     }
 }

@@ -231,14 +231,24 @@ class JunctionTree:
         node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in self.separators]
         # one copy of the tables; eight evidence sets per pass over a table (JTP_MULTISET), marginals formed
         # on demand from the tables and each set's final messages
+        from ._capi import UnsupportedStructure
         try:
             plan = engine.plan_for(self.tree, node_vars, ct.factor_graph.sizes, "f32" if all_f32 else "f64",
                                    n_batch=len(evidence_sets), multiset=True, **self._opts)
-        except ValueError:
+            plan.evidence_mode = "multiset: eight evidence sets per pass over a table"
+        except UnsupportedStructure as exc:
             # separators too large for the per-set LDS regions of a multi-set pass (e.g. 64 x 64 doubles): the sets
-            # still share one copy of the tables but run one pass each, one HIP stream each
+            # still share one copy of the tables but run one pass each, one HIP stream each - up to eight times the table traffic
+            # of a multi-set plan, so it is said, not done silently (`plan.evidence_mode`, and a warning once per tree)
+            import warnings
             plan = engine.plan_for(self.tree, node_vars, ct.factor_graph.sizes, "f32" if all_f32 else "f64",
-                                   n_batch=len(evidence_sets), share_potentials=True, **self._opts)
+                                   n_batch=len(evidence_sets), share_potentials=True, cover=self.cover(), **self._opts)
+            plan.evidence_mode = "one pass per evidence set over shared tables (the multi-set plan was refused: %s)" % exc
+            if not self._memo.get("warned_multiset"):
+                self._memo["warned_multiset"] = True
+                warnings.warn("junctiontree_amd: the evidence sets of this tree run one pass each instead of eight per pass (%s)" % exc,
+                              RuntimeWarning, stacklevel=2)
+        self._memo["evidence_plan"] = plan
         _stage_changed_cliques(plan, ct, xs)
         for b, observed in enumerate(evidence_sets):
             plan.set_evidence(observed, batch=b)

@@ -184,3 +184,39 @@ def test_errors_of_plans_with_cover():
     close(plan.belief(1), np.full((3, 2, 2), 3.5), 1e-12)
     assert abs(plan.z() - 3.5 * 12) < 1e-9
     plan.close()
+
+
+def test_evidence_sets_whose_multiset_plan_is_refused_say_so():
+    """separators too large for the per-set LDS regions of a multi-set pass (a hub whose neighbours share nearly all of it): `propagate_evidence_sets` still
+    answers - one pass per set over shared tables - and says so (a warning, `plan.evidence_mode`) instead of silently running
+    up to eight times the table traffic (robustness)."""
+    rng = np.random.default_rng(5)
+    # a hub of twelve binary variables and four neighbours that each share eleven of them: a set's sub-boxes at the hub are
+    # three or four tables of 2^11 doubles, beyond the 16 KiB region of a multi-set pass however the hub is cut
+    hub = list(range(12))
+    factors = [hub] + [[v for v in hub if v != i] + [12 + i] for i in range(4)]
+    sizes = {v: 2 for v in range(16)}
+    values = [rng.uniform(0.5, 1.5, [2] * len(f)) for f in factors]
+    tree = jt.create_junction_tree(factors, sizes)
+    sets = [{}, {0: 1, 14: 0}, {5: 1}]
+    with pytest.warns(RuntimeWarning, match="one pass each"):
+        res = tree.propagate_evidence_sets(values, sets)
+    assert tree._memo["evidence_plan"].evidence_mode.startswith("one pass per evidence set")
+    ct = tree.clique_tree
+    for obs, got in zip(sets, res):
+        vals = [v.copy() for v in values]
+        done = set()
+        for i, f in enumerate(factors):
+            for ax, v in enumerate(f):
+                if v in obs and v not in done:
+                    done.add(v)
+                    ind = np.zeros(2)
+                    ind[obs[v]] = 1.0
+                    vals[i] = vals[i] * ind.reshape([-1 if a == ax else 1 for a in range(len(f))])
+        want = oracle.propagate(tree.tree, tree.separators, ct.maxcliques, ct.factor_to_maxclique, factors, sizes, vals)
+        for g, w_ in zip(got, want):
+            close(g, w_, 1e-10)
+    # a tree whose multi-set plan is made says that too
+    small = jt.create_junction_tree([["a", "b"], ["b", "c"]], {"a": 2, "b": 3, "c": 2})
+    small.propagate_evidence_sets([np.ones((2, 3)), np.ones((3, 2))], [{}, {"a": 1}])
+    assert small._memo["evidence_plan"].evidence_mode.startswith("multiset")
