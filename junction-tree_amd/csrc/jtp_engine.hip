@@ -280,6 +280,15 @@ struct jtp_plan {
     uint32_t ev_stride = 0;         // uint32 per set's evidence table
     // read-out of multi-set plans: belief task of each clique, built on first use
     std::vector<uint32_t> ev_host;  // host copy of ev_all (which tasks may sum their elements first depends on it)
+    // evidence-free subtrees: group 0 holds evidence-free sets only (the caller's set b is set set0 + b of the allocation); where no
+    // set of a group observes anything below a clique, that group skips the clique's collect task (skip_host[g * n_tasks + t]), its
+    // consumers read group 0's message, and a copy pass behind the propagate (jt_multi_fanout over `fanout`) fills the sets' own arenas
+    int set0 = 0;
+    std::vector<uint8_t> skip_host;
+    uint8_t *d_skip = nullptr;
+    bool skip_dirty = false;
+    JtFanout *d_fanout = nullptr;
+    int n_fanout = 0, cap_fanout = 0;
     struct BeliefTask { JtTask *d_task = nullptr; JtBlock *d_blk = nullptr; int *d_tab = nullptr; int nblocks = 0, lds = 0; };
     std::vector<BeliefTask> belief_tasks;
     std::vector<hipStream_t> streams;
@@ -532,6 +541,8 @@ void jtp_plan_destroy(jtp_plan *pl) {
                 if (pl->bufs[0].bel) (void)hipFree(pl->bufs[0].bel);
             }
             if (pl->msg_all) (void)hipFree(pl->msg_all);
+            if (pl->d_skip) (void)hipFree(pl->d_skip);
+            if (pl->d_fanout) (void)hipFree(pl->d_fanout);
             if (pl->ev_all) (void)hipFree(pl->ev_all);
             if (pl->sync_all) (void)hipFree(pl->sync_all);
         } else
@@ -695,7 +706,11 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     const size_t mbytes = (size_t)std::max<int64_t>(hp.msg_doubles, 2) * 8 * 2;
     const bool share_psi = (hp.flags & JTP_SHARE_POTENTIALS) != 0;     // one potential arena for all evidence sets
     if (pl->multiset) {
-        pl->n_groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS;
+        // (group 0: the evidence-free sets the others take their untouched upward messages from - one more group through the collect
+        //  pass, which pays from eight groups on: measured 64 sets 4.97 -> 4.8 ms, 8 sets 0.91 -> 1.3; JTP_EF_SHARE=1 / JTP_NO_EF_SHARE=1 force it)
+        const bool ef = hp.knobs.no_ef_share == 0 && ((hp.n_batch + JT_MSETS - 1) / JT_MSETS >= 8 || hp.knobs.no_ef_share < 0);
+        pl->set0 = ef ? JT_MSETS : 0;
+        pl->n_groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS + (pl->set0 ? 1 : 0);
         const size_t nsets = (size_t)pl->n_groups * JT_MSETS;          // (the last group is padded with evidence-free sets)
         pl->set_stride = (int64_t)(mbytes / 8);
         pl->ev_stride = (uint32_t)(2 * hp.pn.size());
@@ -716,11 +731,28 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             BatchBuffers &bb = pl->bufs[b];
             bb.psi = psi;
             bb.bel = bel;
-            bb.msg = pl->msg_all + (int64_t)b * pl->set_stride;
-            bb.ev = pl->ev_all + (size_t)b * pl->ev_stride;
-            bb.sync = pl->sync_all + (size_t)(b / JT_MSETS) * hp.sync_words;
+            bb.msg = pl->msg_all + (int64_t)(pl->set0 + b) * pl->set_stride;
+            bb.ev = pl->ev_all + (size_t)(pl->set0 + b) * pl->ev_stride;
+            bb.sync = pl->sync_all + (size_t)((pl->set0 + b) / JT_MSETS) * hp.sync_words;
         }
         pl->belief_tasks.resize(hp.pn.size());
+        if (pl->set0) {
+            // no evidence yet: every collect task of every group but the first copies
+            pl->skip_host.assign((size_t)pl->n_groups * hp.tasks.size(), 0);
+            // (nobody reads group 0's DOWNWARD messages: its sets are not the caller's)
+            for (const PSep &sp : hp.ps) {
+                if (sp.dn_task >= 0) pl->skip_host[sp.dn_task] = 1;
+                if (sp.dn_red_task >= 0) pl->skip_host[sp.dn_red_task] = 1;
+            }
+            for (int g = 1; g < pl->n_groups; ++g)
+                for (const PNode &p : hp.pn)
+                    if (p.collect_task >= 0) {
+                        pl->skip_host[(size_t)g * hp.tasks.size() + p.collect_task] = 1;
+                        if (hp.ps[p.psep].up_red_task >= 0) pl->skip_host[(size_t)g * hp.tasks.size() + hp.ps[p.psep].up_red_task] = 1;
+                    }
+            CREATE_TRY(hipMalloc((void **)&pl->d_skip, pl->skip_host.size()));
+            pl->skip_dirty = true;
+        }
     } else
     for (auto &b : pl->bufs) {
         if (share_psi && &b != &pl->bufs[0]) b.psi = pl->bufs[0].psi;
@@ -1264,9 +1296,30 @@ int jtp_set_evidence(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *var_
     if (pl->multiset) {
         // a group of evidence sets may sum the elements of a vector before the message product on a clique while none of ITS
         // sets observes a variable on that clique's element bits (JtTask::esum_groups; bit b stands for the groups g = b mod 64)
-        std::copy(ev.begin(), ev.end(), pl->ev_host.begin() + (size_t)batch * pl->ev_stride);
+        const int iset = pl->set0 + batch;                       // the set's place in the allocation (group 0: evidence-free sets)
+        std::copy(ev.begin(), ev.end(), pl->ev_host.begin() + (size_t)iset * pl->ev_stride);
+        if (pl->set0) {
+            // which collect tasks of this set's group meet no evidence below them: skipped, group 0's message stands for theirs
+            const int g = iset / JT_MSETS;
+            std::vector<char> below(hp.pn.size(), 0);
+            for (int s = g * JT_MSETS; s < (g + 1) * JT_MSETS; ++s)
+                for (size_t p = 0; p < hp.pn.size(); ++p)
+                    if (pl->ev_host[(size_t)s * pl->ev_stride + 2 * p] != 0) below[p] = 1;
+            std::vector<int> order(hp.pn.size());
+            for (size_t p = 0; p < hp.pn.size(); ++p) order[p] = (int)p;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return hp.pn[a].depth > hp.pn[b].depth; });
+            for (int p : order)
+                if (below[p] && hp.pn[p].parent >= 0) below[hp.pn[p].parent] = 1;
+            for (size_t p = 0; p < hp.pn.size(); ++p)
+                if (hp.pn[p].collect_task >= 0) {
+                    uint8_t &sk = pl->skip_host[(size_t)g * hp.tasks.size() + hp.pn[p].collect_task];
+                    const uint8_t want = below[p] ? 0 : 1;
+                    if (sk != want) sk = want, pl->skip_dirty = true;
+                    if (hp.ps[hp.pn[p].psep].up_red_task >= 0) pl->skip_host[(size_t)g * hp.tasks.size() + hp.ps[hp.pn[p].psep].up_red_task] = want;
+                }
+        }
         const uint32_t emask = (1u << hp.EB) - 1u;
-        const int bit = (batch / JT_MSETS) & 63;
+        const int bit = (iset / JT_MSETS) & 63;
         std::vector<char> on_e(hp.pn.size(), 0);
         const size_t nsets = pl->ev_host.size() / pl->ev_stride;
         for (size_t sidx = 0; sidx < nsets; ++sidx) {
@@ -1333,6 +1386,29 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         fl.set_stride = pl->set_stride;
         fl.ev_stride = pl->ev_stride;
         fl.sync_stride = (uint32_t)hp.sync_words;
+        if (pl->skip_dirty) {
+            std::vector<JtFanout> list;
+            for (int g = 1; g < pl->n_groups; ++g)
+                for (const PNode &p : hp.pn)
+                    if (p.collect_task >= 0 && pl->skip_host[(size_t)g * hp.tasks.size() + p.collect_task]) {
+                        const PSep &sp = hp.ps[p.psep];
+                        list.push_back({sp.up_roff, (int32_t)(((int64_t)sp.up_rnpart) << sp.nbits), g});
+                    }
+            if ((int)list.size() > pl->cap_fanout) {
+                if (pl->d_fanout) HIP_TRY(hipFree(pl->d_fanout));
+                pl->d_fanout = nullptr;
+                pl->cap_fanout = 0;
+                HIP_TRY(hipMalloc((void **)&pl->d_fanout, list.size() * sizeof(JtFanout)));
+                pl->cap_fanout = (int)list.size();
+            }
+            HIP_TRY(hipMemcpyAsync(pl->d_skip, pl->skip_host.data(), pl->skip_host.size(), hipMemcpyHostToDevice, s));
+            if (!list.empty()) HIP_TRY(hipMemcpyAsync(pl->d_fanout, list.data(), list.size() * sizeof(JtFanout), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));                    // (the sources are host vectors)
+            pl->n_fanout = (int)list.size();
+            pl->skip_dirty = false;
+        }
+        fl.skip = pl->d_skip;
+        fl.n_tasks = (uint32_t)hp.tasks.size();
         if (pl->esum_dirty) {
             // which groups may sum a vector's elements first on which task (jtp_set_evidence): the fields of ALL tasks in one
             // strided copy, ordered before the launches below on the plan's stream
@@ -1388,6 +1464,8 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 launch(L.phase, L.blk_off, L.nblocks, multiset_lds(hp, L), -1, 0u);
             }
         }
+        if (pl->n_fanout > 0)        // the messages of the skipped tasks, into the sets' own arenas (read-out, next propagate's markers)
+            hipLaunchKernelGGL(jt_multi_fanout, dim3(pl->n_fanout), dim3(256), 0, s, pl->d_fanout, pl->msg_all, fl);
         if (prof) {
             if (!mid_done) HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
             HIP_TRY(hipEventRecord(pl->ev[ev_base + 2], s));
@@ -1941,8 +2019,22 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     st->n_messages = hp.n_messages;
     st->n_tasks = (int32_t)hp.tasks.size();
     // multi-set plans: a table is read once per GROUP of evidence sets, messages once per set
-    st->algorithmic_bytes = pl->multiset ? hp.alg_table_bytes * std::max(pl->n_groups, (hp.n_batch + JT_MSETS - 1) / JT_MSETS) + hp.alg_msg_bytes * hp.n_batch
-                                         : hp.alg_bytes;
+    st->algorithmic_bytes = hp.alg_bytes;
+    if (pl->multiset) {
+        // what THIS engine streams: a table once per pass and GROUP of evidence sets that runs the pass (group 0 - the evidence-free
+        // sets - included; a (task, group) whose subtree meets no evidence copies group 0's message and streams nothing), messages per set
+        double tb = 0;
+        for (const Launch &L : hp.launches) {
+            if (L.variant != JT_K_MULTI_COLLECT && L.variant != JT_K_MULTI_DISTRIBUTE) continue;
+            for (int t : L.tasks) {
+                const PNode &p = hp.pn[hp.tasks[t].pnode];
+                const double table = hp.tasks[t].kind == 0 && p.real >= 0 ? (double)hp.pack[p.real].host_elems * pl->esize : 0.0;
+                for (int g = 0; g < pl->n_groups; ++g)
+                    if (pl->skip_host.empty() || !pl->skip_host[(size_t)g * hp.tasks.size() + t]) tb += table;
+            }
+        }
+        st->algorithmic_bytes = tb + hp.alg_msg_bytes * hp.n_batch;
+    }
     st->flow_fallbacks = pl->flow_fallbacks;
     st->launch_mode = pl->launch_mode;
     st->tickets_used = pl->tickets_used;
@@ -1961,7 +2053,7 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
         st->n_static_tables += hp.pn[c].unit && hp.pn[c].stat >= 0 ? 1 : 0;
     }
     if (pl->multiset) {
-        const int groups = (hp.n_batch + JT_MSETS - 1) / JT_MSETS;
+        const int groups = pl->n_groups;
         // float64 operations of the element loop of jt_mpass, per thread and table row (VEC elements), G = JT_MSETS sets:
         //   elements summed first (JtTask::esum == 3): VEC - 1 additions, then per set (n_in - 1) multiplications and one
         //   fused multiply-add;  no message on the element bits: per set (n_in - 1) multiplications and VEC fused multiply-adds;
@@ -1977,8 +2069,9 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
                 for (int k = 0; k < tk.n_in; ++k) edep = edep || tk.msg[k].e_dep != 0;
                 const double nin1 = std::max(tk.n_in - 1, 0);
                 const double rows = (double)JT_THREADS * (double)tk.total * (double)(1u << tk.nF);
-                for (int g = 0; g < groups; ++g) {
+                for (int g = 0; g < pl->n_groups; ++g) {
                     double per, ins;
+                    if (!pl->skip_host.empty() && pl->skip_host[(size_t)g * hp.tasks.size() + t]) continue;      // (copies, computes nothing)
                     if ((tk.esum & 1) && ((tk.esum_groups >> (g & 63)) & 1ull) && tk.setb <= JT_SETB_SMALL)
                         per = (VEC - 1) + JT_MSETS * (nin1 + 2.0), ins = (VEC - 1) + JT_MSETS * (nin1 + 1.0);
                     else if (!edep) per = JT_MSETS * (nin1 + 2.0 * VEC), ins = JT_MSETS * (nin1 + VEC);

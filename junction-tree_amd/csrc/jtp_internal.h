@@ -80,6 +80,10 @@ struct JtMsg {
     int32_t fixed;             // incoming: 1 = a STATIC table (the potential of a unit clique at the shape its factors cover,
                                // PNode::stat): it lives in the plan's fixed arena, outside the two alternating halves of the message
                                // arena - its address is msg_arena + JtFlow::fix_shift + off - it is never "unwritten" and has one copy
+    int32_t src_task;          // incoming, multi-set plans: the collect task that forms this upward message (-1: a downward message).  Where
+                               // that task is skipped for a group of evidence sets (JtFlow::skip: nothing observed below it), the
+                               // consumer reads the evidence-free group's copy instead of its own group's
+    int32_t pad_msg;
     int32_t f_w[JT_MAX_HI];    // weight of F bit j in the message's global index
     int32_t f_p[JT_MAX_HI];    // outgoing: weight of F bit j in the partial-copy number
     uint8_t free_pos[16];      // global-index bit of each sub-box index bit
@@ -163,6 +167,13 @@ struct JtFlow {
     uint32_t n_blocks;         // ... and workgroup records per group
     int64_t out_shift;         // added to the address of every outgoing entry (doubles): read-out tasks of multi-set
                                // plans read one set's message arena and write into a scratch buffer elsewhere
+    // multi-set launches: group 0 holds EVIDENCE-FREE sets only; skip[g * n_tasks + t] != 0 = no set of group g observes a variable
+    // in the subtree below task t's clique - the upward message of those sets equals group 0's: the task's workgroups of group g end
+    // at once, its consumers read group 0's copy (JtMsg::src_task), and a copy pass behind the propagate (jt_multi_fanout) puts
+    // the message into the sets' own arenas for the read-out (null: every group computes everything)
+    const uint8_t *skip;
+    uint32_t n_tasks;
+    uint32_t pad_flow;
     int64_t fix_shift;         // static tables (JtMsg::fixed): offset (doubles) of the plan's fixed arena from the base of THIS
                                // propagate's half of the message arena (the consumer adds it to the message's offset)
 };

@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(JT_THREADS, JT_CHAIN_WAVES) void jt_distribute_flow
 template <typename T, int NIN, int SETB, bool ESUM = false>
 __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                          const T *__restrict__ psi_arena, double *__restrict__ msg0,
-                                         const JtFlow &fl, uint32_t *flow_ctl, uint32_t bindex) {
+                                         const JtFlow &fl, uint32_t *flow_ctl, uint32_t bindex, const double *__restrict__ msg_ef = nullptr) {
     constexpr int G = JT_MSETS;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int EB = (VEC == 4) ? 2 : 1;
@@ -1372,6 +1372,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     // ---- stage the incoming sub-boxes of every set (one thread per entry, partial copies summed in copy
     //      order), zero the outgoing ones; wait for entries still marked unwritten (dataflow launches)
     const double *msg_cur = msg0 + fl.cur_off;
+    const double *ef_cur = msg_ef != nullptr ? msg_ef + fl.cur_off : msg_cur;       // the evidence-free group's arena (group 0)
     char *sets = smem + JT_RING_BYTES;                       // region of set s: sets + s * SETB
     const JtMsg &mo = tk.msg[JT_MAX_IN];
     uint64_t wait_t0 = 0;
@@ -1386,12 +1387,14 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
             const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
             const bool thr_mem = m.same_launch != 0;
             const int n = 1 << nfree;
+            // (an upward message whose producer met no evidence in this group: the evidence-free group's copy, fl.skip = this group's row)
+            const double *mbase = (fl.skip != nullptr && m.src_task >= 0 && fl.skip[m.src_task]) ? ef_cur : msg_cur;
             for (int i = tid; i < n; i += JT_THREADS) {
                 int idx = 0;
 #pragma unroll
                 for (int b = 0; b < JT_MAX_FREE; ++b)
                     if (b < nfree) idx += ((i >> b) & 1) << JT_FPOS(fp, b);
-                const double *src = msg_cur + m.off + bk.gbase[k] + idx;
+                const double *src = mbase + m.off + bk.gbase[k] + idx;
                 double sum[G];
 #pragma unroll
                 for (int s = 0; s < G; ++s) sum[s] = 0.0;
@@ -1755,6 +1758,34 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
 #endif
 }
 
+// Evidence-free subtrees (round 5).  Group 0 of a multi-set launch holds evidence-free sets only.  Where no set of group g observes
+// a variable in the subtree below a clique, the upward message of every set of g IS group 0's (with 16 observed variables per set a
+// set's evidence touches at most 16 of 256 cliques: a third of the collect tasks of a group of eight sets meet no evidence at
+// all): that task's workgroups of group g end at once (JtFlow::skip), its consumers stage group 0's copy (JtMsg::src_task), and
+// this copy pass behind the propagate puts the message into the eight sets' own arenas - values in this propagate's half, the
+// "unwritten" marker in the other, exactly what the producer would have left - for the read-out and for the next propagate.
+struct JtFanout {
+    int64_t off;               // msg-arena offset (doubles) of what consumers read of the message (the reduced sum where there is one)
+    int32_t count;             // doubles
+    int32_t group;             // the group whose sets receive it
+};
+#ifndef JT_INST_TU
+__global__ __launch_bounds__(256) void jt_multi_fanout(const JtFanout *__restrict__ list, double *__restrict__ msg, JtFlow fl) {
+    const JtFanout f = list[blockIdx.x];
+    const double *src = msg + fl.cur_off + f.off;                                  // (group 0, set 0)
+    double *dst0 = msg + (int64_t)f.group * JT_MSETS * fl.set_stride + f.off;
+    for (int i = threadIdx.x; i < f.count; i += 256) {
+        const double v = src[i];
+#pragma unroll
+        for (int s = 0; s < JT_MSETS; ++s) {
+            double *base = dst0 + (int64_t)s * fl.set_stride + i;
+            base[fl.cur_off] = v;
+            if (fl.oth_off >= 0) base[fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
+        }
+    }
+}
+#endif
+
 // Multi-set entry point: grid.y = group of JT_MSETS evidence sets; the block list is that of a whole phase
 // (dataflow launch) or of one tree level.  Workgroups of one group only ever wait for workgroups of the same
 // group earlier in the list.
@@ -1782,30 +1813,33 @@ __global__ __launch_bounds__(JT_THREADS, JT_MULTI_WAVES) void jt_multi_flow(cons
     const uint32_t ticket = fl.ticket_idx == 0xffffffffu ? rec : jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
     const JtTask &tk = tasks[bk.task];
+    // (nothing observed below this clique in this group: its upward message is group 0's - nothing to do, reduce task included)
+    if (fl.skip != nullptr && fl.skip[(size_t)grp * fl.n_tasks + bk.task]) return;
+    fl.skip = fl.skip != nullptr ? fl.skip + (size_t)grp * fl.n_tasks : nullptr;          // (this group's row, for the consumers below)
     if (tk.kind != 0) {
         jt_reduce<true, true>(tk, bk, msg0, fl);
         return;
     }
     if (tk.setb <= JT_SETB_SMALL && (tk.esum & 1) && ((tk.esum_groups >> (grp & 63u)) & 1ull)) {
         switch (tk.n_in) {
-            case 0: jt_mpass<T, 0, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            case 1: jt_mpass<T, 1, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            case 2: jt_mpass<T, 2, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            default: jt_mpass<T, 3, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 0: jt_mpass<T, 0, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 1: jt_mpass<T, 1, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 2: jt_mpass<T, 2, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            default: jt_mpass<T, 3, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
         }
     } else if (tk.setb <= JT_SETB_SMALL) {
         switch (tk.n_in) {
-            case 0: jt_mpass<T, 0, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            case 1: jt_mpass<T, 1, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            case 2: jt_mpass<T, 2, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            default: jt_mpass<T, 3, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 0: jt_mpass<T, 0, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 1: jt_mpass<T, 1, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 2: jt_mpass<T, 2, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            default: jt_mpass<T, 3, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
         }
     } else {
         switch (tk.n_in) {
-            case 0: jt_mpass<T, 0, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            case 1: jt_mpass<T, 1, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            case 2: jt_mpass<T, 2, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
-            default: jt_mpass<T, 3, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket); break;
+            case 0: jt_mpass<T, 0, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 1: jt_mpass<T, 1, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 2: jt_mpass<T, 2, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            default: jt_mpass<T, 3, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
         }
     }
 }

@@ -502,6 +502,7 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
         if (hp.knobs.lane_low > (is_out ? 1 : 0) && !hp.tmix)
             std::stable_partition(fr.begin(), fr.end(), [&](const std::pair<int, int> &x) { return x.second >= hp.EB && x.second < hp.EB + 5; });
         jm.nfree = (int)fr.size();
+        jm.src_task = -1;
         for (size_t r = 0; r < fr.size(); ++r) {
             jm.free_pos[r] = (uint8_t)fr[r].first;
             sw[fr[r].second] = 1 << r;
@@ -672,6 +673,7 @@ PlanKnobs jtp_read_knobs() {
     k.marg_group = std::max(1, std::min(geti("JTP_MARG_GROUP", JT_MAX_OUT), JT_MAX_OUT));
     k.marg_block_log2 = geti("JTP_MARG_BLOCK_LOG2", 0);
     k.no_unit = geti("JTP_NO_UNIT", 0);
+    k.no_ef_share = geti("JTP_EF_SHARE", 0) ? -1 : geti("JTP_NO_EF_SHARE", 0);      // (-1: the evidence-free group whatever the number of sets)
     k.unit_ratio = getd("JTP_UNIT_RATIO", 4.0);
     return k;
 }
@@ -1897,6 +1899,7 @@ int PlanBuilder::messages() {
                 tk.msg[k].off = sp.up_roff;
                 tk.msg[k].npart = sp.up_rnpart;
                 tk.msg[k].same_launch = 0;                       // finished by the collect launch
+                tk.msg[k].src_task = hp.pn[p.children[i]].collect_task;
                 ++k;
             }
             tk.msg[JT_MAX_IN].off = hp.ps[hp.pn[p.children[j]].psep].dn_off;
@@ -1926,6 +1929,7 @@ int PlanBuilder::messages() {
             tk.msg[k].off = s.up_roff;
             tk.msg[k].npart = s.up_rnpart;
             tk.msg[k].same_launch = collect && hp.pn[ch].owner == p.owner;
+            tk.msg[k].src_task = hp.pn[ch].collect_task;
             ++k;
         }
         if (collect) tk.msg[JT_MAX_IN].off = hp.ps[p.psep].up_off;

@@ -220,3 +220,60 @@ def test_evidence_sets_whose_multiset_plan_is_refused_say_so():
     small = jt.create_junction_tree([["a", "b"], ["b", "c"]], {"a": 2, "b": 3, "c": 2})
     small.propagate_evidence_sets([np.ones((2, 3)), np.ones((3, 2))], [{}, {"a": 1}])
     assert small._memo["evidence_plan"].evidence_mode.startswith("multiset")
+
+
+def test_evidence_free_subtrees_are_copied_not_recomputed(monkeypatch):
+    """Multi-set plans (round 5): where no set of a group observes anything below a clique, the group copies the evidence-free
+    upward message (group 0 of the launch) instead of streaming the table again.  Two sets that differ only by evidence in one
+    leaf, a group without any evidence and a group with evidence everywhere: every separator belief and Z must be BIT-identical
+    to the plan that computes everything (JTP_NO_EF_SHARE=1), and agree with the oracle."""
+    spec = synthetic.wide_binary_tree(n_cliques=31, width=13, sep=6, card=2, seed=3)
+    n, nb = spec["n_cliques"], 20
+    base = synthetic.potentials_for(spec, seed=4, dtype=np.float32)
+    leaf_var = [v for v in spec["node_vars"][n - 1] if v not in spec["node_vars"][spec["parent"][n - 1]]][0]
+    labels = sorted(spec["sizes"])
+    rng = np.random.default_rng(8)
+    observed = [{}, {leaf_var: 1}] + [{} for _ in range(6)]                       # group 1: evidence in ONE leaf (set 1 only)
+    observed += [{} for _ in range(8)]                                             # group 2: none at all
+    observed += [{labels[i]: int(rng.integers(0, 2)) for i in rng.choice(len(labels), size=12, replace=False)} for _ in range(4)]      # group 3
+
+    def run(share):
+        if share:            # (by itself from eight groups of sets on: forced here for the three groups of the test)
+            monkeypatch.delenv("JTP_NO_EF_SHARE", raising=False)
+            monkeypatch.setenv("JTP_EF_SHARE", "1")
+        else:
+            monkeypatch.delenv("JTP_EF_SHARE", raising=False)
+            monkeypatch.setenv("JTP_NO_EF_SHARE", "1")
+        plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", n_batch=nb, multiset=True)
+        for c in range(n):
+            plan.set_potential(c, base[c])
+        for b, obs in enumerate(observed):
+            plan.set_evidence(obs, batch=b)
+        out = []
+        for rep in range(2):                     # (twice: both halves of the message arenas)
+            plan.propagate(0, nb)
+            out = [[plan.belief(s, batch=b) for s in range(n, 2 * n - 1)] + [np.array(plan.z(batch=b))] for b in range(nb)]
+        st = plan.stats()
+        some = [plan.belief(c, batch=b) for b in (0, 1, 9, 17) for c in (0, n // 2, n - 1)]
+        plan.close()
+        return out, st, some
+
+    got, st, bel = run(True)
+    want, st0, bel0 = run(False)
+    for b in range(nb):
+        for g, w_ in zip(got[b], want[b]):
+            np.testing.assert_array_equal(g, w_, err_msg="evidence set %d" % b)
+    for g, w_ in zip(bel, bel0):
+        np.testing.assert_array_equal(g, w_)
+    # (the engine's own table bytes: four groups of table passes - the evidence-free one included - less what was skipped, against three)
+    assert st["algorithmic_bytes"] < st0["algorithmic_bytes"] * 1.1
+    # sets 0 and 2..15 are evidence-free: identical to each other; set 1 differs from set 0 only along the leaf's path to the root
+    for b in list(range(2, 16)):
+        for g, w_ in zip(got[b], got[0]):
+            np.testing.assert_array_equal(g, w_)
+    from test_gpu_configs import _with_evidence
+    for b in (1, 17):
+        ref, z = oracle.beliefs_exact(spec["tree"], _with_evidence(spec, base, observed[b]), spec["node_vars"], return_z=True)
+        assert abs(float(got[b][-1]) - z) <= RTOL32 * z
+        for i, s in enumerate(range(n, 2 * n - 1)):
+            close(got[b][i], ref[s], RTOL32, "set %d separator %d" % (b, s))
