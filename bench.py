@@ -716,7 +716,8 @@ def main():
         args.dtype = "f32"
         t0 = time.perf_counter()
         factors, sizes, values = synthetic.lattice_mrf(6, args.lattice_w, 8)
-        tree = jt.create_junction_tree(factors, sizes)
+        # (JTP_BENCH_C3_SWEEP=1: the column-sweep tree of SURVEY.md 8d instead of this repo's min-fill tree)
+        tree = jt.create_junction_tree(factors, sizes, order=synthetic.lattice_column_order(6, args.lattice_w) if os.environ.get("JTP_BENCH_C3_SWEEP") else None)
         t_build = time.perf_counter() - t0
         ct = tree.clique_tree
         node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in tree.separators]

@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): bench lines, rocprofv3 kernel trace + stats, PMC passes for HBM traffic
 # (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, never combined with a trace domain).  Everything lands under
 # gpurun_out/prof/; tools/summarize_profiles.py turns it into gpurun_out/prof/summary/, whose files are committed
-# under profiles/ as r04_* (tools/publish_profiles.py).  Every text file starts with the id of the library build it was measured on (the JSON
+# under profiles/ as r05_* (tools/publish_profiles.py).  Every text file starts with the id of the library build it was measured on (the JSON
 # bench lines carry it in config.library; hbm_traffic*.json in "source_id"): bench.py quotes roofline.traffic only
 # when that id is the running library's.
 #   bash tools/collect_profiles.sh            (needs lib/libjtprop_stamps.so = build.py --out ... -DJT_STAMPS of the same sources)
@@ -60,6 +60,8 @@ pmc single
 pmc multiset64 --batch 64 --multiset
 pmc c2 --config c2
 pmc c3 --config c3
+JTP_BENCH_C3_SWEEP=1 pmc c3_sweep --config c3
+JTP_BENCH_NO_COVER=1 pmc c3_full_tables --config c3
 # what bounds jt_multi_flow: busy cycles of the vector and LDS pipes against the kernel's cycles (a few counters per pass)
 for c in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "VALUBusy" "MemUnitStalled"; do
   n=$(echo $c | tr " " "_" | cut -c1-40)

@@ -1,7 +1,7 @@
 """Copy what tools/collect_profiles.sh brought back (gpurun_out/prof) into profiles/ under this round's names.
     python tools/publish_profiles.py [rNN]"""
 import json, os, shutil, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P, D = os.path.join("gpurun_out", "prof"), "profiles"
 for f in ("bench", "bench_driver_form", "bench_batch4", "bench_c2", "bench_c3", "bench_c5_multiset8", "bench_c5_multiset16", "bench_c5_multiset64", "bench_c5_multiset512", "bench_c5_share16"):
     shutil.copy(os.path.join(P, f + ".json"), os.path.join(D, "%s_%s.json" % (rnd, f)))

@@ -46,19 +46,24 @@ for r in range(reps):
     out = plan.factor_marginals(labels, f2c); td = time.perf_counter()
     ev.append(tb - ta); pr.append(tc - tb); mg.append(td - tc)
 d2h = sum(o.nbytes for o in out)
-phys = {p["real"]: p["phys_elems"] for p in d["pnodes"] if p["real"] >= 0}
+# what the device stores of the potentials since round 5: the tables of the cliques covered (nearly) whole and the static tables of
+# the others at the shape their factors cover - a clique without factors stores nothing (plan.stats(): n_unit_cliques)
+st5 = plan.stats()
+phys = {p["real"]: (0 if p["unit"] else p["phys_elems"]) for p in d["pnodes"] if p["real"] >= 0}
 with_factors = sorted(set(f2c))
-staged_bytes = sum(phys[c] for c in with_factors) * 4
+staged_bytes = sum(phys[c] for c in with_factors) * 4 + st5["fixed_bytes"]
+print("cliques %d, of which %d keep no table (%d of those hold factors: static tables, %.1f MB); full-shape tables would be %.2f GiB"
+      % (len(widths), st5["n_unit_cliques"], st5["n_static_tables"], st5["fixed_bytes"] / 1e6, sum(8.0 ** w for w in widths) * 4 / 2**30 if K == 8 else 0))
 # every clique (also the ones no factor is assigned to: all-ones tables, formed once per plan)
 cold = []
 for r in range(3):
     plan._factor_tables.prev = None
     plan.sync()
     ta = time.perf_counter(); n_all = plan.stage_factors(labels, f2c, values); plan.sync(); cold.append(time.perf_counter() - ta)
-all_bytes = sum(phys.values()) * 4
+all_bytes = sum(phys.values()) * 4 + st5["fixed_bytes"]
 print("evaluate of ALL %d cliques (first call of a plan): %.2f ms for %.2f GiB written -> %.2f TB/s" % (n_all, min(cold) * 1e3, all_bytes / 2**30, all_bytes / min(cold) / 1e12))
 print("propagate() steady state, all %d factor tables new each call: end to end %.2f ms (min of %d; median %.2f)" % (len(factors), min(e2e) * 1e3, reps, sorted(e2e)[reps // 2] * 1e3))
-print("   stage by stage (each synchronised, min of %d): evaluate of the %d cliques that have factors %.2f ms (%.2f GiB written -> %.2f TB/s), collect+distribute %.2f ms, %d factor marginals %.2f ms (%.2f GiB of belief tables read; D2H %.2f MB)"
+print("   stage by stage (each synchronised, min of %d): evaluate of the %d cliques that have factors %.2f ms (%.2f GiB written -> %.2f TB/s), collect+distribute %.2f ms, %d factor marginals %.2f ms (%.2f GiB of potentials / belief tables behind them; D2H %.2f MB)"
       % (reps, n_staged, min(ev) * 1e3, staged_bytes / 2**30, staged_bytes / min(ev) / 1e12, min(pr) * 1e3, len(factors), min(mg) * 1e3, staged_bytes / 2**30, d2h / 1e6))
 out = tree.propagate(vals)
 t0 = time.perf_counter(); out = tree.propagate(vals); t1 = time.perf_counter()

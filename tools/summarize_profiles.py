@@ -62,14 +62,23 @@ for case in cases:
         traffic[name] = {"launches_profiled": len(f), "FETCH_SIZE_KB_per_launch_raw": sum(f) / len(f),
                          "fetch_bytes_per_launch_corrected_x2": fetch, "WRITE_SIZE_KB_per_launch": sum(wv) / len(wv),
                          "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
-    all_traffic[case] = traffic
+    # per STEP: every launch of the message-passing kernels in the profiled run (bench.py --steps 5 --warmup 1: six propagates)
+    hot = ("jt_propagate_flow", "jt_collect_flow", "jt_distribute_flow", "jt_multi_flow", "jt_multi_fanout", "jt_collect_level", "jt_distribute_level", "jt_reduce_level")
+    per_step = 0.0
+    for name, c in pmc.items():
+        bare = name.replace("void ", "").split("<")[0]
+        if bare in hot and c.get("FETCH_SIZE") and c.get("WRITE_SIZE"):
+            per_step += (sum(c["FETCH_SIZE"]) * 1024 * 2 + sum(c["WRITE_SIZE"]) * 1024) / 6.0
+    all_traffic[case] = {"kernels": traffic, "hbm_bytes_per_step": per_step,
+                         "hbm_bytes_per_step_note": "all launches of the message-passing kernels in the profiled run / its six propagates (5 steps + 1 warm-up)"}
 note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 1 --no-profile "
         "[case arguments]`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); averages "
         "over all launches of the kernel (one launch per phase)")
-traffic = all_traffic.get("single", {})
+traffic = all_traffic.get("single", {}).get("kernels", {})
 json.dump({"source_id": source_id, "git_head_at_build": git_head, "note": note, "kernels": traffic}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 json.dump({"source_id": source_id, "git_head_at_build": git_head, "note": note + "; cases: single = the default bench (one evidence set); multiset64 = 64 sets, one pass per group of eight sets; "
-           "c2 / c3 = bench.py --config c2 / c3", "cases": all_traffic},
+           "c2 / c3 = bench.py --config c2 / c3 (c3: potentials at the shape their factors cover, round 5); c3_sweep = c3 on the column-sweep tree of "
+           "SURVEY.md 8d; c3_full_tables = c3 with every clique materialised, as in rounds 1-4 (JTP_BENCH_NO_COVER=1)", "cases": all_traffic},
           open(os.path.join(dst, "hbm_traffic_cases.json"), "w"), indent=1)
 valu = defaultdict(list)
 for r in rows("valu_*/**/*counter_collection.csv"):
