@@ -1138,8 +1138,9 @@ __global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_level(const JtTas
                                                                   double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
-    if (tk.unit) {
-        jt_unit_distribute<T, false, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+    if (tk.unit) {           // (a unit clique's downward messages are marginalisations of their own: mode 0 in the distribute phase)
+        if (tk.mode == 0) jt_unit_collect<T, false, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+        else jt_unit_distribute<T, false, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
         return;
     }
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
@@ -1207,8 +1208,9 @@ __device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict
         jt_reduce<true>(tk, bk, msg, fl);
         return;
     }
-    if (tk.unit) {
-        jt_unit_distribute<T, true, false>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
+    if (tk.unit) {           // (a unit clique's downward messages are marginalisations of their own: mode 0 in the distribute phase)
+        if (tk.mode == 0) jt_unit_collect<T, true, false>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
+        else jt_unit_distribute<T, true, false>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
         return;
     }
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
@@ -1923,7 +1925,8 @@ __device__ __forceinline__ void jt_distribute_mix(const JtTask &tk, const JtBloc
                                                   T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                   uint32_t *flow_ctl, uint64_t t_entry) {
     if (tk.unit) {
-        if (tk.n_out == 0 && !FLOW) jt_unit_single<T, true>(tk, bk, itab, psi, bel, msg, fl, bindex);       // (read-out: up to four incoming tables)
+        if (tk.mode == 0) jt_collect_mix<T, FLOW>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);      // (a downward message of a unit clique: its own marginalisation)
+        else if (tk.n_out == 0 && !FLOW) jt_unit_single<T, true>(tk, bk, itab, psi, bel, msg, fl, bindex);       // (read-out: up to four incoming tables)
         else jt_unit_distribute<T, FLOW, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
         return;
     }

@@ -146,6 +146,7 @@ struct PlanKnobs {
     int esum_always = 0;                                            // JTP_EXPERIMENT_ESUM_ALWAYS: multi-set tasks keep summing a vector's elements first whatever the evidence (timing experiment, wrong results)
     double keep_rows_mb = 128.0;                                      // JTP_KEEP_ROWS_MB: table rows of the levels nearest the root, up to this many MiB, are loaded with the default cache policy (0: all non-temporal; A/B on one box: config 4 0.6037 -> 0.5990 ms, an 8-rank share of it 198.5 -> 195.4 us)
     int no_ef_share = 0;                                            // JTP_NO_EF_SHARE: multi-set plans compute every set's upward messages (round 4), no evidence-free group to copy from
+    int unit_joint_down = 0;                                        // JTP_UNIT_JOINT_DOWN: a unit clique forms its downward messages in ONE mode-1 pass (the first form of round 5) instead of a task each
     int no_unit = 0;                                                // JTP_NO_UNIT: no unit cliques - every clique (virtual ones too) keeps a full table (rounds 1-4)
     double unit_ratio = 4.0;                                        // JTP_UNIT_RATIO: a clique becomes a unit clique when its table is at least this many times its covered part
     int marg_group = JT_MAX_OUT;                                    // JTP_MARG_GROUP: marginals of one belief table formed by one pass over it (1: a pass each, round 3)

@@ -420,7 +420,8 @@ class Emulator:
                 if d.get("multiset"):       # every task of a multi-set plan is a marginalisation (mode 0)
                     assert tk["kind"] == 1 or (tk["mode"] == 0 and tk["variant"] == 17 + launch["phase"] and tk["setb"] in (4096, 16384))
                 else:
-                    assert tk["kind"] == 1 or ((tk["variant"] < 4) == (launch["phase"] == 0) and tk["mode"] == launch["phase"])
+                    # (a unit clique's downward messages are marginalisations of their own: mode 0 tasks of the distribute phase)
+                    assert tk["kind"] == 1 or (tk["unit"] and tk["mode"] == 0 and tk["n_out"] == 1) or ((tk["variant"] < 4) == (launch["phase"] == 0) and tk["mode"] == launch["phase"])
                 assert tk["lds_bytes"] <= launch["lds_bytes"]
                 seen.add((t, chunk))
                 self._block(tk, chunk, tk["mode"] == 0, blk[2:])
