@@ -642,6 +642,7 @@ PlanKnobs jtp_read_knobs() {
     k.layout_policy = geti("JTP_LAYOUT_POLICY", -1);
     k.reduce_min = geti("JTP_REDUCE_MIN", -1);
     k.target_blocks_c = getd("JTP_TARGET_BLOCKS", 1024.0);
+    k.target_set = getenv("JTP_TARGET_BLOCKS") != nullptr;
     k.target_blocks_d = getd("JTP_TARGET_BLOCKS_D", k.target_blocks_c);
     k.min_block_log2 = geti("JTP_MIN_BLOCK_LOG2", 13);
     k.multi_min_block_log2 = geti("JTP_MULTI_MIN_BLOCK_LOG2", 16);
@@ -729,7 +730,9 @@ int PlanBuilder::block_log2_for(int phase, int level, int owner, bool tiny_rule)
         // aim at ~1024 workgroups per tree level (one round of resident workgroups; in a dataflow launch
         // the next level fills the tail), each streaming 16 KiB .. 256 KiB.  Measured on C4: 1024 is
         // 2-3 % faster than 2048 (which was best with one launch per level), 512 and 4096 slower.
-        const double target = phase == 0 ? hp.knobs.target_blocks_c : hp.knobs.target_blocks_d;
+        // (plans whose elements are mostly those of unit cliques - no rows to stream, a workgroup is sub-boxes and arithmetic - do
+        //  better with twice the workgroups per level: config 3 8.98 -> 8.63 ms, A/B on one box; 4096: 10.9)
+        const double target = (phase == 0 ? hp.knobs.target_blocks_c : hp.knobs.target_blocks_d) * (hp.unit_dominated && !hp.knobs.target_set ? 2.0 : 1.0);
         // (the distribute pass - read + write - streams best in workgroups of at most 32 rows: config 4 0.4345 -> 0.4300 ms,
         //  the collect pass in up to 64: 0.2055 against 0.2084 ms; multi-set plans - whose second phase is marginalisations,
         //  not a read + write pass - keep 64: 1.058 against 1.074 ms)
@@ -958,6 +961,7 @@ int PlanBuilder::decide_units() {
     //      (junctiontree.py:52-61); rounds 1-4 of this engine materialised them, and streamed 9 GiB of ones three times per
     //      propagate on that lattice.  A clique covered (nearly) whole keeps its table: streaming it costs less than staging it.
     if (!hp.lean || hp.knobs.no_unit) return JTP_OK;
+    double all = 0, unit = 0;
     for (int c = 0; c < N; ++c) {
         PNode &p = hp.pn[c];
         p.cover = hp.cover[c];
@@ -965,7 +969,10 @@ int PlanBuilder::decide_units() {
         for (int v : hp.node_vars[c]) full *= hp.card[v];
         for (int v : p.cover) part *= hp.card[v];
         p.unit = p.cover.size() < hp.node_vars[c].size() && part * hp.knobs.unit_ratio <= full;
+        all += full;
+        unit += p.unit ? full : 0.0;
     }
+    hp.unit_dominated = unit > 0.5 * all;
     return JTP_OK;
 }
 

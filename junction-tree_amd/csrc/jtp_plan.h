@@ -122,6 +122,7 @@ struct PlanKnobs {
     int layout_policy = -1;          // JTP_LAYOUT_POLICY overrides jtp_tree_desc.layout_policy
     int reduce_min = -1;             // JTP_REDUCE_MIN: partial copies from which a reduce task sums them (-1: default)
     double target_blocks_c = 1024.0, target_blocks_d = 1024.0;     // JTP_TARGET_BLOCKS(_D): workgroups per tree level
+    bool target_set = false;                                        // ... given in the environment (else twice that in plans of mostly unit cliques)
     int min_block_log2 = 13, max_block_log2 = 16;                   // JTP_MIN/MAX_BLOCK_LOG2
     int multi_min_block_log2 = 16;                                  // JTP_MULTI_MIN_BLOCK_LOG2: ... of multi-set plans
     int max_block_log2_d = 15;                                      // JTP_MAX_BLOCK_LOG2_D: the cap for the distribute pass
@@ -185,6 +186,7 @@ struct HostPlan {
                                          // length 1) <-> the static table (dev_off = PStatic::off); nvars = 0 for the others
     bool lean = false;                   // the description named covered variables (jtp_tree_desc.cover_*)
     bool has_unit = false;               // some task of this rank's is a unit task
+    bool unit_dominated = false;         // most clique elements of the tree belong to unit cliques (decide_units)
     std::vector<std::vector<int>> cover; // per real clique (lean plans)
     int64_t scratch_elems = 0;           // largest table of a unit clique (elements as it WOULD be stored) + the two shared rows: size of the
                                          // scratch arena beliefs of unit cliques are formed in on demand (jtp_get_belief)
