@@ -73,9 +73,11 @@ def compute_beliefs(tree, potentials, clique_vars, dl=sum_product):
                    and not getattr(dl, "args", ()) and set(getattr(dl, "kwargs", {})) <= {"optimize"})
     if not isinstance(dl, HipSumProduct) and not plain_numpy:
         raise TypeError(
-            "this build runs the sum-product law on the GPU only; pass "
-            "junctiontree_amd.computation.sum_product (got %r).  A custom einsum callable "
-            "can still be wrapped in SumProduct for its own use." % (dl,))
+            "unsupported reference feature: an injected distributive law (`compute_beliefs(..., dl=SumProduct(<einsum-compatible "
+            "callable>, ...))`, junctiontree/computation.py:37 with sum_product.py:14-19).  This build runs ONE law - real sum-product, "
+            "the law numpy.einsum implements - on the GPU and has no host path: pass junctiontree_amd.computation.sum_product or "
+            "SumProduct(numpy.einsum[, optimize=...]) (got %r).  A custom einsum callable can still be wrapped in SumProduct for "
+            "its own use." % (dl,))
     order, parent, parent_sep, _ = engine.flatten_tree(tree)
     seps = [parent_sep[c] for c in order if parent[c] != -1]
     sizes = _infer_sizes(order, potentials, clique_vars)
