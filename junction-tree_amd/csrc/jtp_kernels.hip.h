@@ -34,6 +34,9 @@
 
 #include "jtp_internal.h"
 
+#ifndef JT_UT
+#define JT_UT 8                 // ... of a mixed-radix plan (rows gathered into registers, *_mix kernels): 4 or 8
+#endif
 #ifndef JT_U
 #define JT_U 4                  // loop iterations whose element loads are in flight
 #endif
@@ -82,6 +85,48 @@ __device__ __forceinline__ double jt_shfl_xor(double v, int laneMask) {
     return __hiloint2double(hi, lo);
 }
 
+// v of lane + N (N = 1, 2, 4, 8; inside a row of 16 lanes, 0.0 beyond it) without a trip through the LDS crossbar: two DPP moves.
+// A sum over lane bit b only has to arrive in the lanes whose bit b is clear (the lanes that store it), and lane + 2^b is their
+// partner of the butterfly: same operands, same order, same double as acc += shfl_xor(acc, 2^b) there.
+template <int N>
+__device__ __forceinline__ double jt_row_down(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xf, 0xf, true);       // row_shl:N
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// acc[e] += the partner's acc[e] over every lane bit of red_lane, all elements together (no per-element branch, one wait per bit)
+template <int VEC>
+__device__ __forceinline__ void jt_lane_sums(double (&a)[VEC], const int red_lane) {
+    if (red_lane & 1) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += jt_row_down<1>(a[e]);
+    }
+    if (red_lane & 2) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += jt_row_down<2>(a[e]);
+    }
+    if (red_lane & 4) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += jt_row_down<4>(a[e]);
+    }
+    if (red_lane & 8) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += jt_row_down<8>(a[e]);
+    }
+#pragma unroll
+    for (int b = 4; b < 6; ++b) {
+        if ((red_lane >> b) & 1) {
+            double t[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t[e] = jt_shfl_xor(a[e], 1 << b);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a[e] += t[e];
+        }
+    }
+}
+
 // Diagnostic time stamps (builds with -DJT_STAMPS only: `python junction-tree_amd/build.py --out stamps.so -DJT_STAMPS`, plans
 // made with JTP_DEBUG=2): lane 0 of a workgroup stores the 100 MHz clock at stage boundaries into its JT_NSTAMP slots of the
 // time-stamp region (JtTask::dbg_off).  In the product build the macro is empty: no registers, no branches, no stores.
@@ -106,6 +151,14 @@ __device__ __forceinline__ double jt_shfl_xor(double v, int laneMask) {
 // and while it finds a marker it waits on that entry and loads again.  Loads and stores of message
 // entries are agent-scope atomics here (they go through to memory: the L2 caches of the eight XCDs
 // are not coherent with each other inside a launch); no fences, no counters.
+template <int N, typename F>
+__device__ __forceinline__ void jt_static_for(F &&f) {
+    if constexpr (N > 0) {
+        jt_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 __device__ __forceinline__ bool jt_unwritten(double v) { return (uint64_t)__double_as_longlong(v) == JT_UNWRITTEN; }
 
 template <bool FLOW>
@@ -189,6 +242,8 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     constexpr int NMSG = NIN + NOUT;
     constexpr int NPAR = NIN - NOUT * (MODE == 1);   // distribute: leading inputs that are not children
     constexpr int U = JT_U;                          // element loads in flight per wave
+    // (mixed-radix rows are gathered into registers, a few hundred bytes each: twice the rows in flight)
+    constexpr int UT = TMIX ? JT_UT : U;
     static_assert((U == 4 || U == 8) && (1 << JT_MIN_ITER_LOG2) == 4 && JT_RING_BYTES == U * 4096, "the loop groups below are written out for four or eight slots");
     using VT = typename JtVec<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -200,7 +255,11 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     const uint32_t xF = bk.xF + (uint32_t)tid * VEC;
     const T *psi = psi_arena + tk.psi_off;
     T *bel = bel_arena + (MODE == 1 ? tk.bel_off : 0);   // distribute always stores (virtual cliques: scratch)
+#ifdef JT_EXPERIMENT              // (timing experiments, wrong results: JTP_FLOW_DEBUG 16 = unit tasks run four rows only, 32 = one partial copy staged)
+    const int total = (UNIT && (fl.dbg & 16)) ? U : tk.total;
+#else
     const int total = tk.total;                       // loop iterations of this workgroup (>= U)
+#endif
     const int dbg = tk.debug;
 #ifdef JT_STAMPS
     double *stamp_out = msg_arena + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * JT_NSTAMP;
@@ -221,7 +280,11 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
         sm_off[k] = m.off + bk.gbase[k] + (m.fixed ? fl.fix_shift : 0);
         sm_ps[k] = m.pstride;
+#ifdef JT_EXPERIMENT
+        sm_npart[k] = (UNIT && (fl.dbg & 32)) ? 1 : m.npart;
+#else
         sm_npart[k] = m.npart;
+#endif
         sm_nfree[k] = m.nfree;
         sm_lds[k] = m.lds_off;
         sm_same[k] = m.same_launch != 0;
@@ -305,7 +368,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     //  and count as zero when the row is consumed; `row0` is a register copy of JtBlock::xF: read through `bk` inside the
     //  loop it was a scalar load and a wait in front of every element load, the belief stores could alias it.)
     int tpo[VEC];
-    T tbuf[TMIX ? U : 1][VEC];
+    T tbuf[TMIX ? UT : 1][VEC];
     const uint32_t row0 = bk.xF;
     auto gather_row = [&](const int slot, const uint32_t xrow, const bool ok) {
         if constexpr (TMIX) {
@@ -324,7 +387,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 #pragma unroll
             for (int e = 0; e < VEC; ++e) tpo[e] = tm[e];
 #pragma unroll
-            for (int u = 0; u < U; ++u) gather_row(u, bk.first_x[u], bk.first_x[u] != JT_NO_ROW);
+            for (int u = 0; u < UT; ++u) gather_row(u, bk.first_x[u], bk.first_x[u] != JT_NO_ROW);
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -389,36 +452,62 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                     gp0[k] = (tid >> nfree) * per;
                     gp1[k] = (gp0[k] + per < sm_npart[k]) ? gp0[k] + per : sm_npart[k];
                     maxper = per > maxper ? per : maxper;
-                } else {
-                    // One thread per entry and round of 256 entries, eight loads in flight per thread: eight entries
-                    // of a single-copy message, else 2^plog copies of 8 >> plog entries (a sub-box of 1024 single-copy
-                    // entries used to cost four dependent round trips, now one).  Every entry's copies are still
-                    // summed in ascending order from 0.0.
+                }
+            }
+            // Sub-boxes of a workgroup's size and more: one thread per entry and round of 256 entries.  Where entry `it` * 256 + tid
+            // of message k's sub-box lies in the message (copy pc):
+            auto entry_at = [&](auto k_tag, int it, int pc) {
+                constexpr int k = decltype(k_tag)::value;
+                int idx = idx_t[k];
+#pragma unroll
+                for (int b = 8; b < JT_MAX_FREE; ++b)
+                    if (b < sm_nfree[k]) idx += ((it >> (b - 8)) & 1) << JT_FPOS(sm_fp[k], b);
+                return src[k] + ((int64_t)pc * ps[k] + idx);
+            };
+            // ... single-copy messages first, ALL of them in lock step: the loads of a round - up to eight entries per thread and
+            // message (four when there are three messages or more: registers) - leave together, so a task with two or three
+            // such messages pays one round trip to memory where it paid one per message (round 5: the unit tasks of config 3 are
+            // two 1024-entry sub-boxes and a few cheap rows each - staging was a third of a workgroup's life).
+            {
+                constexpr int SU = NIN >= 3 ? 4 : 8;
+                int nmax = 0;
+#pragma unroll
+                for (int k = 0; k < NIN; ++k)
+                    if (!grouped[k] && sm_npart[k] == 1) nmax = (1 << sm_nfree[k]) > nmax ? (1 << sm_nfree[k]) : nmax;
+                for (int it0 = 0; it0 * JT_THREADS < nmax; it0 += SU) {
+                    double c[NIN > 0 ? NIN : 1][SU];
+                    jt_static_for<NIN>([&](auto k_tag) {
+                        constexpr int k = decltype(k_tag)::value;
+                        const int n = (!grouped[k] && sm_npart[k] == 1) ? 1 << sm_nfree[k] : 0;
+#pragma unroll
+                        for (int u = 0; u < SU; ++u)
+                            c[k][u] = (it0 + u) * JT_THREADS + tid < n ? jt_msg_load<FLOW>(entry_at(k_tag, it0 + u, 0), thr_mem[k]) : 0.0;
+                    });
+                    jt_static_for<NIN>([&](auto k_tag) {
+                        constexpr int k = decltype(k_tag)::value;
+                        const int n = (!grouped[k] && sm_npart[k] == 1) ? 1 << sm_nfree[k] : 0;
+                        double *sub = reinterpret_cast<double *>(smem + sm_lds[k]);
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) {
+                            if ((it0 + u) * JT_THREADS + tid >= n) continue;
+                            if (FLOW) c[k][u] = jt_msg_settle<FLOW>(entry_at(k_tag, it0 + u, 0), c[k][u], thr_mem[k], settle_attempt);
+                            if (FLOW && jt_unwritten(c[k][u])) unready = entry_at(k_tag, it0 + u, 0);
+                            sub[(it0 + u) * JT_THREADS + tid] = 0.0 + c[k][u];
+                        }
+                    });
+                }
+            }
+            // ... then the messages of several copies, one after the other: 2^plog copies of 8 >> plog entries in flight per thread.
+            // Every entry's copies are summed in ascending order from 0.0.
+            jt_static_for<NIN>([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value;
+                if (grouped[k] || sm_npart[k] == 1) return;
+                const int nfree = sm_nfree[k];
+                {
                     double *sub = reinterpret_cast<double *>(smem + sm_lds[k]);
                     const int n = 1 << nfree;
                     const int npart = sm_npart[k];
-                    auto entry_at = [&](int it, int pc) {
-                        int idx = idx_t[k];
-#pragma unroll
-                        for (int b = 8; b < JT_MAX_FREE; ++b)
-                            if (b < nfree) idx += ((it >> (b - 8)) & 1) << JT_FPOS(fp, b);
-                        return src[k] + ((int64_t)pc * ps[k] + idx);
-                    };
-                    if (npart == 1) {
-                        for (int it0 = 0; it0 * JT_THREADS < n; it0 += 8) {
-                            double c[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u)
-                                c[u] = (it0 + u) * JT_THREADS + tid < n ? jt_msg_load<FLOW>(entry_at(it0 + u, 0), thr_mem[k]) : 0.0;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                if ((it0 + u) * JT_THREADS + tid >= n) continue;
-                                if (FLOW) c[u] = jt_msg_settle<FLOW>(entry_at(it0 + u, 0), c[u], thr_mem[k], settle_attempt);
-                                if (FLOW && jt_unwritten(c[u])) unready = entry_at(it0 + u, 0);
-                                sub[(it0 + u) * JT_THREADS + tid] = 0.0 + c[u];
-                            }
-                        }
-                    } else {
+                    {
                         const int plog = npart >= 8 ? 3 : (npart >= 4 ? 2 : 1);
                         const int pmask = (1 << plog) - 1, E = 8 >> plog;
                         for (int it0 = 0; it0 * JT_THREADS < n; it0 += E) {
@@ -429,14 +518,14 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                                 for (int u = 0; u < 8; ++u) {
                                     const int e = u >> plog, pc = p0 + (u & pmask);
                                     const bool ok = (it0 + e) * JT_THREADS + tid < n && pc < npart;
-                                    c[u] = ok ? jt_msg_load<FLOW>(entry_at(it0 + e, pc), thr_mem[k]) : 0.0;
+                                    c[u] = ok ? jt_msg_load<FLOW>(entry_at(k_tag, it0 + e, pc), thr_mem[k]) : 0.0;
                                 }
 #pragma unroll
                                 for (int u = 0; u < 8; ++u) {
                                     const int e = u >> plog, pc = p0 + (u & pmask);
                                     const bool ok = (it0 + e) * JT_THREADS + tid < n && pc < npart;
-                                    if (FLOW && ok) c[u] = jt_msg_settle<FLOW>(entry_at(it0 + e, pc), c[u], thr_mem[k], settle_attempt);
-                                    if (FLOW && jt_unwritten(c[u])) unready = entry_at(it0 + e, pc);
+                                    if (FLOW && ok) c[u] = jt_msg_settle<FLOW>(entry_at(k_tag, it0 + e, pc), c[u], thr_mem[k], settle_attempt);
+                                    if (FLOW && jt_unwritten(c[u])) unready = entry_at(k_tag, it0 + e, pc);
                                 }
                                 // (plog is uniform: the entry a value belongs to is picked with compile-time indices)
                                 if (plog == 1) {
@@ -456,7 +545,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                         }
                     }
                 }
-            }
+            });
             // grouped messages: every thread sums its range of copies of its entry, all messages at once
             constexpr int GC = NIN >= 3 ? 4 : 8;          // copies in flight per message (register budget)
             for (int p = 0; p < maxper; p += GC) {
@@ -592,6 +681,17 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         }
     }
 
+    // (unit tasks: a row is nothing but message look-ups, so every instruction of one counts - the byte address of element e's
+    //  entry of message k inside the sub-box is formed HERE, a row adds its offset: one vector add per LDS read)
+    uint32_t ua[UNIT ? NI : 1][VEC];
+    if constexpr (UNIT) {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                ua[k][e] = (uint32_t)tk.msg[k].lds_off + 8u * (uint32_t)(thr[k] + ((e & 1) ? in_ew0[k] : 0) + ((e & 2) ? in_ew1[k] : 0));
+    }
+
     double acc[NOUT > 0 ? NOUT : 1][VEC];
 #pragma unroll
     for (int j = 0; j < NOUT; ++j)
@@ -603,6 +703,13 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         {
             constexpr int j = decltype(j_tag)::value;
             const int red_e = o_rede[j], red_lane = o_redl[j], red_wave = o_redw[j];
+            if constexpr (UNIT && MODE == 0) {
+                // (which entries of the thread part exist does not change from row to row: applied to the sums of a run, not to
+                //  every product)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (tpo[e] < 0) acc[j][e] = 0.0;
+            }
             if constexpr (VEC == 4) {
                 if (red_e & 1) {
                     acc[j][0] += acc[j][1];
@@ -615,14 +722,8 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             } else {
                 if (red_e & 1) acc[j][0] += acc[j][1];
             }
-#pragma nounroll
-            for (int b = 0; b < 6; ++b) {
-                if (((red_lane >> b) & 1) && !(dbg & 4)) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        if ((e & red_e) == 0) acc[j][e] += jt_shfl_xor(acc[j][e], 1 << b);
-                }
-            }
+            // (all elements take part, also those folded away above: no branch per element - their sums are not stored)
+            if (!(dbg & 4)) jt_lane_sums<VEC>(acc[j], red_lane);
             const bool rep = (lane & red_lane) == 0;
             const int slot = oo_j + thr[NIN + j];
             const int nph = (dbg & 8) ? 1 : 1 << __builtin_popcount((unsigned)red_wave);
@@ -667,9 +768,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         } else if constexpr (TMIX) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) p[e] = tpo[e] >= 0 ? (double)tbuf[SLOT][e] : 0.0;
-            const int inext = (i + U < total) ? i + U : total - 1;
+            const int inext = (i + UT < total) ? i + UT : total - 1;
             const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
-            gather_row(SLOT, xnext, xnext != JT_NO_ROW && chunk_ok && i + U < total);
+            gather_row(SLOT, xnext, xnext != JT_NO_ROW && chunk_ok && i + UT < total);
         } else {
         jt_wait_vmcnt<YOUNGER>();
         const VT v = *reinterpret_cast<const VT *>(ring + SLOT * 1024);
@@ -699,7 +800,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         // messages' runs come with it (jtp_plan.cpp, plan_loops)
         const uint32_t rowinfo = TMIX ? (uint32_t)__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], li) : 0u;
         const uint32_t inest = TMIX ? (rowinfo >> 16) & 63u : (uint32_t)i;
-        if constexpr (UNIT) {
+        if constexpr (UNIT && MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) p[e] = 1.0;          // (entries that do not exist: see the epilogue; rows: below)
+        } else if constexpr (UNIT) {
             const double one = row_ok ? 1.0 : 0.0;             // (uniform)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) p[e] = tpo[e] >= 0 ? one : 0.0;
@@ -723,6 +827,18 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         double in[NIN > 0 ? NIN : 1][VEC];
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
+            if constexpr (UNIT) {
+                const uint32_t rb = (uint32_t)ioff[k] << 3;        // (scalar)
+                if (in_edep[k]) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) in[k][e] = *reinterpret_cast<const double *>(smem + (ua[k][e] + rb));
+                } else {
+                    const double t = *reinterpret_cast<const double *>(smem + (ua[k][0] + rb));
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) in[k][e] = t;
+                }
+                continue;
+            }
             const int base = ioff[k] + thr[k];
             if (in_edep[k]) {
 #pragma unroll
@@ -736,7 +852,31 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 for (int e = 0; e < VEC; ++e) in[k][e] = t;
             }
         }
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 0 && UNIT) {
+            // a row that does not exist (uniform) adds nothing; without evidence an element is the product of its message
+            // entries and nothing else (p = 1 is folded away: (1 * a) * b and a * b are the same double)
+            if (row_ok) {
+                if (ev_mask == 0) {                            // (uniform)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        double w = NIN > 0 ? in[0][e] : 1.0;
+#pragma unroll
+                        for (int k = 1; k < NIN; ++k) w *= in[k][e];
+#pragma unroll
+                        for (int j = 0; j < NOUT; ++j) acc[j][e] += w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        double w = p[e];
+#pragma unroll
+                        for (int k = 0; k < NIN; ++k) w *= in[k][e];
+#pragma unroll
+                        for (int j = 0; j < NOUT; ++j) acc[j][e] += w;
+                    }
+                }
+            }
+        } else if constexpr (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 double w = p[e];
@@ -807,16 +947,16 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     if constexpr (TMIX) {
         // any number of rows from 1 to 64 (the rows that exist); none at all for a chunk that does not
         if (chunk_ok)
-            for (int i0 = 0; i0 < total; i0 += U) {
+            for (int i0 = 0; i0 < total; i0 += UT) {
                 step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, i0);
                 if (i0 + 1 < total) step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, i0 + 1);
                 if (i0 + 2 < total) step(integral_constant<int, 2>{}, integral_constant<int, 0>{}, i0 + 2);
                 if (i0 + 3 < total) step(integral_constant<int, 3>{}, integral_constant<int, 0>{}, i0 + 3);
-                if constexpr (U == 8) {       // (builds with -DJT_U=8 -DJT_RING_BYTES=32768: an experiment)
-                    if (i0 + 4 < total) step(integral_constant<int, 4 % U>{}, integral_constant<int, 0>{}, i0 + 4);
-                    if (i0 + 5 < total) step(integral_constant<int, 5 % U>{}, integral_constant<int, 0>{}, i0 + 5);
-                    if (i0 + 6 < total) step(integral_constant<int, 6 % U>{}, integral_constant<int, 0>{}, i0 + 6);
-                    if (i0 + 7 < total) step(integral_constant<int, 7 % U>{}, integral_constant<int, 0>{}, i0 + 7);
+                if constexpr (UT == 8) {
+                    if (i0 + 4 < total) step(integral_constant<int, 4 % UT>{}, integral_constant<int, 0>{}, i0 + 4);
+                    if (i0 + 5 < total) step(integral_constant<int, 5 % UT>{}, integral_constant<int, 0>{}, i0 + 5);
+                    if (i0 + 6 < total) step(integral_constant<int, 6 % UT>{}, integral_constant<int, 0>{}, i0 + 6);
+                    if (i0 + 7 < total) step(integral_constant<int, 7 % UT>{}, integral_constant<int, 0>{}, i0 + 7);
                 }
             }
     } else {
@@ -1170,8 +1310,11 @@ __device__ __forceinline__ uint32_t jt_flow_ticket(const JtFlow &fl, uint32_t *f
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)flow_ctl[0]);
 }
 
+#ifndef JT_FLOW_WAVES
+#define JT_FLOW_WAVES 4          // (A/B builds: -DJT_FLOW_WAVES=5 / 6 - fewer registers, more workgroups per CU)
+#endif
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS, 4) void jt_collect_flow(const JtTask *__restrict__ tasks,
+__global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_collect_flow(const JtTask *__restrict__ tasks,
                                                               const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                               const T *__restrict__ psi, T *__restrict__ bel,
                                                               double *__restrict__ msg, JtFlow fl) {
@@ -1232,7 +1375,7 @@ __device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict
 // tree); every message is then read through to memory (JtMsg::same_launch), also the upward messages the distribute
 // tasks read, because their producers ran in THIS launch.
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS, 4) void jt_propagate_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+__global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_propagate_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                                    const int *__restrict__ itab, const T *__restrict__ psi,
                                                                    T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
     __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];
@@ -1275,7 +1418,7 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_propagate_flow(const JtTask 
 // On plans made of latency-bound levels (chains, JtTask::settle) the spills sit on the dependent path - config 2
 // 3.56 -> 3.69 ms - so those run the build without (168 registers, three waves).
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS, 4) void jt_distribute_flow(const JtTask *__restrict__ tasks,
+__global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_distribute_flow(const JtTask *__restrict__ tasks,
                                                                     const JtBlock *__restrict__ blk, const int *__restrict__ itab,
                                                                     const T *__restrict__ psi, T *__restrict__ bel,
                                                                     double *__restrict__ msg, JtFlow fl) {
@@ -1551,6 +1694,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
                 }
             }
         }
+#ifdef JT_MULTI_OLD_SHUFFLES
 #pragma nounroll
         for (int b = 0; b < 6; ++b) {
             if ((o_redl >> b) & 1) {
@@ -1561,6 +1705,11 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
                         if ((e & o_rede) == 0) acc[s][e] += jt_shfl_xor(acc[s][e], 1 << b);
             }
         }
+#else
+        // (lane bits 0-3 through DPP row shifts, every set and element together: jt_lane_sums)
+#pragma unroll
+        for (int s = 0; s < G; ++s) jt_lane_sums<NACC>(acc[s], o_redl);
+#endif
         const bool rep = (lane & o_redl) == 0;
         const int slot = oo + thr_out;
         const int nph = 1 << __builtin_popcount((unsigned)o_redw);

@@ -2228,7 +2228,10 @@ int PlanBuilder::finish() {
     // through to memory, which costs where staging is a large share of the traffic (config 3) and buys nothing on chains.
     {
         const bool merge = hp.knobs.merge_phases == 1 ||
-                           (hp.knobs.merge_phases < 0 && !hp.multiset && !hp.chain_plan && !hp.tmix && hp.staging_bytes * 8.0 <= hp.table_bytes);
+                           (hp.knobs.merge_phases < 0 && !hp.multiset && !hp.chain_plan && !hp.tmix &&
+                            // (plans of mostly unit cliques: no tables to speak of, a second launch is a second cold start and every
+                            //  level counts - config 3 8.34 -> 8.13 ms, env sweep on one box, round 5)
+                            (hp.staging_bytes * 8.0 <= hp.table_bytes || hp.unit_dominated));
         if (merge && !hp.multiset && !hp.tmix) {
             std::vector<Segment> segs;
             std::vector<Step> fsteps;

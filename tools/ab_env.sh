@@ -1,15 +1,14 @@
 #!/bin/bash
-# A/B of ENVIRONMENT settings (planner knobs) on ONE box with the current library.
-#   bash tools/ab_env.sh OUTDIR "bench args" name1 "ENV1=.. ENV2=.." name2 "..." ...     (use "-" for no variables)
-OUT=$1; ARGS=$2; shift 2
-REPS=${REPS:-2}
-mkdir -p $OUT
-names=(); envs=()
-while [ $# -gt 1 ]; do names+=("$1"); envs+=("$2"); shift 2; done
-for i in $(seq $REPS); do
-  for j in "${!names[@]}"; do
-    e="${envs[$j]}"; [ "$e" = "-" ] && e=""
-    env $e python bench.py $ARGS --cpu-sample 0 > $OUT/${names[$j]}_$i.json 2>&1
-  done
+# Planner-knob sweep on config 3 inside ONE gpurun call (diagnostic)
+O=gpurun_out/ab_env.txt; : > $O
+run() { echo "== $*" >> $O; env "$@" timeout -k 10 120 python3 tools/c3_time.py >> $O 2>&1; }
+run A=default
+run JTP_MERGE_PHASES=0
+for b in 16384 20480 22528; do
+run JTP_TARGET_BLOCKS=1024 C3_LDS_BUDGET=$b
+run JTP_TARGET_BLOCKS=512 C3_LDS_BUDGET=$b
 done
-python tools/bsum.py $OUT/*.json | grep "ms/step\|unread"
+run JTP_TARGET_BLOCKS=1024 JTP_TARGET_BLOCKS_D=2048 C3_LDS_BUDGET=20480
+run JTP_TARGET_BLOCKS=2048 JTP_TARGET_BLOCKS_D=1024 C3_LDS_BUDGET=20480
+run A=default
+cat $O

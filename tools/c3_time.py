@@ -16,7 +16,8 @@ order = [names[i, j] for j in range(W) for i in range(H)] if os.environ.get("C3_
 tree = jt.create_junction_tree(factors, sizes, order=order)
 node_vars = [list(c) for c in tree.clique_tree.maxcliques] + [list(s) for s in tree.separators]
 # (C3_NO_COVER=1: every clique keeps a full table, as in rounds 1-4)
-plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", cover=None if os.environ.get("C3_NO_COVER") else tree.cover())
+plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", cover=None if os.environ.get("C3_NO_COVER") else tree.cover(),
+                   lds_budget=int(os.environ.get("C3_LDS_BUDGET", "0")), block_log2=int(os.environ.get("C3_BLOCK_LOG2", "0")))
 plan.fill_synthetic(1, [8.0 ** -(len(c) - 1) for c in tree.clique_tree.maxcliques])
 for _ in range(2):
     plan.propagate()
