@@ -295,6 +295,7 @@ struct jtp_plan {
     std::vector<BatchBuffers> bufs;
     JtTask *d_tasks = nullptr;
     JtBlock *d_blocks = nullptr;
+    JtBlock *d_init[2] = {nullptr, nullptr};      // HostPlan::init_blocks on the device (mixed-radix plans)
     int *d_itab = nullptr;
     void *stage = nullptr;          // device staging buffer for host<->device conversion
     size_t stage_bytes = 0;
@@ -566,6 +567,8 @@ void jtp_plan_destroy(jtp_plan *pl) {
         }
         if (pl->d_tasks) (void)hipFree(pl->d_tasks);
         if (pl->d_blocks) (void)hipFree(pl->d_blocks);
+        for (int m = 0; m < 2; ++m)
+            if (pl->d_init[m]) (void)hipFree(pl->d_init[m]);
         if (pl->d_itab) (void)hipFree(pl->d_itab);
         if (pl->stage) (void)hipFree(pl->stage);
         for (int i = 0; i < 2; ++i) {
@@ -582,6 +585,8 @@ void jtp_plan_destroy(jtp_plan *pl) {
     }
     delete pl;
 }
+
+static int zero_padding(jtp_plan *pl, BatchBuffers &b, hipStream_t s);
 
 int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     if (!out) return set_err(JTP_EINVAL, "null output pointer");
@@ -802,6 +807,11 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         CREATE_TRY(hipMalloc((void **)&pl->d_itab, hp.itab.size() * sizeof(int32_t)));
         CREATE_TRY(hipMemcpy(pl->d_itab, hp.itab.data(), hp.itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    for (int m = 0; m < 2; ++m)
+        if (!hp.init_blocks[m].empty()) {
+            CREATE_TRY(hipMalloc((void **)&pl->d_init[m], hp.init_blocks[m].size() * sizeof(JtBlock)));
+            CREATE_TRY(hipMemcpy(pl->d_init[m], hp.init_blocks[m].data(), hp.init_blocks[m].size() * sizeof(JtBlock), hipMemcpyHostToDevice));
+        }
     // dynamic LDS beyond 64 KiB has to be allowed per kernel function (raise_lds remembers what each one has)
     auto kfunc = [&](int v) { return hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v, hp.tmix) : (const void *)KernelTable<double>::get(v, hp.tmix); };
     if (pl->multiset) {
@@ -828,6 +838,12 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         b += (double)hp.tasks.size() * sizeof(JtTask) + (double)hp.blocks.size() * sizeof(JtBlock) + (double)hp.itab.size() * 4;
         pl->device_bytes = b;
     }
+    if (!pl->multiset)
+        for (auto &b : pl->bufs)
+            if (int rc = zero_padding(pl, b, pl->streams[0])) {
+                jtp_plan_destroy(pl);
+                return rc;
+            }
     CREATE_TRY(hipStreamSynchronize(pl->streams[0]));
 #undef CREATE_TRY
     *out = pl;
@@ -1180,6 +1196,30 @@ static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipSt
     return JTP_OK;
 }
 
+// Mixed-radix plans: the chunks whose own digits do not exist are not in the block lists (HostPlan::init_blocks) - their partial
+// copies are zeros, written HERE once per arena half, on `s`, after the arena was set to "unwritten": those entries carry no
+// marker from then on (nobody re-arms them), every propagate finds them written.
+static int zero_padding(jtp_plan *pl, BatchBuffers &b, hipStream_t s) {
+    const HostPlan &hp = pl->hp;
+    const int64_t half = std::max<int64_t>(hp.msg_doubles, 2);
+    for (int m = 0; m < 2; ++m) {
+        if (hp.init_blocks[m].empty() || !pl->d_init[m]) continue;
+        for (int h = 0; h < 2; ++h) {
+            JtFlow fl;
+            memset(&fl, 0, sizeof fl);
+            fl.sync = b.sync;
+            fl.host_abort = pl->host_abort;
+            fl.cur_off = h ? half : 0;
+            fl.oth_off = -1;
+            fl.fix_shift = b.fix_shift(fl.cur_off);
+            launch_variant(pl, m ? JT_K_DISTRIBUTE_LEVEL : JT_K_COLLECT_LEVEL, (int)hp.init_blocks[m].size(), hp.max_lds, s, pl->d_tasks, pl->d_init[m],
+                           pl->d_itab, b.psi, b.bel, b.msg, fl);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return JTP_OK;
+}
+
 // Called wherever the host has just synchronised with the plan's streams.  A dataflow launch whose
 // workgroups gave up waiting (it would take workgroups dispatched out of order, or a stuck device;
 // never observed) has left that propagate unfinished: mark the whole arena unwritten again, switch the
@@ -1219,6 +1259,8 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
         if (!b.unchecked) continue;
         HIP_TRY(hipMemset(b.sync, 0, (size_t)pl->hp.sync_words * 4));
         HIP_TRY(hipMemsetD32((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 4));
+        if (int rc = zero_padding(pl, b, pl->streams[0])) return rc;
+        HIP_TRY(hipStreamSynchronize(pl->streams[0]));
         b.epoch = 0;
         b.flow_runs = 0;
         b.ticket_runs = 0;

@@ -703,9 +703,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         {
             constexpr int j = decltype(j_tag)::value;
             const int red_e = o_rede[j], red_lane = o_redl[j], red_wave = o_redw[j];
-            if constexpr (UNIT && MODE == 0) {
+            if constexpr ((UNIT || TMIX) && MODE == 0) {
                 // (which entries of the thread part exist does not change from row to row: applied to the sums of a run, not to
-                //  every product)
+                //  every product; mixed-radix rows: an entry that does not exist was gathered from the row's first element)
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
                     if (tpo[e] < 0) acc[j][e] = 0.0;
@@ -767,7 +767,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             // (filled in below, once the row is known to exist)
         } else if constexpr (TMIX) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) p[e] = tpo[e] >= 0 ? (double)tbuf[SLOT][e] : 0.0;
+            for (int e = 0; e < VEC; ++e) p[e] = (MODE == 0 || tpo[e] >= 0) ? (double)tbuf[SLOT][e] : 0.0;
             const int inext = (i + UT < total) ? i + UT : total - 1;
             const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
             gather_row(SLOT, xnext, xnext != JT_NO_ROW && chunk_ok && i + UT < total);
@@ -1841,13 +1841,28 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
 #pragma unroll
             for (int s = 0; s < G; ++s) {
                 load_set(s, cur);
-                const double rs = __hiloint2double(__builtin_amdgcn_readfirstlane(((rowok >> s) & 1u) ? 0x3FF00000 : 0), 0);
+                if constexpr (ROWEV) {
+                    const double rs = __hiloint2double(__builtin_amdgcn_readfirstlane(((rowok >> s) & 1u) ? 0x3FF00000 : 0), 0);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    double w = p[e];
+                    for (int e = 0; e < VEC; ++e) {
+                        double w = p[e];
 #pragma unroll
-                    for (int k = 0; k < NIN; ++k) w *= cur[k][e];
-                    acc[s][e] = __builtin_fma(w, rs, acc[s][e]);
+                        for (int k = 0; k < NIN; ++k) w *= cur[k][e];
+                        acc[s][e] = __builtin_fma(w, rs, acc[s][e]);
+                    }
+                } else {
+                    // (no set of the group observes a variable on the row bits - decided once per workgroup: the last message
+                    //  entry is the multiplier of the accumulating fma, NIN operations per element and set instead of NIN + 1)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if constexpr (NIN == 0) acc[s][e] += p[e];
+                        else {
+                            double w = p[e];
+#pragma unroll
+                            for (int k = 0; k + 1 < NIN; ++k) w *= cur[k][e];
+                            acc[s][e] = __builtin_fma(w, cur[NIN - 1][e], acc[s][e]);
+                        }
+                    }
                 }
             }
         }

@@ -674,6 +674,7 @@ PlanKnobs jtp_read_knobs() {
     k.marg_group = std::max(1, std::min(geti("JTP_MARG_GROUP", JT_MAX_OUT), JT_MAX_OUT));
     k.marg_block_log2 = geti("JTP_MARG_BLOCK_LOG2", 0);
     k.no_unit = geti("JTP_NO_UNIT", 0);
+    k.keep_invalid = geti("JTP_KEEP_INVALID", 0);
     k.unit_joint_down = geti("JTP_UNIT_JOINT_DOWN", 0);
     k.no_ef_share = geti("JTP_EF_SHARE", 0) ? -1 : geti("JTP_NO_EF_SHARE", 0);      // (-1: the evidence-free group whatever the number of sets)
     k.unit_ratio = getd("JTP_UNIT_RATIO", 4.0);
@@ -2096,7 +2097,14 @@ int PlanBuilder::schedule() {
             for (int t : L.tasks) {
                 const JtTask &tk = hp.tasks[t];
                 for (uint32_t f = 0; f < (1u << tk.nF); ++f) {
-                    hp.blocks.push_back(jtp_make_block(hp, tk, (uint32_t)t, f));
+                    const JtBlock b = jtp_make_block(hp, tk, (uint32_t)t, f);
+                    if ((b.flags & JT_BLOCK_INVALID) && hp.tmix && !hp.multiset && !hp.knobs.keep_invalid) {
+                        // (a chunk that does not exist: zeros, written once per arena - HostPlan::init_blocks)
+                        hp.init_blocks[tk.mode ? 1 : 0].push_back(b);
+                        hp.init_chunk[tk.mode ? 1 : 0].push_back(f);
+                        continue;
+                    }
+                    hp.blocks.push_back(b);
                     hp.block_chunk.push_back(f);
                 }
                 L.lds_bytes = std::max(L.lds_bytes, tk.lds_bytes);
@@ -2612,6 +2620,21 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             o << "," << k.lxF << "," << k.flags;
             o << "]";
         }
+        o << "],\"init_blocks\":[";
+        bool first_init = true;
+        for (int m = 0; m < 2; ++m)
+            for (size_t b = 0; b < hp.init_blocks[m].size(); ++b) {
+                if (!first_init) o << ",";
+                first_init = false;
+                const JtBlock &k = hp.init_blocks[m][b];
+                o << "[" << k.task << "," << hp.init_chunk[m][b] << "," << k.xF;
+                for (int i = 0; i < JT_MAX_MSG; ++i) o << "," << k.gbase[i];
+                for (int i = 0; i < JT_MAX_OUT; ++i) o << "," << k.pnum[i];
+                o << "," << k.psi_x0;
+                for (int i = 0; i < 8; ++i) o << "," << k.first_x[i];
+                o << "," << k.lxF << "," << k.flags;
+                o << "]";
+            }
         o << "]";
     }
     o << "}";

@@ -148,6 +148,7 @@ struct PlanKnobs {
     double keep_rows_mb = 128.0;                                      // JTP_KEEP_ROWS_MB: table rows of the levels nearest the root, up to this many MiB, are loaded with the default cache policy (0: all non-temporal; A/B on one box: config 4 0.6037 -> 0.5990 ms, an 8-rank share of it 198.5 -> 195.4 us)
     int no_ef_share = 0;                                            // JTP_NO_EF_SHARE: multi-set plans compute every set's upward messages (round 4), no evidence-free group to copy from
     int unit_joint_down = 0;                                        // JTP_UNIT_JOINT_DOWN: a unit clique forms its downward messages in ONE mode-1 pass (the first form of round 5) instead of a task each
+    int keep_invalid = 0;                                           // JTP_KEEP_INVALID: chunks that do not exist stay in the block lists (rounds 2-4)
     int no_unit = 0;                                                // JTP_NO_UNIT: no unit cliques - every clique (virtual ones too) keeps a full table (rounds 1-4)
     double unit_ratio = 4.0;                                        // JTP_UNIT_RATIO: a clique becomes a unit clique when its table is at least this many times its covered part
     int marg_group = JT_MAX_OUT;                                    // JTP_MARG_GROUP: marginals of one belief table formed by one pass over it (1: a pass each, round 3)
@@ -179,6 +180,12 @@ struct HostPlan {
     std::vector<JtBlock> blocks;
     std::vector<int32_t> itab;           // iteration tables of all tasks (JtTask::itab_off)
     std::vector<uint32_t> block_chunk;   // chunk number of each block (description/tests)
+    // Mixed-radix plans (tmix, single-set): the chunks whose own digits do not exist (JT_BLOCK_INVALID) have no rows and read no
+    // message - all they ever write is the zeros of their partial copies, the same zeros every propagate.  They are NOT in
+    // `blocks`: the engine runs them once per arena half after the arena is (re)initialised (no marker for those entries
+    // afterwards: they stay 0.0, "written", for good).  [0]: tasks of mode 0, [1]: mode 1 (the level kernel of each).
+    std::vector<JtBlock> init_blocks[2];
+    std::vector<uint32_t> init_chunk[2];
     std::vector<VirtualFill> virtual_fills;
     std::vector<PStatic> statics;        // static tables of unit cliques (PNode::stat)
     int64_t fix_doubles = 0;             // size of the fixed arena (doubles)

@@ -208,6 +208,11 @@ class Emulator:
             s = np.arange(1 << m["nfree"], dtype=np.int64)
             idx = _scatter(s, m["free_pos"])
             tot = np.zeros(len(s))
+            if self.d.get("tmix") and not chunk_ok:
+                # mixed-radix plans: a chunk that does not exist stages nothing and waits for nobody (jt_pass: `!TMIX || chunk_ok`) -
+                # which is what lets the engine run it before any message exists (init_blocks)
+                subs.append(tot)
+                continue
             if m.get("fixed"):      # the clique's static table: one copy in the fixed arena, never "unwritten"
                 assert m["npart"] == 1 and not m["same_launch"] and tk["unit"]
                 subs.append(self.fix[m["off"] + gb_in[k] + idx])
@@ -371,6 +376,7 @@ class Emulator:
         device-side waits deadlock free once workgroups draw their list position from a ticket."""
         d = self.d
         self.msg[:] = np.nan
+        self._init_blocks()
         tickets = [g["ticket_idx"] for g in d["segments"]]
         assert len(set(tickets)) == len(tickets) and all(2 <= t < d["sync_words"] for t in tickets)
         covered = []
@@ -393,6 +399,24 @@ class Emulator:
         assert covered == list(range(len(d["launches"])))
         self._check_unit_counts()
 
+    def _init_blocks(self):
+        """Mixed-radix plans: the chunks that do not exist are not in the block lists - the engine runs them once per arena half
+        when the arena is initialised (jtp_engine.hip zero_padding): all they write is zeros."""
+        d = self.d
+        self._init_seen = {}
+        for blk in d.get("init_blocks", []):
+            tk = d["tasks"][blk[0]]
+            assert d["tmix"] and not d.get("multiset") and tk["kind"] == 0 and (blk[23] & 1) == 1, "only chunks that do not exist may be run at initialisation"
+            before = np.isnan(self.msg)
+            self._block(tk, blk[1], tk["mode"] == 0, blk[2:])
+            written = before & ~np.isnan(self.msg)
+            assert np.all(self.msg[written] == 0.0), "a chunk that does not exist wrote something else than zeros"
+            for j, m in enumerate(tk["out"]):        # ... and it wrote its WHOLE partial copy
+                sub = np.arange(1 << m["nfree"], dtype=np.int64)
+                dst = m["off"] + blk[10 + j] * m["pstride"] + blk[3 + JT_MAX_IN + j] + _scatter(sub, m["free_pos"])
+                assert np.all(self.msg[dst] == 0.0)
+            self._init_seen.setdefault(blk[0], set()).add(blk[1])
+
     def _check_unit_counts(self):
         for tk in self.d["tasks"]:
             if tk["kind"] == 0 and "_live" in tk:
@@ -404,6 +428,7 @@ class Emulator:
         plan's comm records) on the message arena `msg`; it is required for multi-rank plans."""
         d = self.d
         self.msg[:] = np.nan
+        self._init_blocks()
         for kind, first, count in d["steps"]:
             if kind == 1:
                 assert comm is not None, "multi-rank plan needs a comm callback"
@@ -425,5 +450,7 @@ class Emulator:
                 assert tk["lds_bytes"] <= launch["lds_bytes"]
                 seen.add((t, chunk))
                 self._block(tk, chunk, tk["mode"] == 0, blk[2:])
-            assert len(seen) == len(blocks) == sum(1 << d["tasks"][t]["nF"] for t in launch["tasks"])
+            # (every chunk of every task once: in the launch, or - a chunk that does not exist, mixed-radix plans - at initialisation)
+            assert all(not ((t, c) in seen) for t in launch["tasks"] for c in self._init_seen.get(t, ()))
+            assert len(seen) == len(blocks) == sum((1 << d["tasks"][t]["nF"]) - len(self._init_seen.get(t, ())) for t in launch["tasks"])
         self._check_unit_counts()

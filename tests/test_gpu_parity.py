@@ -1256,3 +1256,49 @@ def test_junction_trees_of_a_given_elimination_order():
     with pytest.raises(ValueError):
         jt.create_junction_tree(factors, sizes, order=[1, 1])
     engine.clear_plan_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("card,width,sep,dtype", [(3, 11, 5, "f32"), (5, 7, 3, "f32"), (3, 10, 5, "f64"), (6, 6, 3, "f32")])
+def test_chunks_that_do_not_exist_are_run_once_per_arena_not_once_per_propagate(card, width, sep, dtype):
+    """Mixed-radix plans (round 5): the workgroups of chunks whose own digits do not exist write nothing but the zeros of their
+    partial copies.  They are no longer in the block lists - `jtp_plan_create` runs them once per arena half (`init_blocks` in the
+    description) - so every later propagate must still find those zeros: three propagates with changing potentials (both arena
+    halves in use), each against the oracle, in dataflow launches and in per-level launches; the same plan with JTP_KEEP_INVALID=1
+    (rounds 2-4: every chunk in the lists) gives the same bits."""
+    import os
+    spec = synthetic.wide_binary_tree(n_cliques=7, width=width, sep=sep, card=card, seed=card + width)
+    results = {}
+    for mode in ("flow", "levels", "keep"):
+        if mode == "keep":
+            os.environ["JTP_KEEP_INVALID"] = "1"
+        try:
+            plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, level_launches=(mode == "levels"))
+        finally:
+            os.environ.pop("JTP_KEEP_INVALID", None)
+        d = plan.describe()
+        assert d["tmix"] == 1
+        if mode == "keep":
+            assert not d["init_blocks"] and any(b[23] & 1 for b in d["blocks"])
+        else:
+            assert d["init_blocks"] and not any(b[23] & 1 for b in d["blocks"])
+        got = []
+        for rep in range(3):
+            pots = synthetic.potentials_for(spec, seed=20 + rep)
+            for c in plan.cliques:
+                plan.set_potential(c, pots[c])
+            plan.propagate()
+            want = oracle.beliefs_exact(spec["tree"], pots, spec["node_vars"])
+            tol = 2e-5 if dtype == "f32" else 1e-11
+            for c in plan.cliques:
+                b = plan.belief(c)
+                np.testing.assert_allclose(b, want[c], rtol=tol, atol=tol * np.max(want[c]))
+            got.append([plan.belief(c).copy() for c in plan.cliques] + [plan.belief(s).copy() for s in plan.seps])
+        assert plan.stats()["flow_fallbacks"] == 0
+        results[mode] = got
+        plan.close()
+    for rep in range(3):
+        for a, b in zip(results["flow"][rep], results["keep"][rep]):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(results["flow"][rep], results["levels"][rep]):
+            np.testing.assert_array_equal(a, b)
