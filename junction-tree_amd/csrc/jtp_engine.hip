@@ -1196,25 +1196,34 @@ static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipSt
     return JTP_OK;
 }
 
-// Mixed-radix plans: the chunks whose own digits do not exist are not in the block lists (HostPlan::init_blocks) - their partial
-// copies are zeros, written HERE once per arena half, on `s`, after the arena was set to "unwritten": those entries carry no
-// marker from then on (nobody re-arms them), every propagate finds them written.
+// The chunks whose own digits do not exist (a digit beyond a variable's cardinality, a padding bit set) are not in the block
+// lists of a single-set plan (HostPlan::init_blocks): whatever their incoming messages, all they would write is their partial
+// copies of the outgoing messages, all zeros.  Those zeros are written HERE, once per arena half, on `s`, after the arena was set
+// to "unwritten": the entries carry no marker from then on (nobody re-arms them), every propagate finds them written.
+__global__ __launch_bounds__(256) void jt_zero_copies(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk, double *__restrict__ msg,
+                                                      int64_t cur_off) {
+    const JtBlock &bk = blk[blockIdx.x];
+    const JtTask &tk = tasks[bk.task];
+    for (int j = 0; j < tk.n_out; ++j) {
+        const JtMsg &m = tk.msg[JT_MAX_IN + j];
+        // (where a workgroup's flush puts entry s of its sub-box: jt_pass, "flush outgoing sub-boxes")
+        const int64_t at = cur_off + m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
+        const int n = 1 << m.nfree;
+        for (int s = threadIdx.x; s < n; s += 256) {
+            uint32_t idx = 0;
+            for (int b = 0; b < m.nfree; ++b) idx += (((uint32_t)s >> b) & 1u) << m.free_pos[b];
+            msg[at + idx] = 0.0;
+        }
+    }
+}
+
 static int zero_padding(jtp_plan *pl, BatchBuffers &b, hipStream_t s) {
     const HostPlan &hp = pl->hp;
     const int64_t half = std::max<int64_t>(hp.msg_doubles, 2);
     for (int m = 0; m < 2; ++m) {
         if (hp.init_blocks[m].empty() || !pl->d_init[m]) continue;
-        for (int h = 0; h < 2; ++h) {
-            JtFlow fl;
-            memset(&fl, 0, sizeof fl);
-            fl.sync = b.sync;
-            fl.host_abort = pl->host_abort;
-            fl.cur_off = h ? half : 0;
-            fl.oth_off = -1;
-            fl.fix_shift = b.fix_shift(fl.cur_off);
-            launch_variant(pl, m ? JT_K_DISTRIBUTE_LEVEL : JT_K_COLLECT_LEVEL, (int)hp.init_blocks[m].size(), hp.max_lds, s, pl->d_tasks, pl->d_init[m],
-                           pl->d_itab, b.psi, b.bel, b.msg, fl);
-        }
+        for (int h = 0; h < 2; ++h)
+            hipLaunchKernelGGL(jt_zero_copies, dim3((unsigned)hp.init_blocks[m].size()), dim3(256), 0, s, pl->d_tasks, pl->d_init[m], b.msg, h ? half : (int64_t)0);
     }
     HIP_TRY(hipGetLastError());
     return JTP_OK;

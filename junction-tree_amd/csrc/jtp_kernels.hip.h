@@ -34,8 +34,11 @@
 
 #include "jtp_internal.h"
 
+#ifndef JT_MIX_WAVES
+#define JT_MIX_WAVES 4          // waves per SIMD the dataflow *_mix kernels are compiled for (3: no spills, and 6-16 % slower on cardinality 3 / 5 trees, 3 % faster on cardinality 6 - A/B on one box)
+#endif
 #ifndef JT_UT
-#define JT_UT 8                 // ... of a mixed-radix plan (rows gathered into registers, *_mix kernels): 4 or 8
+#define JT_UT 4                 // ... of a mixed-radix plan (rows gathered into registers, *_mix kernels): 4 or 8 (8: 2-4 % slower, A/B on one box)
 #endif
 #ifndef JT_U
 #define JT_U 4                  // loop iterations whose element loads are in flight
@@ -242,7 +245,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     constexpr int NMSG = NIN + NOUT;
     constexpr int NPAR = NIN - NOUT * (MODE == 1);   // distribute: leading inputs that are not children
     constexpr int U = JT_U;                          // element loads in flight per wave
-    // (mixed-radix rows are gathered into registers, a few hundred bytes each: twice the rows in flight)
+    // (mixed-radix rows are gathered into registers, a few hundred bytes each; JT_UT = 8 - twice the rows in flight - was tried: slower)
     constexpr int UT = TMIX ? JT_UT : U;
     static_assert((U == 4 || U == 8) && (1 << JT_MIN_ITER_LOG2) == 4 && JT_RING_BYTES == U * 4096, "the loop groups below are written out for four or eight slots");
     using VT = typename JtVec<T>::type;
@@ -2139,7 +2142,7 @@ __global__ __launch_bounds__(JT_THREADS, 3) void jt_single_mix(const JtTask *__r
     else jt_distribute_mix<T, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
 }
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS, 3) void jt_collect_flow_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+__global__ __launch_bounds__(JT_THREADS, JT_MIX_WAVES) void jt_collect_flow_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                                      const int *__restrict__ itab, const T *__restrict__ psi,
                                                                      T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
     __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];
@@ -2151,7 +2154,7 @@ __global__ __launch_bounds__(JT_THREADS, 3) void jt_collect_flow_mix(const JtTas
     else jt_collect_mix<T, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
 }
 template <typename T>
-__global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_flow_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+__global__ __launch_bounds__(JT_THREADS, JT_MIX_WAVES) void jt_distribute_flow_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                                         const int *__restrict__ itab, const T *__restrict__ psi,
                                                                         T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
     __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];

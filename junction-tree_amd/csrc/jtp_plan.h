@@ -180,10 +180,10 @@ struct HostPlan {
     std::vector<JtBlock> blocks;
     std::vector<int32_t> itab;           // iteration tables of all tasks (JtTask::itab_off)
     std::vector<uint32_t> block_chunk;   // chunk number of each block (description/tests)
-    // Mixed-radix plans (tmix, single-set): the chunks whose own digits do not exist (JT_BLOCK_INVALID) have no rows and read no
-    // message - all they ever write is the zeros of their partial copies, the same zeros every propagate.  They are NOT in
-    // `blocks`: the engine runs them once per arena half after the arena is (re)initialised (no marker for those entries
-    // afterwards: they stay 0.0, "written", for good).  [0]: tasks of mode 0, [1]: mode 1 (the level kernel of each).
+    // Single-set plans: the chunks whose own digits do not exist (JT_BLOCK_INVALID: tables stored at true cardinalities) have no
+    // rows - all they would ever write is the zeros of their partial copies, the same zeros every propagate.  They are NOT in
+    // `blocks`: the engine zeroes those copies once per arena half after the arena is (re)initialised (no marker for those
+    // entries afterwards: they stay 0.0, "written", for good).  [0]: tasks of mode 0, [1]: mode 1.
     std::vector<JtBlock> init_blocks[2];
     std::vector<uint32_t> init_chunk[2];
     std::vector<VirtualFill> virtual_fills;

@@ -162,7 +162,7 @@ class Emulator:
         assert np.all(np.isnan(self.msg[dst["off"] + i])), "a summed entry is written twice"
         self.msg[dst["off"] + i] = tot
 
-    def _block(self, tk, chunk, collect, record=None, strict=False):
+    def _block(self, tk, chunk, collect, record=None, strict=False, init=False):
         if tk["kind"] == 1:
             return self._reduce_block(tk, chunk, record, strict)
         VEC, EB = self.VEC, self.EB
@@ -208,9 +208,9 @@ class Emulator:
             s = np.arange(1 << m["nfree"], dtype=np.int64)
             idx = _scatter(s, m["free_pos"])
             tot = np.zeros(len(s))
-            if self.d.get("tmix") and not chunk_ok:
-                # mixed-radix plans: a chunk that does not exist stages nothing and waits for nobody (jt_pass: `!TMIX || chunk_ok`) -
-                # which is what lets the engine run it before any message exists (init_blocks)
+            if (self.d.get("tmix") or init) and not chunk_ok:
+                # a chunk that does not exist: in mixed-radix plans it stages nothing and waits for nobody (jt_pass: `!TMIX || chunk_ok`);
+                # at initialisation (init_blocks) nothing is read at all - its partial copies are zeros whatever comes in
                 subs.append(tot)
                 continue
             if m.get("fixed"):      # the clique's static table: one copy in the fixed arena, never "unwritten"
@@ -400,15 +400,15 @@ class Emulator:
         self._check_unit_counts()
 
     def _init_blocks(self):
-        """Mixed-radix plans: the chunks that do not exist are not in the block lists - the engine runs them once per arena half
-        when the arena is initialised (jtp_engine.hip zero_padding): all they write is zeros."""
+        """Single-set plans: the chunks that do not exist are not in the block lists - the engine zeroes their partial copies once
+        per arena half when the arena is initialised (jtp_engine.hip zero_padding)."""
         d = self.d
         self._init_seen = {}
         for blk in d.get("init_blocks", []):
             tk = d["tasks"][blk[0]]
-            assert d["tmix"] and not d.get("multiset") and tk["kind"] == 0 and (blk[23] & 1) == 1, "only chunks that do not exist may be run at initialisation"
+            assert not d.get("multiset") and tk["kind"] == 0 and (blk[23] & 1) == 1, "only chunks that do not exist may be run at initialisation"
             before = np.isnan(self.msg)
-            self._block(tk, blk[1], tk["mode"] == 0, blk[2:])
+            self._block(tk, blk[1], tk["mode"] == 0, blk[2:], init=True)
             written = before & ~np.isnan(self.msg)
             assert np.all(self.msg[written] == 0.0), "a chunk that does not exist wrote something else than zeros"
             for j, m in enumerate(tk["out"]):        # ... and it wrote its WHOLE partial copy
