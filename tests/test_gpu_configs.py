@@ -55,8 +55,9 @@ def test_config3_lattice_card8_f32_vs_oracle():
     plan = tree.plan("f32")
     d = plan.describe()
     st = plan.stats()
-    # sub-boxes beyond 64 KiB make the engine launch per level (jtp_plan_create); otherwise one launch per phase
-    assert (st["n_launches"] == 2) == (d["max_lds"] <= 64 * 1024), (st["n_launches"], d["max_lds"])
+    # sub-boxes beyond 64 KiB make the engine launch per level (jtp_plan_create); otherwise one launch per phase, or - plans made
+    # mostly of cliques that keep no table, round 5 - one launch for both phases
+    assert (st["n_launches"] <= 2) == (d["max_lds"] <= 64 * 1024), (st["n_launches"], d["max_lds"])
     want = oracle.propagate(tree.tree, tree.separators, ct.maxcliques, ct.factor_to_maxclique, factors, sizes, values)
     assert len(out) == len(values)
     for i, (o, w, v) in enumerate(zip(out, want, values)):
@@ -96,7 +97,7 @@ def test_config3_full_lattice_properties():
     assert st["n_unit_cliques"] >= 365 and st["algorithmic_bytes"] < 0.2 * st["algorithmic_bytes_full"]
     # (round 2: the searched layouts keep every sub-box set below 64 KiB, so this config runs as two dataflow
     #  launches; with larger sub-boxes the engine launches per level)
-    assert (plan.stats()["n_launches"] == 2) == (plan.describe()["max_lds"] <= 64 * 1024)
+    assert (plan.stats()["n_launches"] <= 2) == (plan.describe()["max_lds"] <= 64 * 1024)
     z = plan.z()
     assert np.isfinite(z) and z > 0
     sums = np.array([o.sum() for o in out])
