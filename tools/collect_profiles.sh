@@ -34,6 +34,11 @@ for k in 0 1 0 1; do timeout 300 $B --steps 40 --warmup 10 --cpu-sample 0 --idle
 hdr $OUT/rank_time_8.txt; timeout 300 python3 tools/rank_time.py 8 30 >> $OUT/rank_time_8.txt 2>&1
 hdr $OUT/odd_cardinalities.txt
 for a in "3 13 6 63 f32" "3 12 6 63 f64" "5 9 4 63 f32" "6 8 4 63 f32" "7 7 3 63 f32"; do timeout 300 python3 tools/odd_time.py $a >> $OUT/odd_cardinalities.txt 2>&1; done
+# ... the same trees with the chunks that do not exist back in the block lists (rounds 2-4), and one tree level by level
+echo "# JTP_KEEP_INVALID=1 (every chunk a workgroup of every propagate, as in rounds 2-4):" >> $OUT/odd_cardinalities.txt
+for a in "3 13 6 63 f32" "3 12 6 63 f64" "5 9 4 63 f32" "6 8 4 63 f32" "7 7 3 63 f32"; do JTP_KEEP_INVALID=1 timeout 300 python3 tools/odd_time.py $a >> $OUT/odd_cardinalities.txt 2>&1; done
+echo "# ODD_LEVELS=1 (one launch per level, every launch timed), cardinality 3 width 13 f32:" >> $OUT/odd_cardinalities.txt
+ODD_LEVELS=1 timeout 300 python3 tools/odd_time.py 3 13 6 63 f32 >> $OUT/odd_cardinalities.txt 2>&1
 if [ -f $L/libjtprop_stamps.so ]; then
   export JTPROP_LIB=$L/libjtprop_stamps.so JTP_DEBUG=2
   hdr $OUT/stage_times.txt; timeout 300 python3 tools/stamps.py >> $OUT/stage_times.txt 2>&1
