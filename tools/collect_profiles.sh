@@ -72,6 +72,11 @@ for c in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ
   n=$(echo $c | tr " " "_" | cut -c1-40)
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/valu_$n -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-profile --batch 64 --multiset > /dev/null 2> $OUT/valu_$n.err
 done
+# ... and of the message-passing kernel(s) on config 3 (tools/pmc_c3.sh: the same counters over tools/c3_time.py)
+hdr $OUT/counters_c3.txt
+echo "# bash tools/pmc_c3.sh: rocprofv3 --pmc <a few counters per pass> -- python3 tools/c3_time.py; means over the kernel's launches" >> $OUT/counters_c3.txt
+bash tools/pmc_c3.sh > /dev/null 2>&1
+grep "flow" gpurun_out/pmc_c3/summary.txt >> $OUT/counters_c3.txt
 # keep what travels back small: the per-dispatch traces are reduced here
 python3 tools/summarize_profiles.py $OUT
 find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete

@@ -7,7 +7,7 @@ for f in ("bench", "bench_driver_form", "bench_batch4", "bench_c2", "bench_c3", 
     shutil.copy(os.path.join(P, f + ".json"), os.path.join(D, "%s_%s.json" % (rnd, f)))
 shutil.copy(os.path.join(P, "kt_bench.json"), os.path.join(D, rnd + "_bench_under_rocprof.json"))
 shutil.copy(os.path.join(P, "bench_level.json"), os.path.join(D, rnd + "_bench_level_launches.json"))
-for f in ("per_launch", "rank_time_8", "odd_cardinalities", "stage_times", "stage_times_multiset8", "stage_times_rank0_of_8", "timeline_c3", "c3_api", "c3_api_column_sweep"):
+for f in ("per_launch", "rank_time_8", "odd_cardinalities", "stage_times", "stage_times_multiset8", "stage_times_rank0_of_8", "timeline_c3", "c3_api", "c3_api_column_sweep", "counters_c3"):
     shutil.copy(os.path.join(P, f + ".txt"), os.path.join(D, "%s_%s.txt" % (rnd, f)))
 for c in ("c2", "c3"):          # STAMPS_SUMMARY=1 still prints a line per level: keep every tenth, and the medians
     L = open(os.path.join(P, "stage_times_%s.txt" % c)).read().splitlines()
