@@ -586,7 +586,7 @@ void jtp_plan_destroy(jtp_plan *pl) {
     delete pl;
 }
 
-static int zero_padding(jtp_plan *pl, BatchBuffers &b, hipStream_t s);
+static int zero_padding(jtp_plan *pl, double *msg, int nsets, hipStream_t s, int halves = 3);
 
 int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     if (!out) return set_err(JTP_EINVAL, "null output pointer");
@@ -838,9 +838,14 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         b += (double)hp.tasks.size() * sizeof(JtTask) + (double)hp.blocks.size() * sizeof(JtBlock) + (double)hp.itab.size() * 4;
         pl->device_bytes = b;
     }
-    if (!pl->multiset)
+    if (pl->multiset) {
+        if (int rc = zero_padding(pl, pl->msg_all, pl->n_groups * JT_MSETS, pl->streams[0])) {
+            jtp_plan_destroy(pl);
+            return rc;
+        }
+    } else
         for (auto &b : pl->bufs)
-            if (int rc = zero_padding(pl, b, pl->streams[0])) {
+            if (int rc = zero_padding(pl, b.msg, 1, pl->streams[0])) {
                 jtp_plan_destroy(pl);
                 return rc;
             }
@@ -1201,12 +1206,13 @@ static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipSt
 // copies of the outgoing messages, all zeros.  Those zeros are written HERE, once per arena half, on `s`, after the arena was set
 // to "unwritten": the entries carry no marker from then on (nobody re-arms them), every propagate finds them written.
 __global__ __launch_bounds__(256) void jt_zero_copies(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk, double *__restrict__ msg,
-                                                      int64_t cur_off) {
+                                                      int64_t cur_off, int64_t set_stride) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
+    msg += (int64_t)blockIdx.y * set_stride;               // (multi-set plans: one arena per evidence set)
     for (int j = 0; j < tk.n_out; ++j) {
         const JtMsg &m = tk.msg[JT_MAX_IN + j];
-        // (where a workgroup's flush puts entry s of its sub-box: jt_pass, "flush outgoing sub-boxes")
+        // (where a workgroup's flush puts entry s of its sub-box: jt_pass / jt_mpass, "flush outgoing sub-boxes")
         const int64_t at = cur_off + m.off + (int64_t)bk.pnum[j] * m.pstride + bk.gbase[JT_MAX_IN + j];
         const int n = 1 << m.nfree;
         for (int s = threadIdx.x; s < n; s += 256) {
@@ -1217,13 +1223,16 @@ __global__ __launch_bounds__(256) void jt_zero_copies(const JtTask *__restrict__
     }
 }
 
-static int zero_padding(jtp_plan *pl, BatchBuffers &b, hipStream_t s) {
+// (`msg`, `nsets`: one evidence set's arena, or - multi-set plans - all of them, set_stride doubles apart; `halves`: bit h = arena half h)
+static int zero_padding(jtp_plan *pl, double *msg, int nsets, hipStream_t s, int halves) {
     const HostPlan &hp = pl->hp;
     const int64_t half = std::max<int64_t>(hp.msg_doubles, 2);
     for (int m = 0; m < 2; ++m) {
         if (hp.init_blocks[m].empty() || !pl->d_init[m]) continue;
         for (int h = 0; h < 2; ++h)
-            hipLaunchKernelGGL(jt_zero_copies, dim3((unsigned)hp.init_blocks[m].size()), dim3(256), 0, s, pl->d_tasks, pl->d_init[m], b.msg, h ? half : (int64_t)0);
+            if ((halves >> h) & 1)
+                hipLaunchKernelGGL(jt_zero_copies, dim3((unsigned)hp.init_blocks[m].size(), (unsigned)nsets), dim3(256), 0, s, pl->d_tasks, pl->d_init[m], msg,
+                                   h ? half : (int64_t)0, pl->set_stride);
     }
     HIP_TRY(hipGetLastError());
     return JTP_OK;
@@ -1261,6 +1270,8 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
     if (pl->multiset) {                                     // (all sets run together, the padding sets of the last group too)
         const size_t mbytes = (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 16;
         HIP_TRY(hipMemsetD32((hipDeviceptr_t)pl->msg_all, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), mbytes * pl->n_groups * JT_MSETS / 4));
+        if (int rc = zero_padding(pl, pl->msg_all, pl->n_groups * JT_MSETS, pl->streams[0])) return rc;
+        HIP_TRY(hipStreamSynchronize(pl->streams[0]));
         for (auto &b : pl->bufs) b.epoch = 0, b.flow_runs = 0, b.ticket_runs = 0;
     } else
     for (size_t i = 0; i < pl->bufs.size(); ++i) {
@@ -1268,7 +1279,7 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
         if (!b.unchecked) continue;
         HIP_TRY(hipMemset(b.sync, 0, (size_t)pl->hp.sync_words * 4));
         HIP_TRY(hipMemsetD32((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 4));
-        if (int rc = zero_padding(pl, b, pl->streams[0])) return rc;
+        if (int rc = zero_padding(pl, b.msg, 1, pl->streams[0])) return rc;
         HIP_TRY(hipStreamSynchronize(pl->streams[0]));
         b.epoch = 0;
         b.flow_runs = 0;
@@ -1517,6 +1528,10 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         }
         if (pl->n_fanout > 0)        // the messages of the skipped tasks, into the sets' own arenas (read-out, next propagate's markers)
             hipLaunchKernelGGL(jt_multi_fanout, dim3(pl->n_fanout), dim3(256), 0, s, pl->d_fanout, pl->msg_all, fl);
+        // (the copy pass marks every entry of a copied message "unwritten" in the other half - also the partial copies of chunks that do
+        //  not exist, which nobody would write again: those are set back to their zeros)
+        if (pl->n_fanout > 0 && fl.oth_off >= 0 && (pl->d_init[0] || pl->d_init[1]))
+            if (int rc = zero_padding(pl, pl->msg_all, pl->n_groups * JT_MSETS, s, fl.oth_off ? 2 : 1)) return rc;
         if (prof) {
             if (!mid_done) HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
             HIP_TRY(hipEventRecord(pl->ev[ev_base + 2], s));

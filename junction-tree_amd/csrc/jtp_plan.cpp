@@ -2098,7 +2098,7 @@ int PlanBuilder::schedule() {
                 const JtTask &tk = hp.tasks[t];
                 for (uint32_t f = 0; f < (1u << tk.nF); ++f) {
                     const JtBlock b = jtp_make_block(hp, tk, (uint32_t)t, f);
-                    if ((b.flags & JT_BLOCK_INVALID) && !hp.multiset && !hp.knobs.keep_invalid) {
+                    if ((b.flags & JT_BLOCK_INVALID) && !hp.knobs.keep_invalid) {
                         // (a chunk that does not exist: zeros, written once per arena - HostPlan::init_blocks)
                         hp.init_blocks[tk.mode ? 1 : 0].push_back(b);
                         hp.init_chunk[tk.mode ? 1 : 0].push_back(f);

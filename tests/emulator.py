@@ -406,7 +406,7 @@ class Emulator:
         self._init_seen = {}
         for blk in d.get("init_blocks", []):
             tk = d["tasks"][blk[0]]
-            assert not d.get("multiset") and tk["kind"] == 0 and (blk[23] & 1) == 1, "only chunks that do not exist may be run at initialisation"
+            assert tk["kind"] == 0 and (blk[23] & 1) == 1, "only chunks that do not exist may be run at initialisation"
             before = np.isnan(self.msg)
             self._block(tk, blk[1], tk["mode"] == 0, blk[2:], init=True)
             written = before & ~np.isnan(self.msg)

@@ -1303,3 +1303,40 @@ def test_chunks_that_do_not_exist_are_run_once_per_arena_not_once_per_propagate(
             np.testing.assert_array_equal(a, b)
         for a, b in zip(results["flow"][rep], results["levels"][rep]):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("card,width,sep", [(3, 8, 4), (5, 6, 3), (6, 5, 2)])
+def test_multiset_plans_with_odd_cardinalities_share_evidence_free_subtrees_while_evidence_changes(monkeypatch, card, width, sep):
+    """Multi-set plans whose tables are stored at true cardinalities (round 5): the partial copies of chunks that do not exist are
+    zeroed once per arena; the copy pass of the evidence-free subtrees (`jt_multi_fanout`) marks whole messages "unwritten" in the
+    other arena half - those copies included - and the engine sets them back.  Evidence that MOVES between propagates turns
+    skipped tasks into running ones and back (both arena halves): every set's Z and beliefs against the oracle each time, no
+    dataflow time-out."""
+    monkeypatch.setenv("JTP_EF_SHARE", "1")
+    spec = synthetic.wide_binary_tree(n_cliques=15, width=width, sep=sep, card=card, seed=card)
+    pots = synthetic.potentials_for(spec, seed=5)
+    labels = sorted(spec["sizes"])
+    nb = 12
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f64", n_batch=nb, share_potentials=True, multiset=True)
+    d = plan.describe()
+    assert d["init_blocks"] and not any(b[23] & 1 for b in d["blocks"])
+    for c in range(spec["n_cliques"]):
+        plan.set_potential(c, pots[c])
+    for rnd in range(4):
+        rng = np.random.default_rng(40 + rnd)
+        observed = []
+        for b in range(nb):
+            k = 0 if (b + rnd) % 3 == 0 else 1 + (b + rnd) % 4          # some sets without evidence, the others with evidence that moves
+            obs = {labels[i]: int(rng.integers(0, card)) for i in rng.choice(len(labels), size=k, replace=False)}
+            observed.append(obs)
+            plan.set_evidence(obs, batch=b)
+        plan.propagate(0, nb)
+        for b in range(nb):
+            w, zb = oracle.beliefs_exact(spec["tree"], _indicator_potentials(spec, pots, observed[b]), spec["node_vars"], return_z=True)
+            assert abs(plan.z(batch=b) - zb) <= 1e-11 * zb + 1e-300, (rnd, b)
+            for node in (0, spec["n_cliques"] - 1, spec["n_cliques"], len(spec["node_vars"]) - 1):
+                close(plan.belief(node, batch=b), w[node], what="round %d set %d node %d" % (rnd, b, node))
+    st = plan.stats()
+    assert st["flow_fallbacks"] == 0 and st["launch_mode"] == "flow"
+    plan.close()

@@ -341,14 +341,11 @@ def test_rows_above_the_thread_part_are_stored_at_true_cardinalities(card, width
             desc = plan.describe()
             assert desc["compact"] == (1 if compact else 0)
             sizes[compact] = desc["arena_elems"]
-            if not opts.get("multiset"):
-                # round 5: the partial copies of chunks whose digits do not exist are zeroed once per arena (init_blocks), not once per propagate
-                assert all((b[23] & 1) == 0 for b in desc["blocks"])
-                assert all((b[23] & 1) == 1 for b in desc["init_blocks"])
-                if opts.get("block_log2") == 10 and compact:
-                    assert desc["init_blocks"]
-            else:
-                assert not desc["init_blocks"]
+            # round 5: the partial copies of chunks whose digits do not exist are zeroed once per arena (init_blocks), not once per propagate
+            assert all((b[23] & 1) == 0 for b in desc["blocks"])
+            assert all((b[23] & 1) == 1 for b in desc["init_blocks"])
+            if opts.get("block_log2") == 10 and compact:
+                assert desc["init_blocks"]
             emu = Emulator(desc)
             for c in plan.cliques:
                 ids = [plan.var_id[lab] for lab in spec["node_vars"][c]]
