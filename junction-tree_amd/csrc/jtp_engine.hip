@@ -143,6 +143,11 @@ struct Range {
 // ------------------------------------------------------------------------------------------ plan object
 
 
+static bool flow_both() {
+    static const bool on = !(getenv("JTP_FLOW_BOTH") && atoi(getenv("JTP_FLOW_BOTH")) == 0);
+    return on;
+}
+
 template <typename T>
 struct KernelTable {
     typedef void (*fn)(const JtTask *, const JtBlock *, const int *, const T *, T *, double *, JtFlow);
@@ -180,6 +185,10 @@ struct KernelTable {
     static fn get_flow(int phase, bool chain, bool tmix) {
         if (tmix) return phase == 0 ? jt_collect_flow_mix<T> : jt_distribute_flow_mix<T>;      // (never merged: jtp_plan.cpp finish())
         if (phase == 2) return jt_propagate_flow<T>;                    // both phases in one launch
+        // The kernel that runs both phases dispatches on the task's mode, so it serves a distribute segment alone as well - and its
+        // build of the distribute pass is the faster one (round 5, A/B by environment on one box: config 3 in two launches 8.35 -> 8.13 ms,
+        // the whole gain of "one launch"; a rank's share of config 4 at 8 ranks 178 -> 176 us).  JTP_FLOW_BOTH=0: jt_distribute_flow as before.
+        if (phase == 1 && !chain && flow_both()) return jt_propagate_flow<T>;
         return phase == 0 ? jt_collect_flow<T> : (chain ? jt_distribute_flow_chain<T> : jt_distribute_flow<T>);
     }
 };
@@ -2163,7 +2172,8 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
         for (const Segment &sg : hp.segments) st->kernel_launches[sg.phase == 0 ? JT_K_MULTI_COLLECT : JT_K_MULTI_DISTRIBUTE] += flow ? 1 : sg.n_launch;
     } else if (flow) {
         for (const Segment &sg : hp.segments) {
-            const int v = sg.phase == 0 ? JT_K_COLLECT_FLOW : (sg.phase == 1 ? JT_K_DISTRIBUTE_FLOW : JT_K_BOTH_FLOW);
+            // (the kernel that actually runs: KernelTable::get_flow)
+            const int v = sg.phase == 0 ? JT_K_COLLECT_FLOW : (sg.phase == 1 && (pl->chain || hp.tmix || !flow_both()) ? JT_K_DISTRIBUTE_FLOW : JT_K_BOTH_FLOW);
             for (int i = sg.first_launch; i < sg.first_launch + sg.n_launch; ++i) st->kernel_bytes[v] += hp.launches[i].alg_bytes;
             st->kernel_launches[v] += 1;
         }
@@ -2216,7 +2226,7 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
                     st->kernel_ms[JT_K_BOTH_FLOW] = st->distribute_ms;
                 } else {
                     st->kernel_ms[JT_K_COLLECT_FLOW] = st->collect_ms;
-                    st->kernel_ms[JT_K_DISTRIBUTE_FLOW] = st->distribute_ms;
+                    st->kernel_ms[(pl->chain || hp.tmix || !flow_both()) ? JT_K_DISTRIBUTE_FLOW : JT_K_BOTH_FLOW] = st->distribute_ms;
                 }
             } else if (!(hp.flags & JTP_SPLIT_VARIANTS)) {
                 st->kernel_ms[JT_K_COLLECT_LEVEL] = st->collect_ms;

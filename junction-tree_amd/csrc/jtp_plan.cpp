@@ -2237,8 +2237,8 @@ int PlanBuilder::finish() {
     {
         const bool merge = hp.knobs.merge_phases == 1 ||
                            (hp.knobs.merge_phases < 0 && !hp.multiset && !hp.chain_plan && !hp.tmix &&
-                            // (plans of mostly unit cliques: no tables to speak of, a second launch is a second cold start and every
-                            //  level counts - config 3 8.34 -> 8.13 ms, env sweep on one box, round 5)
+                            // (plans of mostly unit cliques: no tables to speak of - one launch.  Measured the same as two launches once
+                            //  the distribute segment ran the two-phase kernel, whose build is the faster one: jtp_engine.hip, get_flow)
                             (hp.staging_bytes * 8.0 <= hp.table_bytes || hp.unit_dominated));
         if (merge && !hp.multiset && !hp.tmix) {
             std::vector<Segment> segs;
