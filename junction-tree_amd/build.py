@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "junctiontree_amd", "lib")
 LIB = os.path.join(LIBDIR, "libjtprop.so")
-INST = ["jtp_inst_%s_%s.hip" % (fam, t) for fam in ("multi", "mix", "both", "flow", "level", "shape") for t in ("f32", "f64")]
+INST = ["jtp_inst_%s_%s.hip" % (fam, t) for fam in ("multi", "mix", "mixc", "both", "flow", "level", "shape") for t in ("f32", "f64")]
 SOURCES = ["jtp_plan.cpp", "jtp_engine.hip"] + INST       # (compiled in parallel, one object each, then linked)
 DEPS = SOURCES + ["jtp_internal.h", "jtp_plan.h", "jtp_kernels.hip.h", os.path.join("..", "..", "include", "jtprop.h")]
 

@@ -143,6 +143,8 @@ struct Range {
 // ------------------------------------------------------------------------------------------ plan object
 
 
+static inline int mixk(const HostPlan &hp) { return hp.tmix ? (hp.tmix_compact ? 2 : 1) : 0; }
+
 static bool flow_both() {
     static const bool on = !(getenv("JTP_FLOW_BOTH") && atoi(getenv("JTP_FLOW_BOTH")) == 0);
     return on;
@@ -151,13 +153,21 @@ static bool flow_both() {
 template <typename T>
 struct KernelTable {
     typedef void (*fn)(const JtTask *, const JtBlock *, const int *, const T *, T *, double *, JtFlow);
-    static fn get(int variant, bool tmix) {
+    // (tmix: 0 no mixed-radix rows, 1 one row per step, 2 the compact form - two rows per step, HostPlan::tmix_compact: mixk())
+    static fn get(int variant, int tmix) {
+        if (tmix == 2) {
+            if (variant >= JT_K_COLLECT0 && variant <= JT_K_COLLECT3) return jt_collect_level_mix<T, true>;
+            if (variant >= JT_K_DIST_P0C0 && variant <= JT_K_DIST_P1C3) return jt_distribute_level_mix<T, true>;
+            if (variant == JT_K_COLLECT_LEVEL) return jt_collect_level_mix<T, true>;
+            if (variant == JT_K_DISTRIBUTE_LEVEL) return jt_distribute_level_mix<T, true>;
+            if (variant == JT_K_SINGLE || variant == JT_K_MARGINALS) return jt_single_mix<T, true>;
+        }
         if (tmix) {                 // plans with a mixed-radix thread part: one kernel per launch style (they dispatch on the task)
-            if (variant >= JT_K_COLLECT0 && variant <= JT_K_COLLECT3) return jt_collect_level_mix<T>;
-            if (variant >= JT_K_DIST_P0C0 && variant <= JT_K_DIST_P1C3) return jt_distribute_level_mix<T>;
-            if (variant == JT_K_COLLECT_LEVEL) return jt_collect_level_mix<T>;
-            if (variant == JT_K_DISTRIBUTE_LEVEL) return jt_distribute_level_mix<T>;
-            if (variant == JT_K_SINGLE || variant == JT_K_MARGINALS) return jt_single_mix<T>;
+            if (variant >= JT_K_COLLECT0 && variant <= JT_K_COLLECT3) return jt_collect_level_mix<T, false>;
+            if (variant >= JT_K_DIST_P0C0 && variant <= JT_K_DIST_P1C3) return jt_distribute_level_mix<T, false>;
+            if (variant == JT_K_COLLECT_LEVEL) return jt_collect_level_mix<T, false>;
+            if (variant == JT_K_DISTRIBUTE_LEVEL) return jt_distribute_level_mix<T, false>;
+            if (variant == JT_K_SINGLE || variant == JT_K_MARGINALS) return jt_single_mix<T, false>;
         }
         switch (variant) {
             case JT_K_COLLECT0: return jt_collect<T, 0>;
@@ -182,8 +192,9 @@ struct KernelTable {
         }
         return nullptr;
     }
-    static fn get_flow(int phase, bool chain, bool tmix) {
-        if (tmix) return phase == 0 ? jt_collect_flow_mix<T> : jt_distribute_flow_mix<T>;      // (never merged: jtp_plan.cpp finish())
+    static fn get_flow(int phase, bool chain, int tmix) {
+        if (tmix == 2) return phase == 0 ? jt_collect_flow_mix<T, true> : jt_distribute_flow_mix<T, true>;
+        if (tmix) return phase == 0 ? jt_collect_flow_mix<T, false> : jt_distribute_flow_mix<T, false>;      // (never merged: jtp_plan.cpp finish())
         if (phase == 2) return jt_propagate_flow<T>;                    // both phases in one launch
         // The kernel that runs both phases dispatches on the task's mode, so it serves a distribute segment alone as well - and its
         // build of the distribute pass is the faster one (round 5, A/B by environment on one box: config 3 in two launches 8.35 -> 8.13 ms,
@@ -822,7 +833,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             CREATE_TRY(hipMemcpy(pl->d_init[m], hp.init_blocks[m].data(), hp.init_blocks[m].size() * sizeof(JtBlock), hipMemcpyHostToDevice));
         }
     // dynamic LDS beyond 64 KiB has to be allowed per kernel function (raise_lds remembers what each one has)
-    auto kfunc = [&](int v) { return hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v, hp.tmix) : (const void *)KernelTable<double>::get(v, hp.tmix); };
+    auto kfunc = [&](int v) { return hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(v, mixk(hp)) : (const void *)KernelTable<double>::get(v, mixk(hp)); };
     if (pl->multiset) {
         CREATE_TRY(raise_lds(kfunc(JT_K_MULTI_COLLECT), JT_RING_BYTES + JT_MSETS * (JT_MSETS > 8 ? JT_SETB_SMALL : JT_SETB_LARGE)));
     } else if (hp.max_lds > 64 * 1024) {
@@ -831,7 +842,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             CREATE_TRY(raise_lds(kfunc(v), hp.max_lds));
         }
         for (int ph = 0; ph < 3; ++ph) {
-            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain, hp.tmix) : (const void *)KernelTable<double>::get_flow(ph, pl->chain, hp.tmix);
+            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain, mixk(hp)) : (const void *)KernelTable<double>::get_flow(ph, pl->chain, mixk(hp));
             CREATE_TRY(raise_lds(f, hp.max_lds));
         }
     }
@@ -1201,10 +1212,10 @@ int jtp_fill_synthetic(jtp_plan *pl, int32_t batch, uint64_t seed, const double 
 static int launch_variant(jtp_plan *pl, int variant, int nblocks, int lds, hipStream_t s, const JtTask *tasks,
                           const JtBlock *blocks, const int *itab, void *psi, void *bel, double *msg, const JtFlow &fl) {
     if (pl->hp.dtype == JTP_F32) {
-        auto f = KernelTable<float>::get(variant, pl->hp.tmix);
+        auto f = KernelTable<float>::get(variant, mixk(pl->hp));
         hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const float *)psi, (float *)bel, msg, fl);
     } else {
-        auto f = KernelTable<double>::get(variant, pl->hp.tmix);
+        auto f = KernelTable<double>::get(variant, mixk(pl->hp));
         hipLaunchKernelGGL(f, dim3(nblocks), dim3(JT_THREADS), lds, s, tasks, blocks, itab, (const double *)psi, (double *)bel, msg, fl);
     }
     return JTP_OK;
@@ -1612,10 +1623,10 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 fl.blk_base = (uint32_t)sg.blk_off;
                 fl.ticket_base = ticket_run * (uint32_t)sg.nblocks;
                 if (hp.dtype == JTP_F32)
-                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase, pl->chain, hp.tmix), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase, pl->chain, mixk(hp)), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const float *)bb.psi, (float *)bb.bel, bb.msg, fl);
                 else
-                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase, pl->chain, hp.tmix), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase, pl->chain, mixk(hp)), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const double *)bb.psi, (double *)bb.bel, bb.msg, fl);
             } else if (st.kind == 0) {
                 const Launch &L = hp.launches[st.first];
@@ -1744,7 +1755,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
             one.oth_off = -1;
             one.ev = b.ev;
             one.fix_shift = b.fix_shift(one.cur_off);
-            HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE, hp.tmix) : (const void *)KernelTable<double>::get(JT_K_SINGLE, hp.tmix), bt.lds));
+            HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE, mixk(hp)) : (const void *)KernelTable<double>::get(JT_K_SINGLE, mixk(hp)), bt.lds));
             launch_variant(pl, JT_K_SINGLE, bt.nblocks, bt.lds, s, bt.d_task, bt.d_blk, bt.d_tab, b.psi, bel_src, b.msg, one);
             HIP_TRY(hipGetLastError());
         }
@@ -1984,9 +1995,9 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
     }
     // the kernels that are actually launched below must be allowed this much dynamic LDS
     if (mb->nblocks > 0)
-        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_MARGINALS, hp.tmix) : (const void *)KernelTable<double>::get(JT_K_MARGINALS, hp.tmix), mb->lds));
+        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_MARGINALS, mixk(hp)) : (const void *)KernelTable<double>::get(JT_K_MARGINALS, mixk(hp)), mb->lds));
     if (mb->unit_nblocks > 0)
-        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE, hp.tmix) : (const void *)KernelTable<double>::get(JT_K_SINGLE, hp.tmix), mb->unit_lds));
+        HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE, mixk(hp)) : (const void *)KernelTable<double>::get(JT_K_SINGLE, mixk(hp)), mb->unit_lds));
     JtFlow plain;
     memset(&plain, 0, sizeof plain);
     plain.oth_off = -1;

@@ -121,7 +121,8 @@ struct JtTask {
                                // table row: which entries of a row exist comes from the clique's thread map (tmap_off, always set for
                                // such a task), which rows exist from the iteration table (JT_NO_ROW); a belief is stored only when
                                // bel_off >= 0 (read-out tasks: into a scratch arena).  Kernels: jt_pass<..., UNIT = true>.
-    int32_t pad_unit;
+    int32_t vgroups;           // mixed-radix rows, compact form: 2 = two row groups of 128 threads, the logical thread of each behind the
+                               // clique's thread map (tmap_off + 2^TB: 128 ints); 0: every thread is its own logical thread
     int32_t keep_rows;         // 1: the table rows are loaded with the default cache policy instead of non-temporal - this pass
                                // and the next over the same table are close enough in time for the second to find the rows in
                                // the Infinity Cache (the top of a tree: read last by collect, first by distribute; a plan whose

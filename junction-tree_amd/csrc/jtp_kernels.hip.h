@@ -235,7 +235,7 @@ __device__ __forceinline__ uint32_t jt_sub_hi(const uint32_t (&fp)[4], int nfree
 // names a place for it (read-out tasks).  The reference never materialises such axes either (junctiontree.py:52-61).
 // BEL (unit tasks only): the belief is stored - by read-out tasks; the passes of a propagate leave it out at compile time (the
 // conversions and the store were a tenth of the distribute step's vector instructions).
-template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false, bool KEEP = false, bool UNIT = false, bool BEL = !UNIT>
+template <typename T, int NIN, int NOUT, int MODE, bool FLOW = false, bool EARLY_FLUSH = (MODE == 0), bool TMIX = false, bool KEEP = false, bool UNIT = false, bool BEL = !UNIT, bool VG = false>
 __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                         const T *__restrict__ psi_arena, T *__restrict__ bel_arena,
                                         double *__restrict__ msg_arena, const JtFlow &fl,
@@ -254,6 +254,21 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // Mixed-radix rows, compact form (JtTask::vgroups == 2, round 5): at most 128 of the 256 logical threads of the thread part own
+    // an entry that exists (cardinality 3: 81), so two waves serve a row and the workgroup works on TWO rows at a time - threads
+    // 0..127 on rows 0, 2, 4, ..., threads 128..255 on rows 1, 3, 5, ...; which logical thread a thread stands for says the clique's
+    // list behind its thread map (vt).  Everything that indexes by the thread part (message look-ups, thread map, evidence) uses
+    // vt; staging and flush - plain copies - keep the physical thread; sums over thread-part variables go through LDS adds in wave
+    // order (the lanes of a logical variable are no longer an XOR apart).
+    // (VG: instantiated by the *_mix kernels for such tasks only - jt_collect_mix / jt_distribute_mix)
+    static_assert(!VG || TMIX, "row groups are a form of mixed-radix rows");
+    constexpr int ngrp = VG ? 2 : 1;
+    int vt = tid, grp = 0;
+    if constexpr (VG) {
+        vt = (itab + tk.tmap_off + (1 << (EB + 8)))[tid & 127];
+        grp = __builtin_amdgcn_readfirstlane(tid >> 7);
+    }
+    const int vlane = vt & 63, vwave = vt >> 6;
 
     const uint32_t xF = bk.xF + (uint32_t)tid * VEC;
     const T *psi = psi_arena + tk.psi_off;
@@ -386,11 +401,14 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 #pragma unroll
             for (int e = 0; e < VEC; ++e) tpo[e] = tm[e];
         } else if constexpr (TMIX) {
-            const int *tm = itab + tk.tmap_off + tid * VEC;
+            const int *tm = itab + tk.tmap_off + vt * VEC;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) tpo[e] = tm[e];
 #pragma unroll
-            for (int u = 0; u < UT; ++u) gather_row(u, bk.first_x[u], bk.first_x[u] != JT_NO_ROW);
+            for (int u = 0; u < UT; ++u) {
+                const uint32_t x = bk.first_x[u * ngrp + grp];          // (rows 0..7: UT * ngrp <= 8)
+                gather_row(u, x, x != JT_NO_ROW);
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -664,9 +682,9 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         const JtMsg &m = tk.msg[k < NIN ? k : JT_MAX_IN + (k - NIN)];
         int t = 0;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) t += ((lane >> b) & 1) * m.t_w[b];
+        for (int b = 0; b < 6; ++b) t += ((vlane >> b) & 1) * m.t_w[b];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) t += ((wave >> b) & 1) * m.t_w[6 + b];
+        for (int b = 0; b < 2; ++b) t += ((vwave >> b) & 1) * m.t_w[6 + b];
         thr[k] = t;
         if (k < NIN) {
             in_sub[k < NIN ? k : 0] = reinterpret_cast<const double *>(smem + m.lds_off);
@@ -702,10 +720,17 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         for (int e = 0; e < VEC; ++e) acc[j][e] = 0.0;
 
     // fold this thread's sums for outgoing message j (one run of iterations) into its sub-box
-    auto epilogue = [&](auto j_tag, const int oo_j) {
+    auto epilogue = [&](auto j_tag, const int oo_j, const bool mine) {
         {
             constexpr int j = decltype(j_tag)::value;
             const int red_e = o_rede[j], red_lane = o_redl[j], red_wave = o_redw[j];
+            constexpr bool compact = VG;
+            if (compact && !mine) {
+                // (compact mixed-radix rows: the other group's sums are due, this wave's run goes on - its sums stay as they are;
+                //  the four barriers of the turns below)
+                for (int ph = 0; ph < 4; ++ph) __syncthreads();
+                return;
+            }
             if constexpr ((UNIT || TMIX) && MODE == 0) {
                 // (which entries of the thread part exist does not change from row to row: applied to the sums of a run, not to
                 //  every product; mixed-radix rows: an entry that does not exist was gathered from the row's first element)
@@ -724,6 +749,26 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                 }
             } else {
                 if (red_e & 1) acc[j][0] += acc[j][1];
+            }
+            if constexpr (compact) {
+                // compact mixed-radix rows: the threads that share an output slot are wherever the clique's list put them - every
+                // thread adds its own sums to its slot, the LDS serialises the lanes of one wave, the waves take turns (a fixed order)
+                const int slot_c = oo_j + thr[NIN + j];
+                for (int ph = 0; ph < 4; ++ph) {
+                    if (wave == ph) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            if ((e & red_e) == 0) {
+                                const int eo = ((e & 1) ? o_ew0[j] : 0) + ((e & 2) ? o_ew1[j] : 0);
+                                __hip_atomic_fetch_add(&out_sub[j][slot_c + eo], acc[j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[j][e] = 0.0;
+                return;
             }
             // (all elements take part, also those folded away above: no branch per element - their sums are not stored)
             if (!(dbg & 4)) jt_lane_sums<VEC>(acc[j], red_lane);
@@ -762,6 +807,8 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     // one iteration: consume `slot`, refill it for iteration i + U, multiply, accumulate
     // SLOT = i mod U (static), YOUNGER = vector-memory operations issued after the DMA of iteration i
     // that may still be outstanding when iteration i is consumed
+    // (compact mixed-radix rows: a step serves row i * ngrp + grp of the iteration table - nit steps in all)
+    const int nit = TMIX ? (total + ngrp - 1) / ngrp : total;
     auto step = [&](auto slot_tag, auto younger_tag, const int i) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int YOUNGER = decltype(younger_tag)::value;
@@ -771,9 +818,10 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         } else if constexpr (TMIX) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) p[e] = (MODE == 0 || tpo[e] >= 0) ? (double)tbuf[SLOT][e] : 0.0;
-            const int inext = (i + UT < total) ? i + UT : total - 1;
-            const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], inext);
-            gather_row(SLOT, xnext, xnext != JT_NO_ROW && chunk_ok && i + UT < total);
+            const int inext = (i + UT < nit) ? i + UT : nit - 1;
+            const int rnext = inext * ngrp + grp;                       // (uniform per wave)
+            const uint32_t xnext = (uint32_t)__builtin_amdgcn_readlane(trow[0], rnext < total ? rnext : total - 1);
+            gather_row(SLOT, xnext, xnext != JT_NO_ROW && chunk_ok && i + UT < nit && rnext < total);
         } else {
         jt_wait_vmcnt<YOUNGER>();
         const VT v = *reinterpret_cast<const VT *>(ring + SLOT * 1024);
@@ -796,9 +844,18 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                      __builtin_amdgcn_readfirstlane(ring_lds + SLOT * 1024));
         }
         }
-        const int li = i;
+        // (compact mixed-radix rows: the second group's last step may have no row - an odd number of rows)
+        const int lraw = TMIX ? i * ngrp + grp : i;
+        const bool row_there = !TMIX || lraw < total;          // (uniform per wave)
+        const int li = row_there ? lraw : total - 1;
         const uint32_t xoff = (uint32_t)__builtin_amdgcn_readlane(trow[0], li);
-        const bool row_ok = xoff != JT_NO_ROW && chunk_ok;   // (uniform)
+        const bool row_ok = xoff != JT_NO_ROW && chunk_ok && row_there;   // (uniform)
+        if constexpr (TMIX && !UNIT) {
+            if (!row_there) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) p[e] = 0.0;
+            }
+        }
         // TMIX: the table holds existing rows only; the row's place in the full loop nest and the ends of the outgoing
         // messages' runs come with it (jtp_plan.cpp, plan_loops)
         const uint32_t rowinfo = TMIX ? (uint32_t)__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], li) : 0u;
@@ -814,7 +871,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         if (ev_mask != 0) {                                // (uniform: no vector instruction is spent without evidence)
             // LOGICAL index of this thread's first element (evidence masks are over index bits, element offsets are
             // physical): chunk bits + the row's loop bits + thread part
-            uint32_t x0 = bk.lxF + (uint32_t)tid * VEC;
+            uint32_t x0 = bk.lxF + (uint32_t)vt * VEC;
 #pragma unroll
             for (int t = 0; t < JT_MAX_ITER_LOG2; ++t) x0 += ((inest >> t) & 1u) << loop_pos[t];
 #pragma unroll
@@ -931,12 +988,30 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         }
         if constexpr (NOUT > 0) {
             if (!(dbg & 1)) {
+                constexpr bool compact = VG;
+                if constexpr (compact) {
+                    // Two rows per step: a group's sums of a run are complete when the run ends at its own row or at the next one (the
+                    // other group's); the epilogue has barriers, so EVERY wave goes through it when either group's are - the first
+                    // group's rows are 2 i, 2 i + 2, ..., the second's 2 i + 1, ... (run-end flags beyond the last row: none)
+                    auto endbit = [&](const int r, const int j) {
+                        return r < total ? ((uint32_t)__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], r) >> (24 + j)) & 1u : 0u;
+                    };
+                    auto both = [&](auto j_tag) {
+                        constexpr int j = decltype(j_tag)::value;
+                        const uint32_t e0 = endbit(2 * i, j), e1 = endbit(2 * i + 1, j), e2 = endbit(2 * i + 2, j);
+                        if (e0 | e1 | e2) epilogue(j_tag, ooff[j], grp == 0 ? (e0 | e1) != 0 : (row_there && (e1 | e2) != 0));
+                    };
+                    both(std::integral_constant<int, 0>{});
+                    if constexpr (NOUT > 1) both(std::integral_constant<int, 1>{});
+                    if constexpr (NOUT > 2) both(std::integral_constant<int, 2>{});
+                } else {
                 auto run_ends = [&](const int j) { return TMIX ? ((rowinfo >> (24 + j)) & 1u) != 0 : (i & rmask[j]) == rmask[j]; };
-                if (run_ends(0)) epilogue(std::integral_constant<int, 0>{}, ooff[0]);
+                if (run_ends(0)) epilogue(std::integral_constant<int, 0>{}, ooff[0], true);
                 if constexpr (NOUT > 1)
-                    if (run_ends(1)) epilogue(std::integral_constant<int, 1>{}, ooff[1]);
+                    if (run_ends(1)) epilogue(std::integral_constant<int, 1>{}, ooff[1], true);
                 if constexpr (NOUT > 2)
-                    if (run_ends(2)) epilogue(std::integral_constant<int, 2>{}, ooff[2]);
+                    if (run_ends(2)) epilogue(std::integral_constant<int, 2>{}, ooff[2], true);
+                }
             }
         }
     };
@@ -950,16 +1025,16 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     if constexpr (TMIX) {
         // any number of rows from 1 to 64 (the rows that exist); none at all for a chunk that does not
         if (chunk_ok)
-            for (int i0 = 0; i0 < total; i0 += UT) {
+            for (int i0 = 0; i0 < nit; i0 += UT) {
                 step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, i0);
-                if (i0 + 1 < total) step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, i0 + 1);
-                if (i0 + 2 < total) step(integral_constant<int, 2>{}, integral_constant<int, 0>{}, i0 + 2);
-                if (i0 + 3 < total) step(integral_constant<int, 3>{}, integral_constant<int, 0>{}, i0 + 3);
+                if (i0 + 1 < nit) step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, i0 + 1);
+                if (i0 + 2 < nit) step(integral_constant<int, 2>{}, integral_constant<int, 0>{}, i0 + 2);
+                if (i0 + 3 < nit) step(integral_constant<int, 3>{}, integral_constant<int, 0>{}, i0 + 3);
                 if constexpr (UT == 8) {
-                    if (i0 + 4 < total) step(integral_constant<int, 4 % UT>{}, integral_constant<int, 0>{}, i0 + 4);
-                    if (i0 + 5 < total) step(integral_constant<int, 5 % UT>{}, integral_constant<int, 0>{}, i0 + 5);
-                    if (i0 + 6 < total) step(integral_constant<int, 6 % UT>{}, integral_constant<int, 0>{}, i0 + 6);
-                    if (i0 + 7 < total) step(integral_constant<int, 7 % UT>{}, integral_constant<int, 0>{}, i0 + 7);
+                    if (i0 + 4 < nit) step(integral_constant<int, 4 % UT>{}, integral_constant<int, 0>{}, i0 + 4);
+                    if (i0 + 5 < nit) step(integral_constant<int, 5 % UT>{}, integral_constant<int, 0>{}, i0 + 5);
+                    if (i0 + 6 < nit) step(integral_constant<int, 6 % UT>{}, integral_constant<int, 0>{}, i0 + 6);
+                    if (i0 + 7 < nit) step(integral_constant<int, 7 % UT>{}, integral_constant<int, 0>{}, i0 + 7);
                 }
             }
     } else {
@@ -2065,8 +2140,8 @@ __global__ __launch_bounds__(JT_THREADS, 4) void jt_marginals(const JtTask *__re
 // bits at their TRUE cardinalities): the same passes with TMIX = true - a thread reaches its elements through the
 // clique's thread map (JtTask::tmap_off) - for every launch style the engine uses with such plans: one launch per
 // phase (dataflow), one per level, and the read-out task lists.
-template <typename T, bool FLOW>
-__device__ __forceinline__ void jt_collect_mix(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
+template <typename T, bool FLOW, bool VG>
+__device__ __forceinline__ void jt_collect_mix_v(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                uint32_t *flow_ctl, uint64_t t_entry) {
     if (tk.unit) {
@@ -2075,73 +2150,75 @@ __device__ __forceinline__ void jt_collect_mix(const JtTask &tk, const JtBlock &
         return;
     }
     if (tk.n_out > 1) {                        // read-out tasks: several marginals of one belief table per pass
-        if (tk.n_out == 2) jt_pass<T, 0, 2, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
-        else jt_pass<T, 0, 3, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
+        if (tk.n_out == 2) jt_pass<T, 0, 2, 0, FLOW, true, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
+        else jt_pass<T, 0, 3, 0, FLOW, true, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
         return;
     }
     switch (tk.n_in) {
-        case 0: jt_pass<T, 0, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        case 1: jt_pass<T, 1, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        case 2: jt_pass<T, 2, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        case 3: jt_pass<T, 3, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        default: jt_pass<T, 4, 1, 0, FLOW, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 0: jt_pass<T, 0, 1, 0, FLOW, true, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 1: jt_pass<T, 1, 1, 0, FLOW, true, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 1, 0, FLOW, true, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 3: jt_pass<T, 3, 1, 0, FLOW, true, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        default: jt_pass<T, 4, 1, 0, FLOW, true, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
     }
 }
-template <typename T, bool FLOW>
-__device__ __forceinline__ void jt_distribute_mix(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
+template <typename T, bool FLOW, bool VG>
+__device__ __forceinline__ void jt_distribute_mix_v(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                   T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                   uint32_t *flow_ctl, uint64_t t_entry) {
     if (tk.unit) {
-        if (tk.mode == 0) jt_collect_mix<T, FLOW>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);      // (a downward message of a unit clique: its own marginalisation)
+        if (tk.mode == 0) jt_collect_mix_v<T, FLOW, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);      // (a downward message of a unit clique: its own marginalisation)
         else if (tk.n_out == 0 && !FLOW) jt_unit_single<T, true>(tk, bk, itab, psi, bel, msg, fl, bindex);       // (read-out: up to four incoming tables)
         else jt_unit_distribute<T, FLOW, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry);
         return;
     }
     if (tk.n_out == 0) {                       // belief only (leaves, and the read-out of multi-neighbour cliques)
         switch (tk.n_in) {
-            case 0: jt_pass<T, 0, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-            case 1: jt_pass<T, 1, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-            case 2: jt_pass<T, 2, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-            case 3: jt_pass<T, 3, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-            default: jt_pass<T, 4, 0, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            case 0: jt_pass<T, 0, 0, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            case 1: jt_pass<T, 1, 0, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            case 2: jt_pass<T, 2, 0, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            case 3: jt_pass<T, 3, 0, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+            default: jt_pass<T, 4, 0, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
         }
         return;
     }
     switch ((tk.n_in - tk.n_out) * 4 + tk.n_out) {
-        case 1: jt_pass<T, 1, 1, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        case 2: jt_pass<T, 2, 2, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        case 3: jt_pass<T, 3, 3, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        case 5: jt_pass<T, 2, 1, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        case 6: jt_pass<T, 3, 2, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
-        default: jt_pass<T, 4, 3, 1, FLOW, false, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 1: jt_pass<T, 1, 1, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 2: jt_pass<T, 2, 2, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 3: jt_pass<T, 3, 3, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 5: jt_pass<T, 2, 1, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        case 6: jt_pass<T, 3, 2, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
+        default: jt_pass<T, 4, 3, 1, FLOW, false, true, false, false, true, VG>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry); break;
     }
 }
 
-template <typename T>
+// (VG: the compact form of the rows, two per step - JtTask::vgroups == 2 on every table-keeping task of the plan, HostPlan::tmix_compact -
+//  is a kernel of its own: built into one kernel with the one-row form, either lost 10-20 %)
+template <typename T, bool VG = false>
 __global__ __launch_bounds__(JT_THREADS, 3) void jt_collect_level_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                                       const int *__restrict__ itab, const T *__restrict__ psi,
                                                                       T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
-    jt_collect_mix<T, false>(tasks[bk.task], bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+    jt_collect_mix_v<T, false, VG>(tasks[bk.task], bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
 }
-template <typename T>
+template <typename T, bool VG = false>
 __global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_level_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                                          const int *__restrict__ itab, const T *__restrict__ psi,
                                                                          T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
-    jt_distribute_mix<T, false>(tasks[bk.task], bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+    jt_distribute_mix_v<T, false, VG>(tasks[bk.task], bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
 }
 // (read-out task lists: marginals - mode 0 - and beliefs of multi-neighbour cliques - mode 1)
-template <typename T>
+template <typename T, bool VG = false>
 __global__ __launch_bounds__(JT_THREADS, 3) void jt_single_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                                const int *__restrict__ itab, const T *__restrict__ psi,
                                                                T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
-    if (tk.mode == 0) jt_collect_mix<T, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
-    else jt_distribute_mix<T, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+    if (tk.mode == 0) jt_collect_mix_v<T, false, VG>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+    else jt_distribute_mix_v<T, false, VG>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
 }
-template <typename T>
+template <typename T, bool VG = false>
 __global__ __launch_bounds__(JT_THREADS, JT_MIX_WAVES) void jt_collect_flow_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                                      const int *__restrict__ itab, const T *__restrict__ psi,
                                                                      T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
@@ -2151,9 +2228,9 @@ __global__ __launch_bounds__(JT_THREADS, JT_MIX_WAVES) void jt_collect_flow_mix(
     const JtBlock &bk = blk[ticket];
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) jt_reduce<true>(tk, bk, msg, fl);
-    else jt_collect_mix<T, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
+    else jt_collect_mix_v<T, true, VG>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
 }
-template <typename T>
+template <typename T, bool VG = false>
 __global__ __launch_bounds__(JT_THREADS, JT_MIX_WAVES) void jt_distribute_flow_mix(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
                                                                         const int *__restrict__ itab, const T *__restrict__ psi,
                                                                         T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
@@ -2163,7 +2240,7 @@ __global__ __launch_bounds__(JT_THREADS, JT_MIX_WAVES) void jt_distribute_flow_m
     const JtBlock &bk = blk[ticket];
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) jt_reduce<true>(tk, bk, msg, fl);
-    else jt_distribute_mix<T, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
+    else jt_distribute_mix_v<T, true, VG>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry);
 }
 
 // Per-shape entry points, used when the plan is built with JTP_SPLIT_VARIANTS (profiling aid:
@@ -2477,12 +2554,14 @@ __global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restri
     X template __global__ void jt_distribute<T, 1, 3>(JT_KARGS(T));
 #define JT_INST_MULTI(X, T) X template __global__ void jt_multi_flow<T>(JT_KARGS(T));
 #define JT_INST_BOTH(X, T) X template __global__ void jt_propagate_flow<T>(JT_KARGS(T));
-#define JT_INST_MIX(X, T)                                                    \
-    X template __global__ void jt_collect_level_mix<T>(JT_KARGS(T));         \
-    X template __global__ void jt_distribute_level_mix<T>(JT_KARGS(T));      \
-    X template __global__ void jt_single_mix<T>(JT_KARGS(T));                \
-    X template __global__ void jt_collect_flow_mix<T>(JT_KARGS(T));          \
-    X template __global__ void jt_distribute_flow_mix<T>(JT_KARGS(T));
+#define JT_INST_MIX_V(X, T, V)                                                  \
+    X template __global__ void jt_collect_level_mix<T, V>(JT_KARGS(T));         \
+    X template __global__ void jt_distribute_level_mix<T, V>(JT_KARGS(T));      \
+    X template __global__ void jt_single_mix<T, V>(JT_KARGS(T));                \
+    X template __global__ void jt_collect_flow_mix<T, V>(JT_KARGS(T));          \
+    X template __global__ void jt_distribute_flow_mix<T, V>(JT_KARGS(T));
+#define JT_INST_MIX(X, T) JT_INST_MIX_V(X, T, false)
+#define JT_INST_MIXC(X, T) JT_INST_MIX_V(X, T, true)
 #ifndef JT_INST_TU
 JT_INST_FLOW(extern, float)
 JT_INST_FLOW(extern, double)
@@ -2496,4 +2575,6 @@ JT_INST_BOTH(extern, float)
 JT_INST_BOTH(extern, double)
 JT_INST_MIX(extern, float)
 JT_INST_MIX(extern, double)
+JT_INST_MIXC(extern, float)
+JT_INST_MIXC(extern, double)
 #endif

@@ -454,6 +454,8 @@ int plan_loops(const HostPlan &hp, const PNode &p, JtTask &tk, std::vector<int32
     }
     tk.nbits = nbits;
     tk.tmap_off = (hp.tmix || tk.unit) ? p.tmap_off : -1;      // (unit tasks: which entries of a row exist)
+    tk.vgroups = (hp.tmix && !tk.unit && !p.vmap.empty()) ? 2 : 0;
+    if (hp.tmix_compact && !tk.unit && tk.vgroups != 2) FAIL(JTP_EUNSUPPORTED, "internal: a task of clique %d without its list of logical threads in a compact plan", p.real);
     tk.real_bits = real_bits;
     tk.debug = hp.knobs.debug;
     tk.nF = (int)Fb.size();
@@ -675,6 +677,7 @@ PlanKnobs jtp_read_knobs() {
     k.marg_block_log2 = geti("JTP_MARG_BLOCK_LOG2", 0);
     k.no_unit = geti("JTP_NO_UNIT", 0);
     k.keep_invalid = geti("JTP_KEEP_INVALID", 0);
+    k.no_vgroups = geti("JTP_NO_VGROUPS", 0);
     k.unit_joint_down = geti("JTP_UNIT_JOINT_DOWN", 0);
     k.no_ef_share = geti("JTP_EF_SHARE", 0) ? -1 : geti("JTP_NO_EF_SHARE", 0);      // (-1: the evidence-free group whatever the number of sets)
     k.unit_ratio = getd("JTP_UNIT_RATIO", 4.0);
@@ -1450,6 +1453,22 @@ int PlanBuilder::layouts() {
             }
             for (int b = 0; b < hp.TB && b < p.nbits; ++b) p.bitw[b] = 0;      // (inside a row: tmap, not bit weights)
             mult = p.trow;
+            // compact form (round 5): the logical threads that own an entry, if two waves hold them all
+            p.vmap.clear();
+            if (!hp.multiset && !hp.knobs.no_vgroups && !p.unit) {
+                std::vector<int32_t> owners;
+                int spare = -1;
+                for (int t = 0; t < JT_THREADS; ++t) {
+                    bool any = false;
+                    for (int e = 0; e < hp.VEC; ++e) any = any || p.tmap[(size_t)t * hp.VEC + e] >= 0;
+                    if (any) owners.push_back(t);
+                    else if (spare < 0) spare = t;
+                }
+                if (owners.size() <= 128 && (owners.size() == 128 || spare >= 0)) {
+                    p.vmap = owners;
+                    p.vmap.resize(128, spare);
+                }
+            }
         }
         for (size_t i = 0; i < p.vars.size(); ++i) {
             const int pos = p.pos[i], nb = p.nb[i], card = hp.card[p.vars[i]];
@@ -1597,6 +1616,20 @@ int PlanBuilder::arenas() {
     };
     std::map<std::vector<int32_t>, int64_t> map_at;          // thread maps already in the table buffer (unit cliques: mostly one)
     hp.fix_doubles = 0;
+    // compact mixed-radix rows are kernels of their own (*_mix<T, true>): all of the plan's mixed-radix cliques, or none
+    {
+        bool all = hp.tmix, any = false;
+        // (EVERY table-keeping clique of such a plan runs in the *_mix kernels - also those whose thread part stayed a bit field,
+        //  and they have no list: one of them and the plan keeps one row per step)
+        for (int c = 0; c < NP; ++c)
+            if (!hp.pn[c].unit) {
+                any = true;
+                all = all && !hp.pn[c].vmap.empty();
+            }
+        hp.tmix_compact = all && any;
+        if (!hp.tmix_compact)
+            for (int c = 0; c < NP; ++c) hp.pn[c].vmap.clear();
+    }
     hp.scratch_elems = 0;
     for (int c = 0; c < NP; ++c) {
         PNode &p = hp.pn[c];
@@ -1625,6 +1658,7 @@ int PlanBuilder::arenas() {
             else {
                 p.tmap_off = (int64_t)hp.itab.size();
                 hp.itab.insert(hp.itab.end(), p.tmap.begin(), p.tmap.end());
+                hp.itab.insert(hp.itab.end(), p.vmap.begin(), p.vmap.end());          // (compact mixed-radix rows: PNode::vmap)
                 if (p.unit) map_at[p.tmap] = p.tmap_off;
             }
         }
@@ -2362,6 +2396,7 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<std:
     if (hp.tmix || p.unit) {                     // the task travels with its own table buffer: the clique's thread map behind its rows
         tk.tmap_off = (int64_t)itab.size();
         itab.insert(itab.end(), p.tmap.begin(), p.tmap.end());
+        itab.insert(itab.end(), p.vmap.begin(), p.vmap.end());
     }
     for (size_t k = 0; k < src.size(); ++k) {
         tk.msg[k].off = src[k].first;
@@ -2397,6 +2432,7 @@ int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<
     if (hp.tmix || p.unit) {
         tk.tmap_off = (int64_t)itab.size();
         itab.insert(itab.end(), p.tmap.begin(), p.tmap.end());
+        itab.insert(itab.end(), p.vmap.begin(), p.vmap.end());
     }
     for (size_t k = 0; k < src.size(); ++k) {
         tk.msg[k].off = src[k].first;
@@ -2452,7 +2488,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
       << ",\"multiset\":" << (hp.multiset ? 1 : 0) << ",\"alg_table_bytes\":" << (long long)hp.alg_table_bytes
       << ",\"alg_msg_bytes\":" << (long long)hp.alg_msg_bytes
       << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
-      << ",\"n_blocks\":" << hp.blocks.size() << ",\"lean\":" << (hp.lean ? 1 : 0) << ",\"has_unit\":" << (hp.has_unit ? 1 : 0)
+      << ",\"n_blocks\":" << hp.blocks.size() << ",\"tmix_compact\":" << (hp.tmix_compact ? 1 : 0) << ",\"lean\":" << (hp.lean ? 1 : 0) << ",\"has_unit\":" << (hp.has_unit ? 1 : 0)
       << ",\"fix_doubles\":" << hp.fix_doubles << ",\"scratch_elems\":" << hp.scratch_elems << ",\"alg_bytes_full\":" << (long long)hp.alg_bytes_full;
     o << ",\"statics\":[";
     for (size_t i = 0; i < hp.statics.size(); ++i) {
@@ -2481,6 +2517,8 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
         if (hp.tmix || p.unit) {
             o << ",\"tmap\":";
             json_vec(o, p.tmap);
+            o << ",\"vmap\":";
+            json_vec(o, p.vmap);
         }
         o << ",\"bitw\":";
         json_vec(o, p.bitw);
@@ -2582,7 +2620,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             if (t) o << ",";
             o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"unit\":" << tk.unit << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
-              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"keep_rows\":" << tk.keep_rows << ",\"tmap_off\":" << tk.tmap_off << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
+              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"keep_rows\":" << tk.keep_rows << ",\"tmap_off\":" << tk.tmap_off << ",\"vgroups\":" << tk.vgroups << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
             json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";

@@ -37,6 +37,10 @@ struct PNode {                       // a clique of the (binarised) tree
                                      // below TB: those are a radix-2^lb digit of the row, the bits above a digit of ceil(card / 2^lb) values of the
                                      // rows above - taken when that wastes at most a quarter (entries with low + (high << lb) >= card are stored as zeros)
     std::vector<int32_t> tmap;
+    // (tmix) compact form: at most 128 logical threads of the thread part own an entry that exists - their list (ascending, padded to
+    // 128 with a logical thread that owns none), stored behind tmap in HostPlan::itab; the kernels then serve two rows per step with
+    // 128 threads each (JtTask::vgroups = 2).  Empty: every thread is its own logical thread.
+    std::vector<int32_t> vmap;
     int64_t tmap_off = -1;           // offset (ints) of tmap in HostPlan::itab
     int collect_task = -1, distribute_task = -1;
     std::vector<int> down_tasks;     // multi-set plans: one task per child (its downward message), child order
@@ -148,6 +152,7 @@ struct PlanKnobs {
     double keep_rows_mb = 128.0;                                      // JTP_KEEP_ROWS_MB: table rows of the levels nearest the root, up to this many MiB, are loaded with the default cache policy (0: all non-temporal; A/B on one box: config 4 0.6037 -> 0.5990 ms, an 8-rank share of it 198.5 -> 195.4 us)
     int no_ef_share = 0;                                            // JTP_NO_EF_SHARE: multi-set plans compute every set's upward messages (round 4), no evidence-free group to copy from
     int unit_joint_down = 0;                                        // JTP_UNIT_JOINT_DOWN: a unit clique forms its downward messages in ONE mode-1 pass (the first form of round 5) instead of a task each
+    int no_vgroups = 0;                                             // JTP_NO_VGROUPS: mixed-radix rows keep one row per step (round 3)
     int keep_invalid = 0;                                           // JTP_KEEP_INVALID: chunks that do not exist stay in the block lists (rounds 2-4)
     int no_unit = 0;                                                // JTP_NO_UNIT: no unit cliques - every clique (virtual ones too) keeps a full table (rounds 1-4)
     double unit_ratio = 4.0;                                        // JTP_UNIT_RATIO: a clique becomes a unit clique when its table is at least this many times its covered part
@@ -207,6 +212,7 @@ struct HostPlan {
     int64_t arena_elems = 0;         // potential arena == belief arena size (elements), zero row included
     double host_table_elems = 0;     // sum of the true sizes of this rank's clique tables (arena_elems / this = padding factor)
     bool compact = true;             // rows above the thread part stored at true cardinalities (JTP_NO_COMPACT clears it)
+    bool tmix_compact = false;       // ... and every such clique in the compact form (PNode::vmap, JtTask::vgroups = 2): kernels *_mix<T, true>
     bool tmix = false;               // some clique stores its thread part at true cardinalities: every task then addresses its
                                      // elements through a per-clique map (PNode::tmap) and runs the *_mix kernels
     int64_t msg_doubles = 0;

@@ -1340,3 +1340,62 @@ def test_multiset_plans_with_odd_cardinalities_share_evidence_free_subtrees_whil
     st = plan.stats()
     assert st["flow_fallbacks"] == 0 and st["launch_mode"] == "flow"
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("card,width,sep,dtype", [(3, 11, 5, "f32"), (3, 10, 5, "f64"), (5, 7, 3, "f32"), (3, 9, 4, "f32")])
+def test_mixed_radix_rows_two_per_step(card, width, sep, dtype):
+    """Compact mixed-radix rows (round 5): where at most 128 logical threads of the thread part own an entry that exists, two waves
+    serve a row and a workgroup works on two rows per step (`vgroups` = 2 in the task records; sums over thread-part variables go
+    through LDS adds in wave order).  Beliefs, Z and a marginal against the oracle, dataflow and per-level launches, hard evidence,
+    an odd number of rows per workgroup among the tasks; the same propagate twenty times gives the same bits; JTP_NO_VGROUPS=1 (one
+    row per step, round 3) agrees to rounding."""
+    import os
+    spec = synthetic.wide_binary_tree(n_cliques=15, width=width, sep=sep, card=card, seed=3 * card + width)
+    pots = synthetic.potentials_for(spec, seed=31)
+    cast = [p.astype(np.float32) for p in pots] if dtype == "f32" else pots
+    ref, z = oracle.beliefs_exact(spec["tree"], cast, spec["node_vars"], return_z=True)
+    tol = RTOL32 if dtype == "f32" else RTOL64
+    got = {}
+    for mode in ("flow", "levels", "one_row"):
+        if mode == "one_row":
+            os.environ["JTP_NO_VGROUPS"] = "1"
+        try:
+            plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, level_launches=(mode == "levels"))
+        finally:
+            os.environ.pop("JTP_NO_VGROUPS", None)
+        d = plan.describe()
+        assert d["tmix"] == 1
+        groups = {t["vgroups"] for t in d["tasks"] if t["kind"] == 0}
+        assert groups == ({0} if mode == "one_row" else {2}), groups
+        if mode != "one_row":
+            assert any(t["total"] % 2 == 1 for t in d["tasks"] if t["kind"] == 0)      # (27 = 3^3 rows, 25, 9 ...: the second group's last step is empty)
+        for c in range(spec["n_cliques"]):
+            plan.set_potential(c, cast[c])
+        plan.propagate()
+        for node in range(len(spec["node_vars"])):
+            close(plan.belief(node), ref[node], rtol=tol, what="%s node %d" % (mode, node))
+        assert abs(plan.z() - z) <= (1e-6 if dtype == "f32" else 1e-11) * z
+        lab = list(spec["node_vars"][3])[1:3]
+        close(plan.marginal(3, lab), ref[3].sum(axis=tuple(i for i in range(width) if i not in (1, 2))), rtol=tol)
+        first = [plan.belief(node).copy() for node in range(len(spec["node_vars"]))]
+        if mode == "flow":
+            for rep in range(20):
+                plan.propagate()
+                for node in (0, 5, spec["n_cliques"], len(spec["node_vars"]) - 1):
+                    np.testing.assert_array_equal(plan.belief(node), first[node], err_msg="propagate %d node %d" % (rep, node))
+        got[mode] = first
+        # hard evidence (its masks are over the LOGICAL index of the thread part)
+        labels = sorted(spec["sizes"])
+        rng = np.random.default_rng(77)
+        obs = {labels[i]: int(rng.integers(0, card)) for i in rng.choice(len(labels), size=4, replace=False)}
+        plan.set_evidence(obs)
+        plan.propagate()
+        w, zb = oracle.beliefs_exact(spec["tree"], _indicator_potentials(spec, cast, obs), spec["node_vars"], return_z=True)
+        assert abs(plan.z() - zb) <= (1e-6 if dtype == "f32" else 1e-11) * zb + 1e-300
+        for node in (0, 3, spec["n_cliques"] + 1):
+            close(plan.belief(node), w[node], rtol=tol, what="%s evidence node %d" % (mode, node))
+        assert plan.stats()["flow_fallbacks"] == 0
+        plan.close()
+    for a, b in zip(got["flow"], got["levels"]):
+        np.testing.assert_array_equal(a, b)
