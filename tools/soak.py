@@ -10,7 +10,9 @@ cases = [("c4", synthetic.wide_binary_tree(n_cliques=256, width=20, sep=10, card
          ("mid", synthetic.wide_binary_tree(n_cliques=63, width=16, sep=8, card=2, seed=3), "f64", reps),
          ("random", synthetic.random_tree(n_cliques=40, width=14, sep=6, card=2, seed=5), "f32", reps),
          ("chain", synthetic.chain_tree(n_cliques=60, card=16, width=3), "f64", reps),
-         ("odd", synthetic.wide_binary_tree(n_cliques=15, width=10, sep=5, card=3, seed=2), "f32", reps)]     # mixed-radix rows (kernels *_mix)
+         ("odd", synthetic.wide_binary_tree(n_cliques=15, width=10, sep=5, card=3, seed=2), "f32", reps),     # mixed-radix rows, compact form (kernels *_mix<T, true>: LDS adds in wave order)
+         ("odd5", synthetic.wide_binary_tree(n_cliques=15, width=7, sep=3, card=5, seed=4), "f64", reps),
+         ("odd6", synthetic.wide_binary_tree(n_cliques=15, width=7, sep=3, card=6, seed=6), "f32", reps)]     # mixed-radix rows, one row per step (*_mix<T, false>)
 for name, spec, dt, n in cases:
     plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dt)
     plan.fill_synthetic(1, spec["scales"])
