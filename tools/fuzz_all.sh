@@ -10,4 +10,5 @@ run timeout -k 10 400 python3 tools/gpu_fuzz_api.py 1500 72000
 run FUZZ_BIG=1 timeout -k 10 300 python3 tools/gpu_fuzz.py 300 73000
 run FUZZ_WIDE=1 timeout -k 10 400 python3 tools/gpu_fuzz_api.py 800 74000
 run timeout -k 10 300 python3 tools/gpu_fuzz_wide.py 200 75000
+run timeout -k 10 600 python3 tools/gpu_fuzz_compact.py 200 90000
 cat $O
