@@ -346,6 +346,19 @@ def test_rows_above_the_thread_part_are_stored_at_true_cardinalities(card, width
             assert all((b[23] & 1) == 1 for b in desc["init_blocks"])
             if opts.get("block_log2") == 10 and compact:
                 assert desc["init_blocks"]
+            # round 5, compact mixed-radix rows: all of a plan's table-keeping cliques or none; a clique's list names exactly the logical
+            # threads that own an entry (ascending), padded to 128 with one that owns none
+            VEC = desc["VEC"]
+            for p_ in desc["pnodes"]:
+                if desc["tmix_compact"] and not p_["unit"]:
+                    owners = [t for t in range(256) if any(x >= 0 for x in p_["tmap"][t * VEC:(t + 1) * VEC])]
+                    assert len(p_["vmap"]) == 128 and p_["vmap"][:len(owners)] == owners and len(owners) <= 128
+                    assert all(v not in owners for v in p_["vmap"][len(owners):])
+                else:
+                    assert not p_.get("vmap")
+            assert {t["vgroups"] for t in desc["tasks"] if t["kind"] == 0 and not t["unit"]} <= ({2} if desc["tmix_compact"] else {0})
+            if compact and not opts.get("multiset") and card in (3, 5):
+                assert desc["tmix_compact"] == 1
             emu = Emulator(desc)
             for c in plan.cliques:
                 ids = [plan.var_id[lab] for lab in spec["node_vars"][c]]
