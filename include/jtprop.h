@@ -142,7 +142,10 @@ typedef struct jtp_stats {
                                        (/dev/shm/jtprop_flight_<PCI bus id>) and sees other processes'; 0: the board could not be opened
                                        (another user's file, no /dev/shm): other PROCESSES on the device are then only noticed by the
                                        2 s time-out; -1: no dataflow propagate has asked for it yet                              */
-    int32_t pad_stats;
+    int32_t lean_refused;           /* 1: the description named covered variables (cover_*) but the plan that keeps no table for the
+                                       uncovered part was refused (JTP_EUNSUPPORTED: a static table's sub-boxes beyond LDS, ...) and
+                                       the tree was planned with EVERY table materialised - on lattices many times the device
+                                       memory; the reason is the "lean_refused" string of jtp_plan_describe                      */
 } jtp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

@@ -72,10 +72,15 @@ def build(force=False, verbose=True, extra=(), out=None, jobs=None):
     import hashlib
     headers = {"jtp_plan.cpp": ["jtp_plan.h", "jtp_internal.h", os.path.join("..", "..", "include", "jtprop.h")],
                "jtp_engine.hip": ["jtp_plan.h", "jtp_internal.h", "jtp_kernels.hip.h", os.path.join("..", "..", "include", "jtprop.h")]}
+    try:                       # (the compiler is part of what an object is made of: a toolchain upgrade must not link old objects)
+        toolchain = subprocess.check_output([hipcc, "--version"], stderr=subprocess.STDOUT)
+    except (OSError, subprocess.CalledProcessError):
+        toolchain = hipcc.encode()
     try:
         def compile_one(src):
             obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
             h = hashlib.sha256()
+            h.update(toolchain)
             for d in [src] + headers.get(src, ["jtp_internal.h", "jtp_kernels.hip.h"]):
                 with open(os.path.join(CSRC, d), "rb") as fh:
                     h.update(d.encode() + b"\0" + fh.read())
@@ -93,7 +98,9 @@ def build(force=False, verbose=True, extra=(), out=None, jobs=None):
             for old in os.listdir(cache):               # one object per unit and flag set is enough
                 if old.startswith(os.path.splitext(src)[0] + ".") and len(os.listdir(cache)) > 64:
                     os.remove(os.path.join(cache, old))
-            shutil.copy(obj, kept)
+            tmp_kept = kept + ".tmp%d" % os.getpid()      # (another build may be reading the cache: entries appear whole or not at all)
+            shutil.copy(obj, tmp_kept)
+            os.replace(tmp_kept, kept)
             return obj
         # (the template translation units take 1-2 GiB of compiler each: at most eight at once, JTP_BUILD_JOBS overrides)
         jobs = jobs or int(os.environ.get("JTP_BUILD_JOBS", 0)) or max(1, min(len(SOURCES), os.cpu_count() or 2, 8))

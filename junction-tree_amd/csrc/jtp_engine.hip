@@ -664,7 +664,10 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         jtp_plan *fresh = nullptr;
         const int rc2 = jtp_plan_create(&again, &fresh);
         delete pl;
-        if (rc2 == JTP_OK) *out = fresh;
+        if (rc2 == JTP_OK) {
+            fresh->hp.lean_refused = err.empty() ? std::string("unsupported") : err;      // (jtp_stats.lean_refused, jtp_plan_describe)
+            *out = fresh;
+        }
         return rc2;
     }
     if (rc != JTP_OK) {
@@ -1289,7 +1292,8 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
     // its arena (its separator beliefs are read from there), and no later launch of this plan waits on markers
     if (pl->multiset) {                                     // (all sets run together, the padding sets of the last group too)
         const size_t mbytes = (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 16;
-        HIP_TRY(hipMemsetD32((hipDeviceptr_t)pl->msg_all, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), mbytes * pl->n_groups * JT_MSETS / 4));
+        // (on the plan's stream, like the zeros that follow: that stream does not synchronise with the null stream)
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)pl->msg_all, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), mbytes * pl->n_groups * JT_MSETS / 4, pl->streams[0]));
         if (int rc = zero_padding(pl, pl->msg_all, pl->n_groups * JT_MSETS, pl->streams[0])) return rc;
         HIP_TRY(hipStreamSynchronize(pl->streams[0]));
         for (auto &b : pl->bufs) b.epoch = 0, b.flow_runs = 0, b.ticket_runs = 0;
@@ -1297,8 +1301,8 @@ static int check_flow(jtp_plan *pl, int synced = -1) {
     for (size_t i = 0; i < pl->bufs.size(); ++i) {
         BatchBuffers &b = pl->bufs[i];
         if (!b.unchecked) continue;
-        HIP_TRY(hipMemset(b.sync, 0, (size_t)pl->hp.sync_words * 4));
-        HIP_TRY(hipMemsetD32((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 4));
+        HIP_TRY(hipMemsetAsync(b.sync, 0, (size_t)pl->hp.sync_words * 4, pl->streams[0]));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b.msg, (int)(uint32_t)(JT_UNWRITTEN & 0xffffffffu), (size_t)std::max<int64_t>(pl->hp.msg_doubles, 2) * 4, pl->streams[0]));
         if (int rc = zero_padding(pl, b.msg, 1, pl->streams[0])) return rc;
         HIP_TRY(hipStreamSynchronize(pl->streams[0]));
         b.epoch = 0;
@@ -1475,6 +1479,12 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                     if (p.collect_task >= 0 && pl->skip_host[(size_t)g * hp.tasks.size() + p.collect_task]) {
                         const PSep &sp = hp.ps[p.psep];
                         list.push_back({sp.up_roff, (int32_t)(((int64_t)sp.up_rnpart) << sp.nbits), g});
+                        // Where a reduce task sums the producer's partial copies, the copies are entries of their own (up_off, not
+                        // up_roff): a skipped producer leaves them alone, so the values of the last propagate that DID run it would
+                        // still stand in the other half when the task runs again two propagates later, and its reduce task - which
+                        // takes "no marker" for "written" - would sum them.  Re-arm them like the producer's flush would have.
+                        if (sp.up_red_task >= 0)
+                            list.push_back({sp.up_off, (int32_t)(((int64_t)sp.up_npart) << sp.nbits), g | JT_FANOUT_MARK_ONLY});
                     }
             if ((int)list.size() > pl->cap_fanout) {
                 if (pl->d_fanout) HIP_TRY(hipFree(pl->d_fanout));
@@ -2134,6 +2144,7 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
     }
     st->algorithmic_bytes_full = hp.alg_bytes_full;
     st->fixed_bytes = (double)hp.fix_doubles * 8;
+    st->lean_refused = hp.lean_refused.empty() ? 0 : 1;
     for (int c = 0; c < hp.n_cliques; ++c) {
         st->n_unit_cliques += hp.pn[c].unit ? 1 : 0;
         st->n_static_tables += hp.pn[c].unit && hp.pn[c].stat >= 0 ? 1 : 0;

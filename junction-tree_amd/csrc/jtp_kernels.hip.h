@@ -2008,16 +2008,25 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
 // all): that task's workgroups of group g end at once (JtFlow::skip), its consumers stage group 0's copy (JtMsg::src_task), and
 // this copy pass behind the propagate puts the message into the eight sets' own arenas - values in this propagate's half, the
 // "unwritten" marker in the other, exactly what the producer would have left - for the read-out and for the next propagate.
+#define JT_FANOUT_MARK_ONLY 0x40000000
 struct JtFanout {
     int64_t off;               // msg-arena offset (doubles) of what consumers read of the message (the reduced sum where there is one)
     int32_t count;             // doubles
-    int32_t group;             // the group whose sets receive it
+    int32_t group;             // the group whose sets receive it; | JT_FANOUT_MARK_ONLY: nothing is copied, the entries of the OTHER
+                               // arena half are marked "unwritten" (the partial copies a skipped producer would have re-armed)
 };
 #ifndef JT_INST_TU
 __global__ __launch_bounds__(256) void jt_multi_fanout(const JtFanout *__restrict__ list, double *__restrict__ msg, JtFlow fl) {
     const JtFanout f = list[blockIdx.x];
     const double *src = msg + fl.cur_off + f.off;                                  // (group 0, set 0)
-    double *dst0 = msg + (int64_t)f.group * JT_MSETS * fl.set_stride + f.off;
+    double *dst0 = msg + (int64_t)(f.group & ~JT_FANOUT_MARK_ONLY) * JT_MSETS * fl.set_stride + f.off;
+    if (f.group & JT_FANOUT_MARK_ONLY) {
+        if (fl.oth_off < 0) return;
+        for (int i = threadIdx.x; i < f.count; i += 256)
+#pragma unroll
+            for (int s = 0; s < JT_MSETS; ++s) dst0[(int64_t)s * fl.set_stride + i + fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
+        return;
+    }
     for (int i = threadIdx.x; i < f.count; i += 256) {
         const double v = src[i];
 #pragma unroll

@@ -2477,6 +2477,16 @@ void json_msg(std::ostringstream &o, const JtMsg &m, int nF) {
 }
 }  // namespace
 
+static std::string json_escape(const std::string &s) {
+    std::string o;
+    for (char c : s) {
+        if (c == '"' || c == '\\') o += '\\', o += c;
+        else if ((unsigned char)c < 0x20) o += ' ';
+        else o += c;
+    }
+    return o;
+}
+
 void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
     std::ostringstream o;
     o << "{\"version\":1,\"dtype\":" << hp.dtype << ",\"VEC\":" << hp.VEC << ",\"EB\":" << hp.EB << ",\"TB\":" << hp.TB
@@ -2489,7 +2499,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
       << ",\"alg_msg_bytes\":" << (long long)hp.alg_msg_bytes
       << ",\"n_messages\":" << hp.n_messages << ",\"n_tasks\":" << hp.tasks.size()
       << ",\"n_blocks\":" << hp.blocks.size() << ",\"tmix_compact\":" << (hp.tmix_compact ? 1 : 0) << ",\"lean\":" << (hp.lean ? 1 : 0) << ",\"has_unit\":" << (hp.has_unit ? 1 : 0)
-      << ",\"fix_doubles\":" << hp.fix_doubles << ",\"scratch_elems\":" << hp.scratch_elems << ",\"alg_bytes_full\":" << (long long)hp.alg_bytes_full;
+      << ",\"lean_refused\":\"" << json_escape(hp.lean_refused) << "\",\"fix_doubles\":" << hp.fix_doubles << ",\"scratch_elems\":" << hp.scratch_elems << ",\"alg_bytes_full\":" << (long long)hp.alg_bytes_full;
     o << ",\"statics\":[";
     for (size_t i = 0; i < hp.statics.size(); ++i) {
         const PStatic &st = hp.statics[i];

@@ -197,6 +197,7 @@ struct HostPlan {
     std::vector<JtPackDesc> stat_pack;   // per real clique with a static table: host array of the clique (axes of uncovered variables have
                                          // length 1) <-> the static table (dev_off = PStatic::off); nvars = 0 for the others
     bool lean = false;                   // the description named covered variables (jtp_tree_desc.cover_*)
+    std::string lean_refused;            // ... and that plan was refused for this reason: this one materialises every table (jtp_plan_create)
     bool has_unit = false;               // some task of this rank's is a unit task
     bool unit_dominated = false;         // most clique elements of the tree belong to unit cliques (decide_units)
     std::vector<std::vector<int>> cover; // per real clique (lean plans)

@@ -87,7 +87,7 @@ class Stats(C.Structure):
         ("n_unit_cliques", C.c_int32),
         ("n_static_tables", C.c_int32),
         ("flight_board", C.c_int32),
-        ("pad_stats", C.c_int32),
+        ("lean_refused", C.c_int32),
     ]
 
 

@@ -168,6 +168,13 @@ class Plan:
         st = _capi.Stats()
         _capi.check(self._lib.jtp_get_stats(self._handle, C.byref(st)))
         self.dtype = int(st.storage_dtype)
+        if st.lean_refused:
+            # (jtp_plan_create planned the tree again with every table materialised: say so, and do not pretend to be lean)
+            import warnings
+            self.cover = None
+            warnings.warn("junctiontree_amd: the plan that keeps no table for uncovered variables was refused (%s); every clique "
+                          "table is materialised on the device" % self.describe().get("lean_refused", "unsupported"),
+                          RuntimeWarning, stacklevel=3)
         if self.dtype != self.requested_dtype:
             import warnings
             warnings.warn("junctiontree_amd: float32 tables asked for, float64 tables made (the float32 layout of this tree does "
@@ -251,29 +258,42 @@ class Plan:
             recs[i].shape = C.cast(shape, C.POINTER(C.c_int64))
         _capi.check(self._lib.jtp_set_potential_product(self._handle, batch, self.abi_of[node], len(arrays), recs))
 
-    def stage_factors(self, factor_labels, factor_to_clique, xs):
+    def stage_factors(self, factor_labels, factor_to_clique, xs, changed=None):
         """`CliqueGraph.evaluate` (`junctiontree.py:203-226`) on the device for a whole factor graph: clique c's potential is
         the product of the tables `xs[f]` with `factor_to_clique[f] == c` (labels `factor_labels[f]`, one axis each; an axis
         may have length 1 to broadcast).  ONE call into the library for all cliques whose tables differ from what this
         plan was last staged with (`jtp_set_potential_products`: one host-to-device copy, one kernel launch); the reference
         recomputes every clique on every call and says so in a FIXME (`junctiontree.py:206-214`).  Returns the number of
-        cliques formed (also kept as `staged_cliques`)."""
+        cliques formed (also kept as `staged_cliques`).
+
+        `changed`: None - every table is compared with the values last staged; "all" or the indices of the factors whose
+        tables are new - nothing is compared, only the cliques of those factors are formed again, and the caller vouches that
+        the factor structure (labels, assignment, shapes, dtypes) is what it was at the last call with these lists."""
         arrs = [x if type(x) is np.ndarray else np.asarray(x) for x in xs]
+        ft = self.__dict__.get("_factor_tables")
+        if (changed is not None and ft is not None and ft.src[0] is factor_labels and ft.src[1] is factor_to_clique
+                and ft.n_f == len(arrs) and ft.prev is not None):
+            self.staged_cliques = ft.stage(self, arrs, changed)
+            return self.staged_cliques
         all_f32 = all(a.dtype == np.float32 for a in arrs)
         key = (tuple(map(tuple, factor_labels)), tuple(factor_to_clique), [a.shape for a in arrs], all_f32)
-        ft = self.__dict__.get("_factor_tables")
         if ft is None or ft.key != key:
             ft = self._factor_tables = _FactorTables(self, key)
+        ft.src = (factor_labels, factor_to_clique)
         self.staged_cliques = ft.stage(self, arrs)
         return self.staged_cliques
 
-    def factor_marginals(self, factor_labels, factor_to_clique, batch=0):
+    def factor_marginals(self, factor_labels, factor_to_clique, batch=0, trusted=False):
         """`CliqueGraph.marginalize` (`junctiontree.py:229-274`) on the device: the marginal of clique
-        `factor_to_clique[f]`'s belief onto `factor_labels[f]` for every factor, as float64 arrays (views of one buffer)."""
-        key = (tuple(map(tuple, factor_labels)), tuple(factor_to_clique))
+        `factor_to_clique[f]`'s belief onto `factor_labels[f]` for every factor, as float64 arrays (views of one buffer).
+        `trusted`: the two lists are the objects of the last call and have not been modified (no look at their contents)."""
         req = self.__dict__.get("_marginal_requests")
+        if trusted and req is not None and req.src[0] is factor_labels and req.src[1] is factor_to_clique:
+            return req.read(self, batch)
+        key = (tuple(map(tuple, factor_labels)), tuple(factor_to_clique))
         if req is None or req.key != key:
             req = self._marginal_requests = _MarginalRequests(self, key)
+        req.src = (factor_labels, factor_to_clique)
         return req.read(self, batch)
 
     def set_evidence(self, observed, batch=0):
@@ -482,22 +502,46 @@ class _FactorTables:
         self.recs = recs
         self.n_f = n_f
         self.prev = None             # the small tables as last staged
+        self.src = (None, None)      # the caller's list objects this was last used with (Plan.stage_factors)
+        self.is_small = small
         self.mine = np.asarray([plan.owns(c) for c in plan.cliques], dtype=bool)
 
-    def stage(self, plan, arrs):
+    def stage(self, plan, arrs, named=None):
+        """`named`: None = compare every small table with the copy last staged; "all" / factor indices = the caller names the
+        tables that changed (`JunctionTree.propagate(xs, changed=...)`): nothing is compared."""
         n_f, item = self.n_f, np.dtype(self.np_dtype).itemsize
-        if len(self.small_idx):
-            flat = np.concatenate([arrs[i].reshape(-1) for i in self.small_idx], dtype=self.np_dtype)
-        else:
-            flat = np.empty(0, dtype=self.np_dtype)
         dirty = np.ones(len(self.cliques), dtype=bool)
-        if self.prev is not None:
-            changed = np.zeros(n_f, dtype=bool)
-            changed[self.big_idx] = True
-            if len(flat):
-                changed[self.small_idx] = np.logical_or.reduceat(flat != self.prev, self.seg_start)
+        if named is not None and self.prev is not None and not isinstance(named, str):
+            # the copy last staged is brought up to date in place: only the named tables are looked at
+            idx = np.unique(np.asarray(list(named), dtype=np.int64))
+            if len(idx) and (idx[0] < 0 or idx[-1] >= n_f):
+                raise IndexError("changed: factor index out of range [0, %d)" % n_f)
+            flat = self.prev
+            for i in idx:
+                if self.is_small[i]:
+                    a = arrs[i]
+                    if a.size != self.small_off[i + 1] - self.small_off[i]:
+                        raise ValueError("factor %d changed its shape" % i)
+                    flat[self.small_off[i]:self.small_off[i + 1]] = a.reshape(-1)
             dirty[:] = False
-            dirty[self.f_pos[changed]] = True
+            dirty[self.f_pos[idx]] = True
+            dirty[self.f_pos[self.big_idx]] = True
+        else:
+            if named is not None and named != "all" and isinstance(named, str):
+                raise ValueError('changed: "all" or an iterable of factor indices')
+            if len(self.small_idx):
+                flat = np.concatenate([arrs[i].reshape(-1) for i in self.small_idx], dtype=self.np_dtype)
+            else:
+                flat = np.empty(0, dtype=self.np_dtype)
+            if self.prev is not None and named is None:
+                changed = np.zeros(n_f, dtype=bool)
+                changed[self.big_idx] = True
+                if len(flat):
+                    if len(flat) != len(self.prev):
+                        raise ValueError("the factor tables changed their shapes")
+                    changed[self.small_idx] = np.logical_or.reduceat(flat != self.prev, self.seg_start)
+                dirty[:] = False
+                dirty[self.f_pos[changed]] = True
         dirty &= self.mine                                           # (sharded plans: this rank's cliques only)
         todo = np.flatnonzero(dirty)
         if len(todo) == 0:
@@ -537,6 +581,7 @@ class _MarginalRequests:
     def __init__(self, plan, key):
         labels, f2c = key
         self.key = key
+        self.src = (None, None)      # the caller's list objects this was last used with (Plan.factor_marginals)
         n = len(labels)
         var_ids, var_off, out_off, self.shapes = [], [0], [0], []
         for labs in labels:

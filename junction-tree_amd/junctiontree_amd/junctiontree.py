@@ -70,14 +70,14 @@ def einsum(xs, xs_keys, y_keys):
     return np.einsum(*call)
 
 
-def _stage_changed_cliques(plan, ct, xs):
+def _stage_changed_cliques(plan, ct, xs, changed=None):
     """`evaluate` on the device for the cliques whose member factors differ from what `plan` holds: one call into the
     library for all of them (`engine.Plan.stage_factors`).  Returns the number of cliques formed (`plan.staged_cliques`
     keeps the count of the last call for tests and tools).  What is staged = which factors, over which variables in which
     axis order, with which values: two JunctionTree objects whose junction trees coincide share one cached plan
     (`engine.plan_for` keys on the tree, not on the factors), and the same bytes under a transposed label list are
-    another table - `stage_factors` compares all of that."""
-    return plan.stage_factors(ct.factor_graph.factors, ct.factor_to_maxclique, xs)
+    another table - `stage_factors` compares all of that, unless the caller names the changed factors (`changed`)."""
+    return plan.stage_factors(ct.factor_graph.factors, ct.factor_to_maxclique, xs, changed=changed)
 
 
 @dataclass(frozen=True)
@@ -156,13 +156,17 @@ class JunctionTree:
         for k, v in state.items():
             object.__setattr__(self, k, v)
 
-    def cover(self):
+    def cover(self, trusted=False):
         """Per clique, the variables its potential depends on: the union of the variables of the factors assigned to it
         (`junctiontree.py:203-226` - evaluate leaves every other variable of the clique a length-1 axis, `:52-61`).  The device
-        plan keeps no full-size table for a clique that is mostly such axes (`engine.Plan(cover=...)`)."""
+        plan keeps no full-size table for a clique that is mostly such axes (`engine.Plan(cover=...)`).  `trusted`: the caller
+        vouches that the factor lists are what they were at the last call (`propagate(xs, changed=...)`): the remembered
+        cover is returned without looking at them."""
         ct = self.clique_tree
-        mark = (tuple(map(tuple, ct.factor_graph.factors)), tuple(ct.factor_to_maxclique))
         hit = self._memo.get("cover")
+        if trusted and hit is not None:
+            return hit[1]
+        mark = (tuple(map(tuple, ct.factor_graph.factors)), tuple(ct.factor_to_maxclique))
         if hit is not None and hit[0] == mark:
             return hit[1]
         cover = [[] for _ in ct.maxcliques]
@@ -178,7 +182,7 @@ class JunctionTree:
         self._memo["cover"] = (mark, cover)
         return cover
 
-    def plan(self, dtype="f64"):
+    def plan(self, dtype="f64", trusted=False):
         """The device plan for the current variable sizes (sizes are read at call time, as
         `junctiontree.py:311` does: the reference's tests condition on evidence by setting
         a size to 1, `tests/test_junctiontree.py:393-411`)."""
@@ -186,10 +190,11 @@ class JunctionTree:
         from . import engine
 
         # the plan cache's key names the whole structure (1-2 ms to build for a thousand cliques): a tree remembers the key
-        # and a weak reference to the plan it was last given for (dtype, the sizes as they are NOW, its options)
+        # and a weak reference to the plan it was last given for (dtype, the sizes as they are NOW, its options, and the
+        # factor structure its cover was computed from - by value: a recomputed cover may reuse the old list's id)
         sizes = self.clique_tree.factor_graph.sizes
-        cover = self.cover()
-        mark = (dtype, tuple(sizes.items()), tuple(sorted(self._opts.items())), id(cover))
+        cover = self.cover(trusted=trusted)
+        mark = (dtype, tuple(sizes.items()), tuple(sorted(self._opts.items())), self._memo["cover"][0])
         hit = self._memo.get("plan")
         if hit is not None and hit[0] == mark:
             plan = engine.cached_plan(hit[1], hit[2]())
@@ -200,20 +205,26 @@ class JunctionTree:
         self._memo["plan"] = (mark, key, weakref.ref(plan))
         return plan
 
-    def propagate(self, xs):
+    def propagate(self, xs, changed=None):
         """Belief propagation: factor values in, unnormalised factor marginals out (same
-        list length and array shapes as `xs`; float64)."""
+        list length and array shapes as `xs`; float64).
+
+        `changed` (not in the reference; it answers the FIXME at `junctiontree.py:206-214`): the indices of the factors whose
+        tables differ from the previous call on this tree, or "all".  By default every table is compared with what the device
+        holds (one vectorised pass over all of them, so that arrays updated in place are seen); a caller that knows what it
+        changed skips that - and vouches that the factor structure and every other table are what they were."""
         ct = self.clique_tree
-        all_f32 = all(isinstance(x, np.ndarray) and x.dtype == np.float32 for x in xs)
-        plan = self.plan("f32" if all_f32 else "f64")
+        trusted = changed is not None and "plan" in self._memo
+        all_f32 = all(type(x) is np.ndarray and x.dtype == np.float32 for x in xs)
+        plan = self.plan("f32" if all_f32 else "f64", trusted=trusted)
         # evaluate (junctiontree.py:203-226) on the device: only factor tables cross PCIe, and only those of
         # cliques whose factors changed since this plan last saw them (the reference recomputes every clique on
         # every call and says so in a FIXME, junctiontree.py:206-214)
-        _stage_changed_cliques(plan, ct, xs)
+        _stage_changed_cliques(plan, ct, xs, changed=changed)
         plan.propagate()
         # marginalize (junctiontree.py:229-274) on the device: one launch for all factors, the factors of one clique
         # sharing the passes over its belief table
-        return plan.factor_marginals(ct.factor_graph.factors, ct.factor_to_maxclique)
+        return plan.factor_marginals(ct.factor_graph.factors, ct.factor_to_maxclique, trusted=trusted)
 
     def propagate_evidence_sets(self, xs, evidence_sets):
         """`propagate` for several hard-evidence sets over the same factor values (no counterpart in the

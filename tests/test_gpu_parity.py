@@ -1192,6 +1192,50 @@ def test_factor_tables_are_staged_in_one_call_and_only_where_they_changed():
     engine.clear_plan_cache()
 
 
+def test_a_caller_may_name_the_factors_it_changed():
+    """`tree.propagate(values, changed=[...])` (round 6; the reference's FIXME at `junctiontree.py:206-214`): nothing is compared,
+    the cliques of the named factors are formed again, the others stand; "all" forms every clique; an unnamed change is - by
+    contract - not seen until a call without `changed` compares everything again."""
+    rng = np.random.default_rng(5)
+    names = list("abcdefgh")
+    sizes = dict(zip(names, (2, 3, 2, 4, 3, 2, 5, 2)))
+    factors = [["a", "b"], ["b", "c"], ["c", "d", "e"], ["e", "f"], ["f", "g"], ["g", "h"], ["a"], ["d"], ["h", "g"]]
+    values = [rng.uniform(0.2, 1.0, [sizes[v] for v in f]) for f in factors]
+    tree = jt.create_junction_tree(factors, sizes)
+    n_cl = len(tree.clique_tree.maxcliques)
+    got = tree.propagate(values, changed="all")               # (first call: there is nothing to trust yet - everything is staged)
+    plan = tree.plan("f64")
+    assert plan.staged_cliques == n_cl
+    for g, w in zip(got, _joint_marginals(factors, sizes, values)):
+        close(g, w)
+    values[3] = values[3] * 2.0
+    values[7] = values[7] + 0.5
+    got = tree.propagate(values, changed=[3, 7, 3])
+    assert 1 <= plan.staged_cliques <= 2
+    for g, w in zip(got, _joint_marginals(factors, sizes, values)):
+        close(g, w)
+    stale = [v.copy() for v in values]
+    values[0] = values[0] * 5.0                                # not named: not looked at
+    got = tree.propagate(values, changed=[])
+    assert plan.staged_cliques == 0
+    for g, w in zip(got, _joint_marginals(factors, sizes, stale)):
+        close(g, w)
+    got = tree.propagate(values)                               # a call without `changed` compares everything
+    assert plan.staged_cliques >= 1
+    for g, w in zip(got, _joint_marginals(factors, sizes, values)):
+        close(g, w)
+    values = [v * 1.5 for v in values]
+    got = tree.propagate(values, changed="all")
+    assert plan.staged_cliques == n_cl
+    for g, w in zip(got, _joint_marginals(factors, sizes, values)):
+        close(g, w)
+    with pytest.raises(IndexError):
+        tree.propagate(values, changed=[len(factors)])
+    with pytest.raises(ValueError):
+        tree.propagate(values, changed="some")
+    engine.clear_plan_cache()
+
+
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_cliques_of_many_factors_and_of_large_factor_tables(dt):
     """`jtp_set_potential_products`: a clique that collects more factors than one pass multiplies (JT_EVAL_MAX_F = 8: the rest
@@ -1337,6 +1381,52 @@ def test_multiset_plans_with_odd_cardinalities_share_evidence_free_subtrees_whil
             assert abs(plan.z(batch=b) - zb) <= 1e-11 * zb + 1e-300, (rnd, b)
             for node in (0, spec["n_cliques"] - 1, spec["n_cliques"], len(spec["node_vars"]) - 1):
                 close(plan.belief(node, batch=b), w[node], what="round %d set %d node %d" % (rnd, b, node))
+    st = plan.stats()
+    assert st["flow_fallbacks"] == 0 and st["launch_mode"] == "flow"
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_skipped_producers_re_arm_the_partial_copies_their_reduce_tasks_sum(monkeypatch, dtype):
+    """Round 6 (advisor, round 5): a multi-set plan that shares evidence-free subtrees skips a collect task for a group whose sets observe
+    nothing below it.  Where a REDUCE task sums that producer's partial copies, the copies are entries of their own - a skipped
+    producer used to leave them alone, so when evidence moved into the subtree, out of it and back in, the reduce task of the third
+    propagate found the first propagate's values in its arena half (no marker = written) and summed them.  The copy pass now re-arms
+    them.  Evidence of ONE subtree goes in, out and in again with another observed state, six propagates over both arena halves,
+    every set's Z and beliefs against the oracle."""
+    monkeypatch.setenv("JTP_EF_SHARE", "1")
+    monkeypatch.setenv("JTP_REDUCE_MIN", "2")
+    spec = synthetic.wide_binary_tree(n_cliques=15, width=13, sep=6, card=2, seed=2)
+    pots = synthetic.potentials_for(spec, seed=8)
+    cast = [p.astype(np.float32) for p in pots] if dtype == "f32" else pots
+    nb = 8
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, n_batch=nb, share_potentials=True, multiset=True)
+    d = plan.describe()
+    ups = [s for s in d["pseps"] if s["up_red_task"] >= 0]
+    assert ups, "this tree must have upward reduce tasks"
+    # a variable private to the subtree below a separator with an upward reduce task (it is in the child clique, not in the separator)
+    sp = ups[-1]
+    child_vars = [v for v in d["pnodes"][sp["child"]]["vars"] if v not in sp["vars"]]
+    inside = plan.var_labels[child_vars[0]]
+    for c in range(spec["n_cliques"]):
+        plan.set_potential(c, cast[c])
+    tol = RTOL32 if dtype == "f32" else RTOL64
+    # (a group's task is skipped only when NO set of the group observes anything below it: all eight sets move together)
+    for rnd, state in enumerate([0, None, 1, None, None, 0]):
+        observed = []
+        for b in range(nb):
+            obs = {}
+            if state is not None:
+                obs[inside] = (state + b) % 2
+            observed.append(obs)
+            plan.set_evidence(obs, batch=b)
+        plan.propagate(0, nb)
+        for b in range(nb):
+            w, zb = oracle.beliefs_exact(spec["tree"], _indicator_potentials(spec, cast, observed[b]), spec["node_vars"], return_z=True)
+            assert abs(plan.z(batch=b) - zb) <= (1e-6 if dtype == "f32" else 1e-11) * zb + 1e-300, (rnd, b)
+            for node in (0, sp["child"], sp["node"], spec["n_cliques"] - 1):
+                close(plan.belief(node, batch=b), w[node], rtol=tol, what="round %d set %d node %d" % (rnd, b, node))
     st = plan.stats()
     assert st["flow_fallbacks"] == 0 and st["launch_mode"] == "flow"
     plan.close()
