@@ -218,6 +218,8 @@ struct BatchBuffers {
     double *msg = nullptr;
     double *fix = nullptr;          // fixed arena: the static tables of unit cliques (HostPlan::statics; shared like psi)
     uint32_t *ev = nullptr;         // hard evidence: (mask, value) per planner node, or null (jtp_set_evidence)
+    bool ev_any = false;            // ... and it observes something: the kernels get a null table otherwise (single-set plans: the lean
+                                    // unit pass takes that for "no evidence anywhere", jt_unit_collect)
     uint32_t *sync = nullptr;       // dataflow launches: abort flag and ticket counters
     uint32_t epoch = 0;             // propagates enqueued so far; its parity selects the message arena half
     uint32_t flow_runs = 0;         // of which dataflow
@@ -1379,6 +1381,7 @@ int jtp_set_evidence(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *var_
     HIP_TRY(hipStreamSynchronize(s));                      // a propagate in flight may still read the old table
     if (!b.ev) HIP_TRY(hipMalloc((void **)&b.ev, ev.size() * sizeof(uint32_t)));      // (multi-set plans: a slice of ev_all)
     HIP_TRY(hipMemcpy(b.ev, ev.data(), ev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    b.ev_any = n > 0;
     if (pl->multiset) {
         // a group of evidence sets may sum the elements of a vector before the message product on a clique while none of ITS
         // sets observes a variable on that clique's element bits (JtTask::esum_groups; bit b stands for the groups g = b mod 64)
@@ -1600,7 +1603,7 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         // (a plan that launches per level never waits on entries: it need not mark the other half)
         fl.oth_off = pl->flow ? half - fl.cur_off : -1;
         fl.dbg = pl->flow_debug;
-        fl.ev = bb.ev;
+        fl.ev = bb.ev_any ? bb.ev : nullptr;
         fl.fix_shift = bb.fix_shift(fl.cur_off);
         if (flow) {
             bb.flow_runs++;
@@ -1763,7 +1766,7 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
             memset(&one, 0, sizeof one);
             one.cur_off = b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));
             one.oth_off = -1;
-            one.ev = b.ev;
+            one.ev = b.ev_any || pl->multiset ? b.ev : nullptr;
             one.fix_shift = b.fix_shift(one.cur_off);
             HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_SINGLE, mixk(hp)) : (const void *)KernelTable<double>::get(JT_K_SINGLE, mixk(hp)), bt.lds));
             launch_variant(pl, JT_K_SINGLE, bt.nblocks, bt.lds, s, bt.d_task, bt.d_blk, bt.d_tab, b.psi, bel_src, b.msg, one);
@@ -2019,7 +2022,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         // marginalised directly - inputs from the set's message arena (and the fixed arena), outputs into the request list's
         // scratch buffer (JtFlow::out_shift)
         plain.cur_off = b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));
-        plain.ev = b.ev;
+        plain.ev = b.ev_any || pl->multiset ? b.ev : nullptr;
         plain.fix_shift = b.fix_shift(plain.cur_off);
         plain.out_shift = (int64_t)(((intptr_t)mb->scratch - (intptr_t)(b.msg + plain.cur_off)) / 8);
         launch_variant(pl, JT_K_SINGLE, mb->unit_nblocks, mb->unit_lds, s, mb->d_tasks, mb->d_blocks + mb->nblocks, mb->d_itab, b.psi, b.bel, b.msg, plain);

@@ -144,7 +144,45 @@ struct JtTask {
     int64_t tmap_off;          // plans with a mixed-radix thread part (HostPlan::tmix, kernels *_mix): offset (ints) in the table
                                // buffer of the clique's thread map - 2^TB entries, entry x = element offset inside a row of
                                // logical thread index x, or -1 where x names no table entry; else -1
+    int64_t lean_off;          // > 0: offset (ints, a multiple of 16) in the table buffer of this task's JtLean record - a unit task of
+                               // one outgoing message whose incoming tables have one copy each runs jt_unit_lean (round 6) when its
+                               // evidence set observes nothing; 0 (what a zeroed record says): the generic pass
     JtMsg msg[JT_MAX_MSG];     // [0, n_in) incoming; [JT_MAX_IN, JT_MAX_IN + n_out) outgoing
+};
+
+// Round 6: what a UNIT task of one outgoing message needs, and nothing else (jt_unit_lean, jtp_kernels.hip.h).  The generic pass
+// interprets JtTask - 2.3 KB of record, bit-deposit loops over free_pos[] in scalar code for every staged entry, a branch per
+// message and row on e_dep: 1 200 scalar instructions per wave for a workgroup of 13 rows (profiles/r05_counters_c3.txt) - which is
+// what bounds a plan made of hundreds of thousands of such workgroups (BASELINE configs[2]).  Here the host has done the deposits:
+// a sub-box entry's place in its message is  w_lo . (bits of the thread id) + w_hi . (bits of the round)  with plain weights (0
+// beyond nfree), the incoming tables are ORDERED - those that depend on the element bits of a thread's four elements first (`n_e`
+// of them: the row loop is compiled per (n_in, n_e) and has no branch) - and the record is 64-byte aligned, read with a few
+// s_load_dwordx16.  The record lives in the plan's table buffer (JtTask::lean_off).
+struct JtLeanMsg {             // 32 ints
+    int64_t off;               // JtMsg::off
+    int32_t nfree;
+    int32_t lds_off;           // bytes
+    int32_t flags;             // 1: same_launch (read through to memory, wait on markers), 2: fixed (a static table)
+    int32_t src;               // the message's index in JtTask::msg / JtBlock::gbase
+    int32_t e_w[2];            // sub-box slot weights of the element bits
+    int32_t w_lo[8];           // place in the MESSAGE of sub-box index bit b, b = 0..7 (as a weight: 1 << free_pos[b]; 0: b >= nfree)
+    int32_t w_hi[8];           // ... b = 8..12 (three spare)
+    int32_t t_w[8];            // sub-box slot weights of the six lane bits, then the two wave bits
+};
+struct JtLean {                // 5 * 32 + 16 = 176 ints
+    JtLeanMsg in[JT_MAX_IN];   // [0, n_e): depend on the element bits; [n_e, n_in): do not
+    JtLeanMsg out;
+    int32_t n_in, n_e;
+    int32_t total;             // rows per workgroup
+    int32_t rmask;             // the outgoing message's sums are folded after every row i with (i & rmask) == rmask
+    int32_t red_e, red_lane, red_wave;
+    int32_t settle;            // JtTask::settle
+    int32_t out_pstride;       // doubles between partial copies of the outgoing message
+    int32_t some_invalid;      // 1: the clique's thread map has entries that do not exist (it is read, JtLean::tmap_off)
+    int64_t tmap_off;          // JtTask::tmap_off
+    int64_t itab_off;          // JtTask::itab_off
+    int32_t some_norow;        // 1: some row of the workgroups' loop nest does not exist (JT_NO_ROW in the iteration table)
+    int32_t pad;
 };
 
 // per-launch arguments of the message-passing kernels

@@ -1257,6 +1257,335 @@ __global__ __launch_bounds__(JT_THREADS) void jt_reduce_level(const JtTask *__re
     jt_reduce<false>(tasks[bk.task], bk, msg, fl);
 }
 
+// ------------------------------------------------------------------------------------------
+// The lean unit pass (round 6; JtLean, jtp_internal.h).  A unit task of ONE outgoing message whose incoming tables have one copy each,
+// run for an evidence set that observes nothing:
+//     out[S] = sum_{C \ S} prod_k in_k[S_k]          (computation.py:79-88 for a clique the reference keeps as length-1 axes,
+//                                                     junctiontree.py:52-61; every downward message of such a clique likewise)
+// Same sub-boxes, same LDS offsets, same iteration table, same marker protocol and the same epilogue as jt_pass<..., UNIT> - what is
+// gone is the interpretation: no bit-deposit loops over free_pos[] (the host stored the weights), no branch per message and row on
+// e_dep (the tables that depend on a thread's element bits come first and their number NE is a template parameter), no table row,
+// no evidence, no belief, no ring, one read of a 704-byte record instead of scattered reads of a 2.3 KB one.  Where no incoming
+// table depends on the element bits (NE = 0) the VEC elements of a thread share ONE product and one accumulator.
+// Product order: in[0] * in[1] * ... in the RECORD's order (element-dependent tables first) - a fixed order, the same in every
+// launch mode; the generic pass multiplies in JtTask order, so the two agree to rounding, not bit for bit.
+template <typename T, int NIN, int NE, bool FLOW>
+__device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk, const int *__restrict__ itab,
+                                             double *__restrict__ msg_arena, const JtFlow &fl, uint32_t *flow_ctl) {
+    constexpr int VEC = 16 / sizeof(T);               // elements of a thread per row (the plan's thread part: 256 threads x VEC)
+    constexpr int NI = NIN > 0 ? NIN : 1;
+    constexpr int NACC = NE > 0 ? VEC : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = ln.total;
+
+    // ---- everything that does not depend on a message: the iteration table (row r in lane r), the thread's validity
+    int trow[JT_NCOL];
+    {
+        const int *gtab = itab + ln.itab_off;
+        const int r = lane < total ? lane : total - 1;
+        const int4 a = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL);
+        const int4 b = *reinterpret_cast<const int4 *>(gtab + r * JT_NCOL + 4);
+        trow[0] = a.x; trow[1] = a.y; trow[2] = a.z; trow[3] = a.w;
+        trow[4] = b.x; trow[5] = b.y; trow[6] = b.z; trow[7] = b.w;
+    }
+    uint32_t dead = 0;                                // bit e: element e of this thread names no entry of the clique
+    if (ln.some_invalid) {
+        const int *tm = itab + ln.tmap_off + tid * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dead |= tm[e] < 0 ? 1u << e : 0u;
+    }
+    const bool chunk_ok = !(bk.flags & JT_BLOCK_INVALID);
+
+    // a sub-box entry's place in its message: weights . bits of (round, thread)
+    auto lo_of = [&](const JtLeanMsg &m) {
+        uint32_t g = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) g += (((uint32_t)tid >> b) & 1u) * (uint32_t)m.w_lo[b];
+        return g;
+    };
+    auto hi_of = [&](const JtLeanMsg &m) {            // (lane j: round j)
+        uint32_t g = 0;
+#pragma unroll
+        for (int b = 0; b < JT_MAX_FREE - 8; ++b) g += (((uint32_t)lane >> b) & 1u) * (uint32_t)m.w_hi[b];
+        return g;
+    };
+
+    // ---- stage the incoming sub-boxes, all of them in lock step: four rounds of 256 entries of every message in flight together
+    const double *msg_cur = msg_arena + fl.cur_off;
+    const double *src[NI];
+    uint32_t lo[NI], hiv[NI];
+    int nent[NI];
+    bool thr_mem[NI];
+    int rounds = 0;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const JtLeanMsg &m = ln.in[k];
+        const int gb = m.src == 0 ? bk.gbase[0] : (m.src == 1 ? bk.gbase[1] : (m.src == 2 ? bk.gbase[2] : bk.gbase[3]));
+        src[k] = msg_cur + (m.off + gb + ((m.flags & 2) ? fl.fix_shift : 0));
+        lo[k] = lo_of(m);
+        hiv[k] = hi_of(m);
+        nent[k] = 1 << m.nfree;
+        thr_mem[k] = (m.flags & 1) != 0;
+        const int r = (nent[k] + JT_THREADS - 1) >> 8;
+        rounds = r > rounds ? r : rounds;
+    }
+    const uint32_t out_lo = lo_of(ln.out), out_hiv = hi_of(ln.out);
+    uint64_t wait_t0 = 0;
+    for (int attempt = 0;; ++attempt) {
+        const int settle_attempt = ln.settle ? attempt : 0;
+        const double *unready = nullptr;
+        for (int it0 = 0; it0 < rounds; it0 += 4) {
+            double c[NI][4];
+            const double *at[NI][4];
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    at[k][u] = src[k] + (lo[k] + (uint32_t)__builtin_amdgcn_readlane((int)hiv[k], it0 + u));
+                    c[k][u] = (it0 + u) * JT_THREADS + tid < nent[k] ? jt_msg_load<FLOW>(at[k][u], thr_mem[k]) : 0.0;
+                }
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                double *sub = reinterpret_cast<double *>(smem + ln.in[k].lds_off);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if ((it0 + u) * JT_THREADS + tid >= nent[k]) continue;
+                    if (FLOW) c[k][u] = jt_msg_settle<FLOW>(at[k][u], c[k][u], thr_mem[k], settle_attempt);
+                    if (FLOW && jt_unwritten(c[k][u])) unready = at[k][u];
+                    sub[(it0 + u) * JT_THREADS + tid] = 0.0 + c[k][u];
+                }
+            }
+        }
+        if (attempt == 0) {
+            double *sub = reinterpret_cast<double *>(smem + ln.out.lds_off);
+            const int n = 1 << ln.out.nfree;
+            for (int s = tid; s < n; s += JT_THREADS) sub[s] = 0.0;
+        }
+        if constexpr (!FLOW || NIN == 0) {
+            __syncthreads();
+            break;
+        } else {
+            // (the wait of jt_pass: one lane polls one entry that was not ready, with back-off; it gives up after 2 s or when another
+            //  workgroup did, so that the grid always drains)
+            if (fl.dbg & 4) unready = nullptr;
+            if (fl.dbg & 8) unready = msg_cur;
+            uint32_t *slot = flow_ctl + 4 + (attempt & 1) * 12;
+            {
+                const uint64_t have = __ballot(unready != nullptr);
+                if (have != 0 && lane == (int)__builtin_ctzll(have)) {
+                    slot[4 + 2 * wave] = (uint32_t)(uintptr_t)unready;
+                    slot[5 + 2 * wave] = (uint32_t)((uintptr_t)unready >> 32);
+                }
+                if (lane == 0) slot[wave] = have != 0 ? 1u : 0u;
+            }
+            __syncthreads();
+            const uint32_t w3 = slot[3], w2 = slot[2], w1 = slot[1], w0 = slot[0];
+            if ((w0 | w1 | w2 | w3) == 0) break;
+            if (tid == 0) {
+                const int cw = w3 ? 3 : (w2 ? 2 : (w1 ? 1 : 0));
+                const double *entry = reinterpret_cast<const double *>((uintptr_t)slot[4 + 2 * cw] | ((uintptr_t)slot[5 + 2 * cw] << 32));
+                if (wait_t0 == 0) wait_t0 = __builtin_amdgcn_s_memrealtime();
+                uint32_t give_up = 0;
+                unsigned spins = 0;
+                const uint64_t limit = (fl.dbg & 8) ? 2000000ull : 200000000ull;
+                while (jt_unwritten(jt_msg_load<true>(entry)) || (fl.dbg & 8)) {
+                    if (spins >= 64) __builtin_amdgcn_s_sleep(32);
+                    else if (spins >= 16) __builtin_amdgcn_s_sleep(16);
+                    if ((++spins & 15u) == 0) {
+                        if (__hip_atomic_load(fl.sync + JT_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = 1;
+                        else if (__builtin_amdgcn_s_memrealtime() - wait_t0 > limit) {
+                            __hip_atomic_store(fl.sync + JT_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(fl.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            give_up = 1;
+                        }
+                        if (give_up) break;
+                    }
+                }
+                flow_ctl[1] = give_up;
+            }
+            __syncthreads();
+            if (flow_ctl[1] != 0) return;
+        }
+    }
+
+    // ---- per-thread constants: the byte address inside LDS of this thread's entry of every incoming sub-box (a row adds its offset)
+    auto slot_of = [&](const JtLeanMsg &m) {
+        int t = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) t += ((lane >> b) & 1) * m.t_w[b];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) t += ((wave >> b) & 1) * m.t_w[6 + b];
+        return t;
+    };
+    uint32_t ua[NI][NE > 0 ? VEC : 1];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const JtLeanMsg &m = ln.in[k];
+        const int t = slot_of(m);
+        ua[k][0] = (uint32_t)m.lds_off + 8u * (uint32_t)t;
+        if constexpr (NE > 0) {
+            if (k < NE) {
+#pragma unroll
+                for (int e = 1; e < VEC; ++e) ua[k][e] = ua[k][0] + 8u * (uint32_t)(((e & 1) ? m.e_w[0] : 0) + ((e & 2) ? m.e_w[1] : 0));
+            }
+        }
+    }
+    double *out_sub = reinterpret_cast<double *>(smem + ln.out.lds_off);
+    const int thr_out = slot_of(ln.out);
+    const int o_ew0 = ln.out.e_w[0], o_ew1 = ln.out.e_w[1];
+    const int red_e = ln.red_e, red_lane = ln.red_lane, red_wave = ln.red_wave;
+    const int rmask = ln.rmask;
+    const bool rep = (lane & red_lane) == 0;
+    const int nph = 1 << __builtin_popcount((unsigned)red_wave);
+    int myph = 0;
+    if (red_wave == 1) myph = wave & 1;
+    else if (red_wave == 2) myph = wave >> 1;
+    else if (red_wave == 3) myph = wave;
+
+    double acc[NACC];
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
+    // (the record orders the tables its own way; a table's column of the iteration table is its place in JtTask::msg - picked once)
+    int tcol[NI];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const int sk = ln.in[k].src;
+        tcol[k] = sk == 0 ? trow[1] : (sk == 1 ? trow[2] : (sk == 2 ? trow[3] : trow[4]));
+    }
+
+    // fold this thread's sums of one run of rows into the outgoing sub-box (jt_pass: same sums, same order)
+    auto epilogue = [&](const int oo) {
+        double a[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = ((dead >> e) & 1u) ? 0.0 : acc[NE > 0 ? e : 0];
+        if constexpr (VEC == 4) {
+            if (red_e & 1) {
+                a[0] += a[1];
+                a[2] += a[3];
+            }
+            if (red_e & 2) {
+                a[0] += a[2];
+                a[1] += a[3];
+            }
+        } else {
+            if (red_e & 1) a[0] += a[1];
+        }
+        jt_lane_sums<VEC>(a, red_lane);
+        const int slot = oo + thr_out;
+        for (int ph = 0; ph < nph; ++ph) {
+            if (rep && myph == ph) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if ((e & red_e) == 0) {
+                        const int eo = ((e & 1) ? o_ew0 : 0) + ((e & 2) ? o_ew1 : 0);
+                        __hip_atomic_fetch_add(&out_sub[slot + eo], a[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            if (nph > 1) __syncthreads();
+        }
+#pragma unroll
+        for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
+    };
+
+#pragma unroll
+    for (int c = 0; c < JT_NCOL; ++c) asm volatile("" : "+v"(trow[c]));
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) asm volatile("" : "+v"(tcol[k]));
+
+    // ---- the rows: nothing but look-ups and products.  The entries of row i + 1 are asked for before those of row i are used (one
+    //      LDS round trip per row otherwise, and nothing to do in it).  CHECK: some row of the loop nest does not exist (a digit
+    //      beyond a cardinality: JT_NO_ROW) - such a row adds nothing; plans of power-of-two cardinalities never look.
+    struct Entries {
+        double e[NE > 0 ? NE : 1][VEC], c[NIN - NE > 0 ? NIN - NE : 1];
+    };
+    auto fetch = [&](const int i, Entries &x) {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane(tcol[k], i) << 3;
+            if constexpr (NE > 0) {
+                if (k < NE) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) x.e[k < NE ? k : 0][e] = *reinterpret_cast<const double *>(smem + (ua[k][e] + rb));
+                    continue;
+                }
+            }
+            x.c[k - NE >= 0 ? k - NE : 0] = *reinterpret_cast<const double *>(smem + (ua[k][0] + rb));
+        }
+    };
+    auto use = [&](const Entries &x) {
+        if constexpr (NIN == 0) {
+            acc[0] += 1.0;
+        } else if constexpr (NE == 0) {
+            double w = x.c[0];
+#pragma unroll
+            for (int k = 1; k < NIN; ++k) w *= x.c[k];
+            acc[0] += w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double w = x.e[0][e];
+#pragma unroll
+                for (int k = 1; k < NE; ++k) w *= x.e[k][e];
+#pragma unroll
+                for (int k = NE; k < NIN; ++k) w *= x.c[k - NE];
+                acc[e] += w;
+            }
+        }
+    };
+    auto rows = [&](auto check_tag) {
+        constexpr bool CHECK = decltype(check_tag)::value;
+        Entries cur, nxt;
+        fetch(0, cur);
+        for (int i = 0; i < total; ++i) {
+            fetch(i + 1 < total ? i + 1 : i, nxt);
+            if (!CHECK || (uint32_t)__builtin_amdgcn_readlane(trow[0], i) != JT_NO_ROW) use(cur);
+            if ((i & rmask) == rmask) epilogue(__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], i));
+            cur = nxt;
+        }
+    };
+    if (chunk_ok) {                                       // (a chunk whose own digits do not exist writes its zeros and nothing else)
+        if (ln.some_norow) rows(std::integral_constant<bool, true>{});
+        else rows(std::integral_constant<bool, false>{});
+    }
+
+    // ---- flush the outgoing sub-box as this chunk's partial copy; the same entries of the other arena half become "unwritten"
+    __syncthreads();
+    {
+        const int64_t at = ln.out.off + (int64_t)bk.pnum[0] * ln.out_pstride + bk.gbase[JT_MAX_IN];
+        double *dst = msg_arena + fl.cur_off + at + fl.out_shift;
+        double *oth = msg_arena + fl.oth_off + at;
+        const bool mark = fl.oth_off >= 0;
+        const int n = 1 << ln.out.nfree;
+        for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
+            const uint32_t idx = out_lo + (uint32_t)__builtin_amdgcn_readlane((int)out_hiv, it);
+            jt_msg_store<FLOW>(dst + idx, out_sub[s]);
+            if (mark) oth[idx] = __longlong_as_double((long long)JT_UNWRITTEN);
+        }
+    }
+}
+
+// (which of the ten row loops: incoming tables x those among them that depend on the element bits)
+template <typename T, bool FLOW>
+__device__ __forceinline__ void jt_unit_lean_dispatch(const JtLean &ln, const JtBlock &bk, const int *__restrict__ itab,
+                                                      double *__restrict__ msg, const JtFlow &fl, uint32_t *flow_ctl) {
+#define JT_LEAN(NIN, NE) jt_unit_lean<T, NIN, NE, FLOW>(ln, bk, itab, msg, fl, flow_ctl); break
+    switch (ln.n_in * 8 + ln.n_e) {
+        case 0: JT_LEAN(0, 0);
+        case 8: JT_LEAN(1, 0);
+        case 9: JT_LEAN(1, 1);
+        case 16: JT_LEAN(2, 0);
+        case 17: JT_LEAN(2, 1);
+        case 18: JT_LEAN(2, 2);
+        case 24: JT_LEAN(3, 0);
+        case 25: JT_LEAN(3, 1);
+        case 26: JT_LEAN(3, 2);
+        default: JT_LEAN(3, 3);                           // (jtp_make_lean: at most three incoming tables)
+    }
+#undef JT_LEAN
+}
+
 // Unit tasks (JtTask::unit): their shapes differ from the table-keeping tasks' - the static table is one more incoming one
 // (collect: up to three children, or the static table and two; distribute: the parent's message and / or the static table, then
 // up to three children) - so they are dispatched here, by every kernel that may meet one.
@@ -1266,6 +1595,14 @@ template <typename T, bool FLOW, bool TMIX>
 __device__ __forceinline__ void jt_unit_collect(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                 T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                 uint32_t *flow_ctl, uint64_t t_entry) {
+    if constexpr (!TMIX) {
+        // (round 6) a task of one outgoing message and single-copy inputs, run for an evidence set that observes nothing - the engine
+        // passes no evidence table then: the lean pass
+        if (tk.lean_off > 0 && fl.ev == nullptr) {
+            jt_unit_lean_dispatch<T, FLOW>(*reinterpret_cast<const JtLean *>(itab + tk.lean_off), bk, itab, msg, fl, flow_ctl);
+            return;
+        }
+    }
     switch (tk.n_in) {
         case 0: JT_UNIT_PASS(0, 1, 0); break;
         case 1: JT_UNIT_PASS(1, 1, 0); break;

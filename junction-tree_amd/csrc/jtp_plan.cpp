@@ -636,6 +636,58 @@ JtBlock jtp_make_block(const HostPlan &hp, const JtTask &tk, uint32_t task_index
     return b;
 }
 
+// The lean record of a unit task (JtLean, jtp_internal.h), appended to `itab` at a 64-byte boundary; JtTask::lean_off says where
+// (0: the task runs the generic pass - it keeps a table, has several outputs, stores a belief, belongs to a plan with mixed-radix
+// rows or to a multi-set plan, or stages a message of several partial copies).  JTP_NO_LEAN=1: no task gets one.
+void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab) {
+    tk.lean_off = 0;
+    if (hp.knobs.no_lean || hp.tmix || hp.multiset) return;
+    if (tk.kind != 0 || !tk.unit || tk.mode != 0 || tk.n_out != 1 || tk.n_in > 3 || tk.bel_off >= 0 || tk.vgroups) return;
+    for (int k = 0; k < tk.n_in; ++k)
+        if (tk.msg[k].npart != 1) return;
+    if ((tk.debug & ~2) != 0) return;                 // (the JTP_DEBUG timing experiments are switches of the generic pass)
+    JtLean ln;
+    memset(&ln, 0, sizeof ln);
+    auto fill = [&](JtLeanMsg &lm, const JtMsg &m, int src) {
+        lm.off = m.off;
+        lm.nfree = m.nfree;
+        lm.lds_off = m.lds_off;
+        lm.flags = (m.same_launch ? 1 : 0) | (m.fixed ? 2 : 0);
+        lm.src = src;
+        lm.e_w[0] = m.e_w[0], lm.e_w[1] = m.e_w[1];
+        for (int b = 0; b < 8; ++b) lm.w_lo[b] = b < m.nfree ? 1 << m.free_pos[b] : 0;
+        for (int b = 0; b < 8; ++b) lm.w_hi[b] = 8 + b < m.nfree ? 1 << m.free_pos[8 + b] : 0;
+        for (int t = 0; t < 8; ++t) lm.t_w[t] = m.t_w[t];
+    };
+    int n = 0;
+    for (int pass = 0; pass < 2; ++pass)                      // the tables that depend on the element bits first
+        for (int k = 0; k < tk.n_in; ++k)
+            if ((tk.msg[k].e_dep != 0) == (pass == 0)) fill(ln.in[n++], tk.msg[k], k);
+    for (int k = 0; k < tk.n_in; ++k) ln.n_e += tk.msg[k].e_dep ? 1 : 0;
+    const JtMsg &mo = tk.msg[JT_MAX_IN];
+    fill(ln.out, mo, JT_MAX_IN);
+    ln.n_in = tk.n_in;
+    ln.total = tk.total;
+    ln.rmask = (1 << (tk.out_run & 0xffu)) - 1;
+    ln.red_e = mo.red_e, ln.red_lane = mo.red_lane, ln.red_wave = mo.red_wave;
+    ln.settle = tk.settle;
+    ln.out_pstride = mo.pstride;
+    ln.tmap_off = tk.tmap_off;
+    ln.itab_off = tk.itab_off;
+    if (tk.tmap_off >= 0) {
+        const int n_t = 1 << hp.TB;
+        for (int x = 0; x < n_t; ++x)
+            if (itab[(size_t)tk.tmap_off + x] < 0) ln.some_invalid = 1;
+    } else
+        ln.some_invalid = 0;
+    for (int i = 0; i < tk.total; ++i)
+        if ((uint32_t)itab[(size_t)tk.itab_off + (size_t)i * JT_NCOL] == JT_NO_ROW) ln.some_norow = 1;
+    while (itab.empty() || itab.size() % 16) itab.push_back(0);
+    tk.lean_off = (int64_t)itab.size();
+    const int32_t *w = reinterpret_cast<const int32_t *>(&ln);
+    itab.insert(itab.end(), w, w + sizeof ln / 4);
+}
+
 PlanKnobs jtp_read_knobs() {
     PlanKnobs k;
     auto geti = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
@@ -681,6 +733,7 @@ PlanKnobs jtp_read_knobs() {
     k.unit_joint_down = geti("JTP_UNIT_JOINT_DOWN", 0);
     k.no_ef_share = geti("JTP_EF_SHARE", 0) ? -1 : geti("JTP_NO_EF_SHARE", 0);      // (-1: the evidence-free group whatever the number of sets)
     k.unit_ratio = getd("JTP_UNIT_RATIO", 4.0);
+    k.no_lean = geti("JTP_NO_LEAN", 0);
     return k;
 }
 
@@ -2324,6 +2377,8 @@ int PlanBuilder::finish() {
     hp.n_messages = 0;
     for (int c = 0; c < N; ++c)
         if (c != hp.root && (hp.owner[c] == hp.rank || (hp.owner[c] == ALL && hp.rank == 0))) hp.n_messages += 2;
+    // Lean records (round 6, JtLean): every field of every task is final here
+    for (JtTask &tk : hp.tasks) jtp_make_lean(hp, tk, hp.itab);
     return JTP_OK;
 }
 
@@ -2630,7 +2685,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             if (t) o << ",";
             o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"unit\":" << tk.unit << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
-              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"keep_rows\":" << tk.keep_rows << ",\"tmap_off\":" << tk.tmap_off << ",\"vgroups\":" << tk.vgroups << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
+              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"keep_rows\":" << tk.keep_rows << ",\"tmap_off\":" << tk.tmap_off << ",\"lean_off\":" << tk.lean_off << ",\"vgroups\":" << tk.vgroups << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
             json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";

@@ -118,6 +118,7 @@ struct VirtualFill { JtPackDesc d; };   // all-ones table of a virtual clique (1
 struct HostPlan;
 // decode chunk number -> workgroup record (element base, message bases, partial numbers)
 JtBlock jtp_make_block(const HostPlan &hp, const JtTask &tk, uint32_t task_index, uint32_t chunk);
+void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab);
 
 // Development knobs, read from the environment ONCE per plan (jtp_read_knobs, at the top of jtp_build_plan):
 // nothing else in the product path calls getenv while planning or propagating.
@@ -155,6 +156,7 @@ struct PlanKnobs {
     int no_vgroups = 0;                                             // JTP_NO_VGROUPS: mixed-radix rows keep one row per step (round 3)
     int keep_invalid = 0;                                           // JTP_KEEP_INVALID: chunks that do not exist stay in the block lists (rounds 2-4)
     int no_unit = 0;                                                // JTP_NO_UNIT: no unit cliques - every clique (virtual ones too) keeps a full table (rounds 1-4)
+    int no_lean = 0;                                                // JTP_NO_LEAN: unit tasks run the generic pass (round 5), no JtLean records
     double unit_ratio = 4.0;                                        // JTP_UNIT_RATIO: a clique becomes a unit clique when its table is at least this many times its covered part
     int marg_group = JT_MAX_OUT;                                    // JTP_MARG_GROUP: marginals of one belief table formed by one pass over it (1: a pass each, round 3)
     int marg_block_log2 = 0;                                        // JTP_MARG_BLOCK_LOG2: log2 of the elements per workgroup of a marginal pass (0: the 64 rows a workgroup can hold)

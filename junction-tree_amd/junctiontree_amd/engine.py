@@ -563,11 +563,16 @@ class _FactorTables:
         if len(todo) == len(self.cliques):
             cl, off, rr = self.cliques, fo, recs
         else:
-            cl = np.ascontiguousarray(self.cliques[todo])
-            counts = (fo[1:] - fo[:-1])[todo]
-            off = np.zeros(len(todo) + 1, dtype=np.int32)
-            np.cumsum(counts, out=off[1:])
-            pick = np.concatenate([np.arange(fo[c], fo[c + 1]) for c in todo]) if off[-1] else np.zeros(0, dtype=np.int64)
+            # (the same subset call after call - the cliques that hold factors, all of them new: its index tables are kept)
+            memo = self.__dict__.get("_subset")
+            if memo is None or len(memo[0]) != len(todo) or not np.array_equal(memo[0], todo):
+                cl = np.ascontiguousarray(self.cliques[todo])
+                counts = (fo[1:] - fo[:-1])[todo]
+                off = np.zeros(len(todo) + 1, dtype=np.int32)
+                np.cumsum(counts, out=off[1:])
+                pick = np.concatenate([np.arange(fo[c], fo[c + 1]) for c in todo]) if off[-1] else np.zeros(0, dtype=np.int64)
+                memo = self._subset = (todo.copy(), cl, off, pick)
+            _, cl, off, pick = memo
             rr = np.ascontiguousarray(recs[pick]) if off[-1] else recs[:1].copy()
         self.prev = None                                             # (whatever happens below, the device no longer matches it)
         _capi.check(plan._lib.jtp_set_potential_products(plan._handle, 0, len(todo), cl.ctypes.data, off.ctypes.data, rr.ctypes.data))
