@@ -302,13 +302,19 @@ struct jtp_plan {
     uint32_t ev_stride = 0;         // uint32 per set's evidence table
     // read-out of multi-set plans: belief task of each clique, built on first use
     std::vector<uint32_t> ev_host;  // host copy of ev_all (which tasks may sum their elements first depends on it)
-    // evidence-free subtrees: group 0 holds evidence-free sets only (the caller's set b is set set0 + b of the allocation); where no
-    // set of a group observes anything below a clique, that group skips the clique's collect task (skip_host[g * n_tasks + t]), its
-    // consumers read group 0's message, and a copy pass behind the propagate (jt_multi_fanout over `fanout`) fills the sets' own arenas
+    // evidence-free subtrees: the first JT_MSETS arena slots are not the caller's (the caller's set b is slot set0 + b); slot 0 runs
+    // every collect task without evidence, and a set takes from it the upward message of every clique below which it observes nothing
     int set0 = 0;
-    std::vector<uint8_t> skip_host;
-    uint8_t *d_skip = nullptr;
-    bool skip_dirty = false;
+    // Round 6: per TASK, not per group - the active list of a collect task holds the arena slots of the sets that observe something below
+    // its clique (slot 0, the evidence-free set, first); the list of a downward task every caller's slot (rebuild_active).
+    std::vector<uint8_t> member_host;     // [task * cap + slot] != 0: the slot is on the task's list
+    std::vector<uint16_t> act_ids_host;   // [task * cap + j]
+    std::vector<int32_t> act_n_host;      // [task]
+    std::vector<uint8_t> esum_oct_host;   // [task * n_groups + g]: entries 8 g .. 8 g + 7 of the list observe nothing on the clique's element bits
+    uint8_t *d_member = nullptr, *d_esum_oct = nullptr;
+    uint16_t *d_act_ids = nullptr;
+    int32_t *d_act_n = nullptr;
+    bool act_dirty = false;
     JtFanout *d_fanout = nullptr;
     int n_fanout = 0, cap_fanout = 0;
     struct BeliefTask { JtTask *d_task = nullptr; JtBlock *d_blk = nullptr; int *d_tab = nullptr; int nblocks = 0, lds = 0; };
@@ -564,7 +570,10 @@ void jtp_plan_destroy(jtp_plan *pl) {
                 if (pl->bufs[0].bel) (void)hipFree(pl->bufs[0].bel);
             }
             if (pl->msg_all) (void)hipFree(pl->msg_all);
-            if (pl->d_skip) (void)hipFree(pl->d_skip);
+            if (pl->d_member) (void)hipFree(pl->d_member);
+            if (pl->d_esum_oct) (void)hipFree(pl->d_esum_oct);
+            if (pl->d_act_ids) (void)hipFree(pl->d_act_ids);
+            if (pl->d_act_n) (void)hipFree(pl->d_act_n);
             if (pl->d_fanout) (void)hipFree(pl->d_fanout);
             if (pl->ev_all) (void)hipFree(pl->ev_all);
             if (pl->sync_all) (void)hipFree(pl->sync_all);
@@ -767,21 +776,13 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
         }
         pl->belief_tasks.resize(hp.pn.size());
         if (pl->set0) {
-            // no evidence yet: every collect task of every group but the first copies
-            pl->skip_host.assign((size_t)pl->n_groups * hp.tasks.size(), 0);
-            // (nobody reads group 0's DOWNWARD messages: its sets are not the caller's)
-            for (const PSep &sp : hp.ps) {
-                if (sp.dn_task >= 0) pl->skip_host[sp.dn_task] = 1;
-                if (sp.dn_red_task >= 0) pl->skip_host[sp.dn_red_task] = 1;
-            }
-            for (int g = 1; g < pl->n_groups; ++g)
-                for (const PNode &p : hp.pn)
-                    if (p.collect_task >= 0) {
-                        pl->skip_host[(size_t)g * hp.tasks.size() + p.collect_task] = 1;
-                        if (hp.ps[p.psep].up_red_task >= 0) pl->skip_host[(size_t)g * hp.tasks.size() + hp.ps[p.psep].up_red_task] = 1;
-                    }
-            CREATE_TRY(hipMalloc((void **)&pl->d_skip, pl->skip_host.size()));
-            pl->skip_dirty = true;
+            // (the active lists are made by the first propagate: rebuild_active)
+            const size_t cap = (size_t)pl->n_groups * JT_MSETS, nt = hp.tasks.size();
+            CREATE_TRY(hipMalloc((void **)&pl->d_member, nt * cap));
+            CREATE_TRY(hipMalloc((void **)&pl->d_act_ids, nt * cap * sizeof(uint16_t)));
+            CREATE_TRY(hipMalloc((void **)&pl->d_act_n, nt * sizeof(int32_t)));
+            CREATE_TRY(hipMalloc((void **)&pl->d_esum_oct, nt * (size_t)pl->n_groups));
+            pl->act_dirty = true;
         }
     } else
     for (auto &b : pl->bufs) {
@@ -1387,26 +1388,7 @@ int jtp_set_evidence(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *var_
         // sets observes a variable on that clique's element bits (JtTask::esum_groups; bit b stands for the groups g = b mod 64)
         const int iset = pl->set0 + batch;                       // the set's place in the allocation (group 0: evidence-free sets)
         std::copy(ev.begin(), ev.end(), pl->ev_host.begin() + (size_t)iset * pl->ev_stride);
-        if (pl->set0) {
-            // which collect tasks of this set's group meet no evidence below them: skipped, group 0's message stands for theirs
-            const int g = iset / JT_MSETS;
-            std::vector<char> below(hp.pn.size(), 0);
-            for (int s = g * JT_MSETS; s < (g + 1) * JT_MSETS; ++s)
-                for (size_t p = 0; p < hp.pn.size(); ++p)
-                    if (pl->ev_host[(size_t)s * pl->ev_stride + 2 * p] != 0) below[p] = 1;
-            std::vector<int> order(hp.pn.size());
-            for (size_t p = 0; p < hp.pn.size(); ++p) order[p] = (int)p;
-            std::sort(order.begin(), order.end(), [&](int a, int b) { return hp.pn[a].depth > hp.pn[b].depth; });
-            for (int p : order)
-                if (below[p] && hp.pn[p].parent >= 0) below[hp.pn[p].parent] = 1;
-            for (size_t p = 0; p < hp.pn.size(); ++p)
-                if (hp.pn[p].collect_task >= 0) {
-                    uint8_t &sk = pl->skip_host[(size_t)g * hp.tasks.size() + hp.pn[p].collect_task];
-                    const uint8_t want = below[p] ? 0 : 1;
-                    if (sk != want) sk = want, pl->skip_dirty = true;
-                    if (hp.ps[hp.pn[p].psep].up_red_task >= 0) pl->skip_host[(size_t)g * hp.tasks.size() + hp.ps[hp.pn[p].psep].up_red_task] = want;
-                }
-        }
+        if (pl->set0) pl->act_dirty = true;                       // (the tasks' active lists follow the evidence: rebuilt by the next propagate)
         const uint32_t emask = (1u << hp.EB) - 1u;
         const int bit = (iset / JT_MSETS) & 63;
         std::vector<char> on_e(hp.pn.size(), 0);
@@ -1436,6 +1418,104 @@ static int multiset_lds(const HostPlan &hp, const Launch &L) {
     int lds = 0;
     for (int t : L.tasks) lds = std::max(lds, hp.tasks[t].kind == 0 ? hp.tasks[t].lds_bytes : 0);
     return lds;
+}
+
+// Multi-set plans with an evidence-free set (round 6): which evidence sets every task serves.  The upward message of a clique below
+// which a set observes NOTHING is the evidence-free one, whatever the set observes elsewhere; with 16 observations per set on the
+// width-20 tree that is four collect tasks in five, per SET - round 5 skipped a task only where all eight sets of a fixed group
+// agreed, one in three.  So the sets of a workgroup are no longer "group g" but entries 8 g .. 8 g + 7 of the TASK's list:
+//   collect task of clique c (and its reduce task): arena slot 0 - the evidence-free set - and every caller's set with an observed
+//     variable in the subtree below c;
+//   downward task: every caller's slot (and the padding slots behind them, which exist: the last group as before).
+// A consumer stages an upward message of slot s from s's own arena where s is on the producer's list, from slot 0 where it is not
+// (JtFlow::skip = member); the copy pass behind the propagate (jt_multi_fanout) then gives every other caller's set its copy -
+// values in this propagate's half, markers in the other, and the markers of the partial copies a reduce task would sum.
+static int rebuild_active(jtp_plan *pl, hipStream_t s) {
+    const HostPlan &hp = pl->hp;
+    const int cap = pl->n_groups * JT_MSETS, set0 = pl->set0, S = hp.n_batch;
+    const size_t nt = hp.tasks.size(), np = hp.pn.size();
+    pl->member_host.assign(nt * cap, 0);
+    pl->act_ids_host.assign(nt * cap, 0);
+    pl->act_n_host.assign(nt, 0);
+    pl->esum_oct_host.assign(nt * (size_t)pl->n_groups, 0);
+    // below[slot * np + p]: the set in that slot observes a variable hosted by clique p or by a clique below it
+    std::vector<uint8_t> below((size_t)cap * np, 0);
+    std::vector<int> order(np);
+    for (size_t p = 0; p < np; ++p) order[p] = (int)p;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return hp.pn[a].depth > hp.pn[b].depth; });
+    for (int slot = set0; slot < set0 + S; ++slot) {
+        uint8_t *bl = &below[(size_t)slot * np];
+        const uint32_t *ev = &pl->ev_host[(size_t)slot * pl->ev_stride];
+        for (size_t p = 0; p < np; ++p) bl[p] = ev[2 * p] != 0;
+        for (int p : order)
+            if (bl[p] && hp.pn[p].parent >= 0) bl[hp.pn[p].parent] = 1;
+    }
+    auto put = [&](int t, const std::vector<uint16_t> &list) {
+        if (t < 0) return;
+        pl->act_n_host[t] = (int32_t)list.size();
+        for (size_t j = 0; j < list.size(); ++j) {
+            pl->act_ids_host[(size_t)t * cap + j] = list[j];
+            pl->member_host[(size_t)t * cap + list[j]] = 1;
+        }
+    };
+    std::vector<uint16_t> everyone;
+    for (int slot = set0; slot < cap; ++slot) everyone.push_back((uint16_t)slot);
+    std::vector<JtFanout> fan;
+    auto fan_out = [&](int64_t off, int64_t count, int flags, const std::vector<uint16_t> &slots) {
+        for (size_t i = 0; i < slots.size(); i += JT_MSETS) {
+            JtFanout f;
+            memset(&f, 0, sizeof f);
+            f.off = off, f.count = (int32_t)count, f.flags = flags;
+            for (int j = 0; j < JT_MSETS; ++j) f.slot[j] = i + j < slots.size() ? slots[i + j] : (uint16_t)0xffffu;
+            fan.push_back(f);
+        }
+    };
+    for (size_t p = 0; p < np; ++p) {
+        const PNode &pn = hp.pn[p];
+        if (pn.collect_task >= 0) {
+            std::vector<uint16_t> list(1, (uint16_t)0), rest;
+            for (int slot = set0; slot < set0 + S; ++slot) (below[(size_t)slot * np + p] ? list : rest).push_back((uint16_t)slot);
+            put(pn.collect_task, list);
+            const PSep &sp = hp.ps[pn.psep];
+            put(sp.up_red_task, list);
+            if (!rest.empty()) {
+                fan_out(sp.up_roff, ((int64_t)sp.up_rnpart) << sp.nbits, 0, rest);
+                if (sp.up_red_task >= 0) fan_out(sp.up_off, ((int64_t)sp.up_npart) << sp.nbits, JT_FANOUT_MARK_ONLY, rest);
+            }
+        }
+    }
+    for (const PSep &sp : hp.ps) {
+        put(sp.dn_task, everyone);
+        put(sp.dn_red_task, everyone);
+    }
+    const uint32_t emask = (1u << hp.EB) - 1u;
+    for (size_t t = 0; t < nt; ++t) {
+        const JtTask &tk = hp.tasks[t];
+        if (tk.kind != 0 || !(tk.esum & 1)) continue;
+        const int n = pl->act_n_host[t];
+        for (int g = 0; g * JT_MSETS < n; ++g) {
+            bool free_e = true;
+            for (int j = g * JT_MSETS; j < std::min(n, (g + 1) * JT_MSETS); ++j)
+                if (pl->ev_host[(size_t)pl->act_ids_host[t * cap + j] * pl->ev_stride + 2 * tk.pnode] & emask) free_e = false;
+            pl->esum_oct_host[t * (size_t)pl->n_groups + g] = (free_e || hp.knobs.esum_always) ? 1 : 0;
+        }
+    }
+    if ((int)fan.size() > pl->cap_fanout) {
+        if (pl->d_fanout) HIP_TRY(hipFree(pl->d_fanout));
+        pl->d_fanout = nullptr;
+        pl->cap_fanout = 0;
+        HIP_TRY(hipMalloc((void **)&pl->d_fanout, fan.size() * sizeof(JtFanout)));
+        pl->cap_fanout = (int)fan.size();
+    }
+    HIP_TRY(hipMemcpyAsync(pl->d_member, pl->member_host.data(), pl->member_host.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(pl->d_act_ids, pl->act_ids_host.data(), pl->act_ids_host.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(pl->d_act_n, pl->act_n_host.data(), pl->act_n_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(pl->d_esum_oct, pl->esum_oct_host.data(), pl->esum_oct_host.size(), hipMemcpyHostToDevice, s));
+    if (!fan.empty()) HIP_TRY(hipMemcpyAsync(pl->d_fanout, fan.data(), fan.size() * sizeof(JtFanout), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                    // (the sources are host vectors)
+    pl->n_fanout = (int)fan.size();
+    pl->act_dirty = false;
+    return JTP_OK;
 }
 
 int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
@@ -1475,34 +1555,14 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
         fl.set_stride = pl->set_stride;
         fl.ev_stride = pl->ev_stride;
         fl.sync_stride = (uint32_t)hp.sync_words;
-        if (pl->skip_dirty) {
-            std::vector<JtFanout> list;
-            for (int g = 1; g < pl->n_groups; ++g)
-                for (const PNode &p : hp.pn)
-                    if (p.collect_task >= 0 && pl->skip_host[(size_t)g * hp.tasks.size() + p.collect_task]) {
-                        const PSep &sp = hp.ps[p.psep];
-                        list.push_back({sp.up_roff, (int32_t)(((int64_t)sp.up_rnpart) << sp.nbits), g});
-                        // Where a reduce task sums the producer's partial copies, the copies are entries of their own (up_off, not
-                        // up_roff): a skipped producer leaves them alone, so the values of the last propagate that DID run it would
-                        // still stand in the other half when the task runs again two propagates later, and its reduce task - which
-                        // takes "no marker" for "written" - would sum them.  Re-arm them like the producer's flush would have.
-                        if (sp.up_red_task >= 0)
-                            list.push_back({sp.up_off, (int32_t)(((int64_t)sp.up_npart) << sp.nbits), g | JT_FANOUT_MARK_ONLY});
-                    }
-            if ((int)list.size() > pl->cap_fanout) {
-                if (pl->d_fanout) HIP_TRY(hipFree(pl->d_fanout));
-                pl->d_fanout = nullptr;
-                pl->cap_fanout = 0;
-                HIP_TRY(hipMalloc((void **)&pl->d_fanout, list.size() * sizeof(JtFanout)));
-                pl->cap_fanout = (int)list.size();
-            }
-            HIP_TRY(hipMemcpyAsync(pl->d_skip, pl->skip_host.data(), pl->skip_host.size(), hipMemcpyHostToDevice, s));
-            if (!list.empty()) HIP_TRY(hipMemcpyAsync(pl->d_fanout, list.data(), list.size() * sizeof(JtFanout), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));                    // (the sources are host vectors)
-            pl->n_fanout = (int)list.size();
-            pl->skip_dirty = false;
+        if (pl->act_dirty) {
+            if (int rc2 = rebuild_active(pl, s)) return rc2;
         }
-        fl.skip = pl->d_skip;
+        fl.skip = pl->d_member;
+        fl.act_ids = pl->d_act_ids;
+        fl.act_n = pl->d_act_n;
+        fl.esum_oct = pl->d_esum_oct;
+        fl.cap = (uint32_t)(pl->n_groups * JT_MSETS);
         fl.n_tasks = (uint32_t)hp.tasks.size();
         if (pl->esum_dirty) {
             // which groups may sum a vector's elements first on which task (jtp_set_evidence): the fields of ALL tasks in one
@@ -2128,8 +2188,7 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
             for (int t : L.tasks) {
                 const PNode &p = hp.pn[hp.tasks[t].pnode];
                 const double table = hp.tasks[t].kind == 0 && p.real >= 0 ? (double)hp.pack[p.real].host_elems * pl->esize : 0.0;
-                for (int g = 0; g < pl->n_groups; ++g)
-                    if (pl->skip_host.empty() || !pl->skip_host[(size_t)g * hp.tasks.size() + t]) tb += table;
+                tb += table * (pl->act_n_host.empty() ? pl->n_groups : (pl->act_n_host[t] + JT_MSETS - 1) / JT_MSETS);
             }
         }
         st->algorithmic_bytes = tb + hp.alg_msg_bytes * hp.n_batch;
@@ -2169,10 +2228,11 @@ int jtp_get_stats(jtp_plan *pl, jtp_stats *st) {
                 for (int k = 0; k < tk.n_in; ++k) edep = edep || tk.msg[k].e_dep != 0;
                 const double nin1 = std::max(tk.n_in - 1, 0);
                 const double rows = (double)JT_THREADS * (double)tk.total * (double)(1u << tk.nF);
-                for (int g = 0; g < pl->n_groups; ++g) {
+                const int runs = pl->act_n_host.empty() ? pl->n_groups : (pl->act_n_host[t] + JT_MSETS - 1) / JT_MSETS;
+                for (int g = 0; g < runs; ++g) {
                     double per, ins;
-                    if (!pl->skip_host.empty() && pl->skip_host[(size_t)g * hp.tasks.size() + t]) continue;      // (copies, computes nothing)
-                    if ((tk.esum & 1) && ((tk.esum_groups >> (g & 63)) & 1ull) && tk.setb <= JT_SETB_SMALL)
+                    const bool sum_first = pl->act_n_host.empty() ? ((tk.esum_groups >> (g & 63)) & 1ull) != 0 : pl->esum_oct_host[(size_t)t * pl->n_groups + g] != 0;
+                    if ((tk.esum & 1) && sum_first && tk.setb <= JT_SETB_SMALL)
                         per = (VEC - 1) + JT_MSETS * (nin1 + 2.0), ins = (VEC - 1) + JT_MSETS * (nin1 + 1.0);
                     else if (!edep) per = JT_MSETS * (nin1 + 2.0 * VEC), ins = JT_MSETS * (nin1 + VEC);
                     else per = JT_MSETS * VEC * (tk.n_in + 2.0), ins = JT_MSETS * VEC * (tk.n_in + 1.0);

@@ -51,6 +51,11 @@
 // are marked in the tables with JT_NO_ROW.
 #define JT_NO_ROW 0xFFFFFFFFu
 #define JT_BLOCK_KEEP_ROWS 2u  // JtBlock::flags: JtTask::keep_rows
+#define JT_BLOCK_LEAN 4u       // JtBlock::flags: the task has a JtLean record, at int offset first_x[6] | first_x[7] << 32 of the table buffer (a unit task
+                               // loads no rows: first_x is otherwise unused; first_x[5] = JtTask::pnode) - a dataflow workgroup reaches it without
+                               // reading the task record
+#define JT_BLOCK_NULL 8u       // JtBlock::flags: no workgroup - multi-set plans pad every launch's block list to a multiple of eight records, so
+                               // that the eight records a run of workgroups shares (jt_multi_flow) never span two tree levels
 #define JT_BLOCK_INVALID 1u    // JtBlock::flags: the chunk's own digits do not exist - every row is the zero row (the
                                // workgroup still writes its - all zero - partial copy and padded message entries)
 // Multi-set plans (JTP_MULTISET): evidence sets that share ONE copy of the clique tables are processed
@@ -212,7 +217,18 @@ struct JtFlow {
     // the message into the sets' own arenas for the read-out (null: every group computes everything)
     const uint8_t *skip;
     uint32_t n_tasks;
-    uint32_t pad_flow;
+    uint32_t cap;              // multi-set launches with active lists: arena slots in all (groups x JT_MSETS)
+    // Active lists (round 6): WHICH evidence sets a multi-set workgroup serves is per task, not fixed.  Of the collect task of a clique
+    // only the sets that observe something below it need the pass (one set in five on the width-20 tree with 16 observations per
+    // set; per GROUP of eight sets, round 5's granularity, two in three): act_ids[task * cap + j], j < act_n[task], lists their
+    // arena slots - slot 0, the evidence-free set, first - and the workgroups of "group" g of the launch serve entries 8 g .. 8 g + 7
+    // of that list (none: they end at once).  skip[task * cap + slot] != 0 = the slot is on the task's list: a consumer takes
+    // the upward message of every other slot from slot 0.  Downward tasks list every caller's slot.  Null: the sets of group g
+    // are slots 8 g .. 8 g + 7 for every task.
+    const uint16_t *act_ids;
+    const int32_t *act_n;
+    const uint8_t *esum_oct;   // [task * n_groups + g] != 0: no set among entries 8 g .. 8 g + 7 of the task's list observes a variable on
+                               // the element bits of its clique (what JtTask::esum_groups says for fixed groups)
     int64_t fix_shift;         // static tables (JtMsg::fixed): offset (doubles) of the plan's fixed arena from the base of THIS
                                // propagate's half of the message arena (the consumer adds it to the message's offset)
 };

@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
 // quarter of the copies - set w, then set w + 4 - and every wave stores its own sums.
 template <bool FLOW, bool MULTI = false>
 __device__ __forceinline__ void jt_reduce(const JtTask &tk, const JtBlock &bk, double *__restrict__ msg_arena,
-                                          const JtFlow &fl) {
+                                          const JtFlow &fl, const int sidv = 0) {
     __shared__ double red_part[4][JT_REDUCE_ENTRIES];
     __shared__ uint32_t red_abort;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void jt_reduce(const JtTask &tk, const JtBlock &bk, d
     const int npart = src.npart;
     if constexpr (MULTI) {
         for (int set = wave; set < JT_MSETS; set += 4) {
-            double *arena = msg_arena + (int64_t)set * fl.set_stride;
+            double *arena = msg_arena + (int64_t)__builtin_amdgcn_readlane(sidv, set) * fl.set_stride;      // (MULTI: jt_mpass, `sidv`)
             const double *copies = arena + fl.cur_off + src.off + (active ? i : 0);
             double sum = 0.0;
             uint64_t t0 = 0;
@@ -1586,6 +1586,19 @@ __device__ __forceinline__ void jt_unit_lean_dispatch(const JtLean &ln, const Jt
 #undef JT_LEAN
 }
 
+// A dataflow workgroup whose record says "lean" (JT_BLOCK_LEAN) goes from its workgroup record straight to the task's lean record:
+// one dependent scalar round trip less than through the task record.  (A clique that hosts an observed variable runs the generic pass;
+// first_x[5] = the task's planner node, the index of its entry of the evidence table.)
+template <typename T>
+__device__ __forceinline__ bool jt_lean_block(const JtBlock &bk, const int *__restrict__ itab, double *__restrict__ msg, const JtFlow &fl,
+                                              uint32_t *flow_ctl) {
+    if (!(bk.flags & JT_BLOCK_LEAN)) return false;
+    if (fl.ev != nullptr && fl.ev[2 * bk.first_x[5]] != 0) return false;      // (this clique hosts an observed variable: the generic pass)
+    const int64_t at = (int64_t)((uint64_t)bk.first_x[6] | ((uint64_t)bk.first_x[7] << 32));
+    jt_unit_lean_dispatch<T, true>(*reinterpret_cast<const JtLean *>(itab + at), bk, itab, msg, fl, flow_ctl);
+    return true;
+}
+
 // Unit tasks (JtTask::unit): their shapes differ from the table-keeping tasks' - the static table is one more incoming one
 // (collect: up to three children, or the static table and two; distribute: the parent's message and / or the static table, then
 // up to three children) - so they are dispatched here, by every kernel that may meet one.
@@ -1596,9 +1609,9 @@ __device__ __forceinline__ void jt_unit_collect(const JtTask &tk, const JtBlock 
                                                 T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                 uint32_t *flow_ctl, uint64_t t_entry) {
     if constexpr (!TMIX) {
-        // (round 6) a task of one outgoing message and single-copy inputs, run for an evidence set that observes nothing - the engine
-        // passes no evidence table then: the lean pass
-        if (tk.lean_off > 0 && fl.ev == nullptr) {
+        // (round 6) a task of one outgoing message and single-copy inputs on a clique that hosts no observed variable of this
+        // evidence set (the engine passes no table at all when nothing is observed): the lean pass
+        if (tk.lean_off > 0 && (fl.ev == nullptr || fl.ev[2 * tk.pnode] == 0)) {
             jt_unit_lean_dispatch<T, FLOW>(*reinterpret_cast<const JtLean *>(itab + tk.lean_off), bk, itab, msg, fl, flow_ctl);
             return;
         }
@@ -1737,6 +1750,7 @@ __global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_collect_flow(con
     const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
+    if (jt_lean_block<T>(bk, itab, msg, fl, flow_ctl)) return;
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
         jt_reduce<true>(tk, bk, msg, fl);
@@ -1761,6 +1775,7 @@ __device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict
     const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
+    if (jt_lean_block<T>(bk, itab, msg, fl, flow_ctl)) return;
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
         jt_reduce<true>(tk, bk, msg, fl);
@@ -1797,6 +1812,7 @@ __global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_propagate_flow(c
     const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
+    if (jt_lean_block<T>(bk, itab, msg, fl, flow_ctl)) return;
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
         jt_reduce<true>(tk, bk, msg, fl);
@@ -1873,10 +1889,12 @@ __global__ __launch_bounds__(JT_THREADS, JT_CHAIN_WAVES) void jt_distribute_flow
 // Evidence: the part of a set's (mask, value) that lies in the ROW bits (chunk + loop bits) is uniform per
 // row - a row that contradicts it is skipped for that set; the part in the thread bits (16-byte vector, lane,
 // wave) is constant over the loop, so it is applied to the register sums in the epilogue, not per element.
+// `sidv` (round 6): lane j < G holds the ARENA SLOT of the j-th evidence set this workgroup serves - entries 8 g .. 8 g + 7 of the
+// task's active list (JtFlow::act_ids), or simply 8 g + j; `msg0` is the base of ALL the sets' arenas.
 template <typename T, int NIN, int SETB, bool ESUM = false>
 __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab,
                                          const T *__restrict__ psi_arena, double *__restrict__ msg0,
-                                         const JtFlow &fl, uint32_t *flow_ctl, uint32_t bindex, const double *__restrict__ msg_ef = nullptr) {
+                                         const JtFlow &fl, uint32_t *flow_ctl, uint32_t bindex, const int sidv) {
     constexpr int G = JT_MSETS;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int EB = (VEC == 4) ? 2 : 1;
@@ -1894,6 +1912,9 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     const int total = tk.total;
     const int rmask = (1 << tk.nR) - 1;
     const int64_t sstride = fl.set_stride;
+    int64_t soff[G];                                             // (uniform) where the arena of the s-th set of this workgroup starts
+#pragma unroll
+    for (int s = 0; s < G; ++s) soff[s] = (int64_t)__builtin_amdgcn_readlane(sidv, s) * sstride;
 #ifdef JT_STAMPS
     const int dbg = (fl.dbg & 0x80000000u) ? (tk.debug & ~2) : tk.debug;                      // (time stamps of group 0 only)
     double *stamp_out = msg0 + tk.dbg_off + (int64_t)(fl.blk_base + bindex) * JT_NSTAMP;      // (as in jt_pass)
@@ -1926,13 +1947,12 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
     // live across the loop made hipcc spill scalars into it)
     uint32_t ev_m = 0, ev_v = 0;
     if (fl.ev != nullptr && lane < G) {
-        ev_m = fl.ev[(size_t)lane * fl.ev_stride + 2 * tk.pnode];
-        ev_v = fl.ev[(size_t)lane * fl.ev_stride + 2 * tk.pnode + 1];
+        ev_m = fl.ev[(size_t)sidv * fl.ev_stride + 2 * tk.pnode];
+        ev_v = fl.ev[(size_t)sidv * fl.ev_stride + 2 * tk.pnode + 1];
     }
     // ---- stage the incoming sub-boxes of every set (one thread per entry, partial copies summed in copy
     //      order), zero the outgoing ones; wait for entries still marked unwritten (dataflow launches)
     const double *msg_cur = msg0 + fl.cur_off;
-    const double *ef_cur = msg_ef != nullptr ? msg_ef + fl.cur_off : msg_cur;       // the evidence-free group's arena (group 0)
     char *sets = smem + JT_RING_BYTES;                       // region of set s: sets + s * SETB
     const JtMsg &mo = tk.msg[JT_MAX_IN];
     uint64_t wait_t0 = 0;
@@ -1947,14 +1967,20 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
             const uint32_t fp[4] = {fpw[0], fpw[1], fpw[2], fpw[3]};
             const bool thr_mem = m.same_launch != 0;
             const int n = 1 << nfree;
-            // (an upward message whose producer met no evidence in this group: the evidence-free group's copy, fl.skip = this group's row)
-            const double *mbase = (fl.skip != nullptr && m.src_task >= 0 && fl.skip[m.src_task]) ? ef_cur : msg_cur;
+            // (an upward message whose producer did not run for one of the sets - nothing observed below it: that set's entries are the
+            //  evidence-free set's, arena slot 0; bit s of `own` = the producer's list holds the s-th set of this workgroup)
+            uint32_t own = 0xffu;
+            if (fl.skip != nullptr && m.src_task >= 0)
+                own = (uint32_t)__ballot(lane < G && fl.skip[(size_t)m.src_task * fl.cap + (uint32_t)sidv] != 0);
+            int64_t from[G];
+#pragma unroll
+            for (int s = 0; s < G; ++s) from[s] = ((own >> s) & 1u) ? soff[s] : (int64_t)0;
             for (int i = tid; i < n; i += JT_THREADS) {
                 int idx = 0;
 #pragma unroll
                 for (int b = 0; b < JT_MAX_FREE; ++b)
                     if (b < nfree) idx += ((i >> b) & 1) << JT_FPOS(fp, b);
-                const double *src = mbase + m.off + bk.gbase[k] + idx;
+                const double *src = msg_cur + m.off + bk.gbase[k] + idx;
                 double sum[G];
 #pragma unroll
                 for (int s = 0; s < G; ++s) sum[s] = 0.0;
@@ -1964,13 +1990,13 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
                     for (int s = 0; s < G; ++s)
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            c[s][u] = (p + u < m.npart) ? jt_msg_load<FLOW>(src + (int64_t)s * sstride + (int64_t)(p + u) * m.pstride, thr_mem) : 0.0;
+                            c[s][u] = (p + u < m.npart) ? jt_msg_load<FLOW>(src + from[s] + (int64_t)(p + u) * m.pstride, thr_mem) : 0.0;
 #pragma unroll
                     for (int s = 0; s < G; ++s)
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             sum[s] += c[s][u];
-                            if (jt_unwritten(c[s][u])) unready = src + (int64_t)s * sstride + (int64_t)(p + u) * m.pstride;
+                            if (jt_unwritten(c[s][u])) unready = src + from[s] + (int64_t)(p + u) * m.pstride;
                         }
                 }
 #pragma unroll
@@ -2324,7 +2350,7 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
                 if (b < o_nfree) idx += ((i >> b) & 1) << JT_FPOS(ofp, b);
 #pragma unroll
             for (int s = 0; s < G; ++s) {
-                double *base = msg0 + (int64_t)s * sstride + o_at + idx;
+                double *base = msg0 + soff[s] + o_at + idx;
                 jt_msg_store<FLOW>(base + fl.cur_off, reinterpret_cast<const double *>(sets + s * SETB + o_lds)[i]);
                 if (mark) base[fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
             }
@@ -2349,26 +2375,28 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
 struct JtFanout {
     int64_t off;               // msg-arena offset (doubles) of what consumers read of the message (the reduced sum where there is one)
     int32_t count;             // doubles
-    int32_t group;             // the group whose sets receive it; | JT_FANOUT_MARK_ONLY: nothing is copied, the entries of the OTHER
-                               // arena half are marked "unwritten" (the partial copies a skipped producer would have re-armed)
+    int32_t flags;             // JT_FANOUT_MARK_ONLY: nothing is copied, the entries of the OTHER arena half are marked "unwritten" (the
+                               // partial copies a producer that did not run would have re-armed)
+    uint16_t slot[JT_MSETS];   // the arena slots that receive it (0xffff: none)
 };
 #ifndef JT_INST_TU
 __global__ __launch_bounds__(256) void jt_multi_fanout(const JtFanout *__restrict__ list, double *__restrict__ msg, JtFlow fl) {
     const JtFanout f = list[blockIdx.x];
-    const double *src = msg + fl.cur_off + f.off;                                  // (group 0, set 0)
-    double *dst0 = msg + (int64_t)(f.group & ~JT_FANOUT_MARK_ONLY) * JT_MSETS * fl.set_stride + f.off;
-    if (f.group & JT_FANOUT_MARK_ONLY) {
+    const double *src = msg + fl.cur_off + f.off;                                  // (arena slot 0: the evidence-free set)
+    if (f.flags & JT_FANOUT_MARK_ONLY) {
         if (fl.oth_off < 0) return;
         for (int i = threadIdx.x; i < f.count; i += 256)
 #pragma unroll
-            for (int s = 0; s < JT_MSETS; ++s) dst0[(int64_t)s * fl.set_stride + i + fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
+            for (int s = 0; s < JT_MSETS; ++s)
+                if (f.slot[s] != 0xffffu) msg[(int64_t)f.slot[s] * fl.set_stride + f.off + i + fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
         return;
     }
     for (int i = threadIdx.x; i < f.count; i += 256) {
         const double v = src[i];
 #pragma unroll
         for (int s = 0; s < JT_MSETS; ++s) {
-            double *base = dst0 + (int64_t)s * fl.set_stride + i;
+            if (f.slot[s] == 0xffffu) continue;
+            double *base = msg + (int64_t)f.slot[s] * fl.set_stride + f.off + i;
             base[fl.cur_off] = v;
             if (fl.oth_off >= 0) base[fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
         }
@@ -2398,38 +2426,46 @@ __global__ __launch_bounds__(JT_THREADS, JT_MULTI_WAVES) void jt_multi_flow(cons
     if (rec >= fl.n_blocks) return;
     if (grp != 0) fl.dbg |= 0x80000000u;                     // (diagnostic builds: group 0 writes the time stamps)
     fl.sync += (size_t)grp * fl.sync_stride;
-    if (fl.ev != nullptr) fl.ev += (size_t)grp * JT_MSETS * fl.ev_stride;
-    double *msg0 = msg + (int64_t)grp * JT_MSETS * fl.set_stride;
+    double *msg0 = msg;                                      // (the sets' arenas: slot x set_stride doubles from here)
     const uint32_t ticket = fl.ticket_idx == 0xffffffffu ? rec : jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
+    if (bk.flags & JT_BLOCK_NULL) return;                    // (padding of a level's records to a multiple of eight)
     const JtTask &tk = tasks[bk.task];
-    // (nothing observed below this clique in this group: its upward message is group 0's - nothing to do, reduce task included)
-    if (fl.skip != nullptr && fl.skip[(size_t)grp * fl.n_tasks + bk.task]) return;
-    fl.skip = fl.skip != nullptr ? fl.skip + (size_t)grp * fl.n_tasks : nullptr;          // (this group's row, for the consumers below)
+    // Which evidence sets: entries 8 g .. 8 g + 7 of the task's active list (a shorter last run repeats its last entry: the same
+    // values are then stored twice), or - without lists - arena slots 8 g .. 8 g + 7.  Nothing on the list for this group: done.
+    int sidv = (int)(grp * 8u + (threadIdx.x & 7u));
+    bool esum_ok = ((tk.esum_groups >> (grp & 63u)) & 1ull) != 0;
+    if (fl.act_n != nullptr) {
+        const int n_act = fl.act_n[bk.task];
+        if ((int)(grp * 8u) >= n_act) return;
+        const int j = (int)(grp * 8u + (threadIdx.x & 7u));
+        sidv = (int)fl.act_ids[(size_t)bk.task * fl.cap + (uint32_t)(j < n_act ? j : n_act - 1)];
+        esum_ok = fl.esum_oct[(size_t)bk.task * fl.n_groups + grp] != 0;
+    }
     if (tk.kind != 0) {
-        jt_reduce<true, true>(tk, bk, msg0, fl);
+        jt_reduce<true, true>(tk, bk, msg0, fl, sidv);
         return;
     }
-    if (tk.setb <= JT_SETB_SMALL && (tk.esum & 1) && ((tk.esum_groups >> (grp & 63u)) & 1ull)) {
+    if (tk.setb <= JT_SETB_SMALL && (tk.esum & 1) && esum_ok) {
         switch (tk.n_in) {
-            case 0: jt_mpass<T, 0, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            case 1: jt_mpass<T, 1, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            case 2: jt_mpass<T, 2, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            default: jt_mpass<T, 3, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 0: jt_mpass<T, 0, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            case 1: jt_mpass<T, 1, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            case 2: jt_mpass<T, 2, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            default: jt_mpass<T, 3, JT_SETB_SMALL, true>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
         }
     } else if (tk.setb <= JT_SETB_SMALL) {
         switch (tk.n_in) {
-            case 0: jt_mpass<T, 0, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            case 1: jt_mpass<T, 1, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            case 2: jt_mpass<T, 2, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            default: jt_mpass<T, 3, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 0: jt_mpass<T, 0, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            case 1: jt_mpass<T, 1, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            case 2: jt_mpass<T, 2, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            default: jt_mpass<T, 3, JT_SETB_SMALL>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
         }
     } else {
         switch (tk.n_in) {
-            case 0: jt_mpass<T, 0, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            case 1: jt_mpass<T, 1, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            case 2: jt_mpass<T, 2, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
-            default: jt_mpass<T, 3, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, msg); break;
+            case 0: jt_mpass<T, 0, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            case 1: jt_mpass<T, 1, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            case 2: jt_mpass<T, 2, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
+            default: jt_mpass<T, 3, JT_SETB_LARGE>(tk, bk, itab, psi, msg0, fl, flow_ctl, ticket, sidv); break;
         }
     }
 }

@@ -2139,6 +2139,21 @@ int PlanBuilder::schedule() {
         op.count = ((int64_t)1 << s.nbits) * (up ? s.up_rnpart : s.dn_rnpart);
         pending.push_back(op);
     };
+    // Multi-set plans: a launch's block list is padded to a multiple of eight records with records that start no work
+    // (JT_BLOCK_NULL).  jt_multi_flow hands runs of eight records to the groups of evidence sets in turn; with active lists (round 6) a
+    // workgroup of one group waits for entries another group's workgroup writes, and with every launch - every tree level -
+    // starting on a multiple of eight, that producer has the lower blockIdx whatever its group.
+    auto pad_launch = [&](const Launch &L) {
+        if (!hp.multiset) return;
+        while ((hp.blocks.size() - (size_t)L.blk_off) % 8) {
+            JtBlock nb;
+            memset(&nb, 0, sizeof nb);
+            nb.task = L.tasks.empty() ? 0u : (uint32_t)L.tasks[0];
+            nb.flags = JT_BLOCK_NULL;
+            hp.blocks.push_back(nb);
+            hp.block_chunk.push_back(0xffffffffu);
+        }
+    };
     auto by_level = [&](int level) {
         std::vector<int> v;
         for (int c = 0; c < NP; ++c) if (hp.pn[c].depth == level) v.push_back(c);
@@ -2199,6 +2214,7 @@ int PlanBuilder::schedule() {
                 for (int k = 0; k < tk.n_in; ++k) hp.staging_bytes += (double)(1u << tk.nF) * (8.0 * (1 << tk.msg[k].nfree)) * tk.msg[k].npart;
                 if (!tk.unit) hp.table_bytes += (double)hp.pn[tk.pnode].phys_elems * esize * (phase == 1 && !hp.multiset ? 2 : 1);
             }
+            pad_launch(L);
             L.nblocks = (int)(hp.blocks.size() - L.blk_off);
             hp.max_lds = std::max(hp.max_lds, L.lds_bytes);
             hp.alg_bytes += L.alg_bytes;
@@ -2235,6 +2251,7 @@ int PlanBuilder::schedule() {
                 hp.blocks.push_back(jtp_make_block(hp, hp.tasks[t], (uint32_t)t, f));
                 hp.block_chunk.push_back(f);
             }
+        pad_launch(L);
         L.nblocks = (int)(hp.blocks.size() - L.blk_off);
         Step st;
         st.kind = 0;
@@ -2379,6 +2396,10 @@ int PlanBuilder::finish() {
         if (c != hp.root && (hp.owner[c] == hp.rank || (hp.owner[c] == ALL && hp.rank == 0))) hp.n_messages += 2;
     // Lean records (round 6, JtLean): every field of every task is final here
     for (JtTask &tk : hp.tasks) jtp_make_lean(hp, tk, hp.itab);
+    for (JtBlock &b : hp.blocks) {
+        const int64_t at = hp.tasks[b.task].lean_off;
+        if (at > 0) b.flags |= JT_BLOCK_LEAN, b.first_x[5] = (uint32_t)hp.tasks[b.task].pnode, b.first_x[6] = (uint32_t)at, b.first_x[7] = (uint32_t)((uint64_t)at >> 32);
+    }
     return JTP_OK;
 }
 
@@ -2709,7 +2730,12 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
                 if (k) o << ",";
                 json_msg(o, tk.msg[JT_MAX_IN + k], tk.nF);
             }
-            o << "]}";
+            o << "]";
+            if (tk.lean_off > 0 && (size_t)tk.lean_off + sizeof(JtLean) / 4 <= hp.itab.size()) {      // (the record as the kernel reads it)
+                o << ",\"lean\":";
+                json_list(o, hp.itab.begin() + tk.lean_off, hp.itab.begin() + tk.lean_off + sizeof(JtLean) / 4);
+            }
+            o << "}";
         }
         o << "],\"blocks\":[";
         for (size_t b = 0; b < hp.blocks.size(); ++b) {

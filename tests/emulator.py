@@ -197,7 +197,12 @@ class Emulator:
             assert record[20] == lxF and (record[21] & 1) == (0 if chunk_ok else 1)       # (bit 1: JT_BLOCK_KEEP_ROWS, a cache-policy hint)
             if chunk_ok:
                 assert record[0] == xF and record[11] == tk["psi_off"] + xF and (not tk.get("unit") or tk["psi_off"] == 0)
-                assert list(record[12:20]) == list(tk["first_x"])
+                if record[21] & 4:        # JT_BLOCK_LEAN (round 6): a unit task loads no rows - the last three words say where its lean record is
+                    assert tk["unit"] and tk["lean_off"] > 0 and tk["lean_off"] % 16 == 0
+                    assert list(record[12:17]) == list(tk["first_x"][:5])
+                    assert record[17] == tk["pnode"] and (record[18] | (record[19] << 32)) == tk["lean_off"]
+                else:
+                    assert not tk.get("lean_off") and list(record[12:20]) == list(tk["first_x"])
             else:
                 assert record[0] == 0 and record[11] == 0 and all(v == NO_ROW for v in record[12:20])
             assert list(record[1:1 + n_in]) == gb_in and list(record[5:5 + n_out]) == gb_out
@@ -394,6 +399,9 @@ class Emulator:
             covered += list(range(seg["first_launch"], seg["first_launch"] + seg["n_launch"]))
             self._launch_snapshot = self.msg.copy()
             for blk in d["blocks"][seg["blk_off"]:seg["blk_off"] + seg["nblocks"]]:
+                if blk[23] & 8:             # (JT_BLOCK_NULL: multi-set plans pad every launch to a multiple of eight records)
+                    assert d.get("multiset")
+                    continue
                 tk = d["tasks"][blk[0]]
                 self._block(tk, blk[1], tk["mode"] == 0, blk[2:], strict=True)
         assert covered == list(range(len(d["launches"])))
@@ -436,6 +444,11 @@ class Emulator:
                 continue
             launch = d["launches"][first]
             blocks = d["blocks"][launch["blk_off"]:launch["blk_off"] + launch["nblocks"]]
+            if d.get("multiset"):            # (padded to a multiple of eight records with records that start no work)
+                assert launch["blk_off"] % 8 == 0 and launch["nblocks"] % 8 == 0 and sum(1 for b in blocks if b[23] & 8) < 8
+                blocks = [b for b in blocks if not (b[23] & 8)]
+            else:
+                assert not any(b[23] & 8 for b in blocks)
             seen = set()
             for blk in blocks:
                 t, chunk = blk[0], blk[1]

@@ -247,3 +247,57 @@ def test_a_tree_pickles_after_use():
     assert again == tree and again._memo == {} and again.cover() == tree.cover()
     import copy
     assert copy.deepcopy(tree) == tree
+
+
+def test_lean_records_say_what_the_task_records_say():
+    """Round 6: a unit task of one outgoing message whose incoming tables have one copy each carries a LEAN record (`JtLean`,
+    `jtp_internal.h`) that `jt_unit_lean` runs from instead of interpreting the task record.  The record is derived data: every field
+    is checked here against the task record the emulator executes - the weights are the bit deposits of `free_pos`, the tables that
+    depend on the element bits come first, the fold mask is the outgoing message's run, the workgroup records point at it."""
+    import struct
+    factors, sizes, _ = synthetic.lattice_mrf(6, 14, 8)
+    tree = jt.create_junction_tree(factors, sizes)
+    node_vars = [list(c) for c in tree.clique_tree.maxcliques] + [list(s) for s in tree.separators]
+    seen = 0
+    for dtype in ("f32", "f64"):
+        plan = engine.Plan(tree.tree, node_vars, sizes, dtype=dtype, plan_only=True, cover=tree.cover())
+        d = plan.describe()
+        for t, tk in enumerate(d["tasks"]):
+            eligible = (tk["kind"] == 0 and tk["unit"] and tk["mode"] == 0 and tk["n_out"] == 1 and tk["n_in"] <= 3 and tk["bel_off"] < 0
+                        and all(m["npart"] == 1 for m in tk["in"]))
+            assert (tk["lean_off"] > 0) == eligible, t
+            if not eligible:
+                assert "lean" not in tk
+                continue
+            seen += 1
+            w = tk["lean"]
+            assert len(w) == 176
+
+            def msg(i):
+                r = w[32 * i:32 * (i + 1)]
+                off = struct.unpack("<q", struct.pack("<2i", r[0], r[1]))[0]
+                return dict(off=off, nfree=r[2], lds_off=r[3], flags=r[4], src=r[5], e_w=r[6:8], w_lo=r[8:16], w_hi=r[16:24], t_w=r[24:32])
+            tail = w[160:]
+            n_in, n_e, total, rmask, red_e, red_lane, red_wave, settle, out_pstride, some_invalid = tail[:10]
+            assert n_in == tk["n_in"] and total == tk["total"] and settle == tk["settle"]
+            assert n_e == sum(1 for m in tk["in"] if m["e_dep"])
+            order = [msg(i)["src"] for i in range(n_in)]
+            assert sorted(order) == list(range(n_in))
+            assert all(tk["in"][s]["e_dep"] for s in order[:n_e]) and not any(tk["in"][s]["e_dep"] for s in order[n_e:])
+            for i in range(n_in + 1):
+                lm = msg(i) if i < n_in else msg(4)
+                m = tk["in"][lm["src"]] if i < n_in else tk["out"][0]
+                assert (lm["off"], lm["nfree"], lm["lds_off"]) == (m["off"], m["nfree"], m["lds_off"])
+                assert lm["flags"] == (1 if m["same_launch"] else 0) | (2 if m["fixed"] else 0)
+                fp = list(m["free_pos"]) + [None] * 16
+                assert lm["w_lo"] == [1 << fp[b] if b < m["nfree"] else 0 for b in range(8)]
+                assert lm["w_hi"] == [1 << fp[8 + b] if 8 + b < m["nfree"] else 0 for b in range(8)]
+                assert lm["t_w"] == list(m["t_w"]) and lm["e_w"] == list(m["e_w"])
+            out = tk["out"][0]
+            assert (red_e, red_lane, red_wave, out_pstride) == (out["red_e"], out["red_lane"], out["red_wave"], out["pstride"])
+            assert rmask == (1 << (tk["out_run"] & 0xff)) - 1 and msg(4)["src"] == 4
+            assert struct.unpack("<q", struct.pack("<2i", tail[10], tail[11]))[0] == tk["tmap_off"]
+            assert tail[14] == (1 if any(row[0] == 0xFFFFFFFF or row[0] == -1 for row in tk["itab"]) else 0)
+        for b in d["blocks"]:
+            assert bool(b[23] & 4) == (d["tasks"][b[0]]["lean_off"] > 0)
+    assert seen > 50
