@@ -17,4 +17,15 @@ from .junctiontree import *  # noqa: F401,F403
 from .junctiontree import __all__ as _jt_all
 
 __all__ = list(_jt_all) + ["computation", "construction", "sum_product", "junctiontree"]
-__version__ = "0.1.0"
+
+
+def __getattr__(name):
+    # `__version__` is the library's (`jtp_version()`: "jtprop <version> (gfx950, ...) src:<id>"), read when asked for: importing the
+    # package must not need the built library
+    if name == "__version__":
+        from . import _capi
+        try:
+            return _capi.lib().jtp_version().decode().split()[1]
+        except Exception:       # noqa: BLE001 - no library in this tree (a source checkout before build())
+            return "0.0.0+unbuilt"
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

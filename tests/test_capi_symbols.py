@@ -44,3 +44,11 @@ def test_plan_only_needs_no_gpu_and_device_plans_fail_loudly_without_one():
     if _capi.device_count() == 0:
         with pytest.raises(_capi.JtpError, match="no CPU fallback"):
             engine.Plan([0, (2, [1])], [[1, 2], [2, 3], [2]], {1: 2, 2: 3, 3: 2})
+
+
+def test_package_version_is_the_librarys():
+    """`junctiontree_amd.__version__` is read from `jtp_version()` (round 6: it said 0.1.0 beside a 0.5.0 library)."""
+    import junctiontree_amd as jt
+    from junctiontree_amd import _capi
+    text = _capi.lib().jtp_version().decode()
+    assert text.startswith("jtprop ") and jt.__version__ == text.split()[1]
