@@ -508,7 +508,7 @@ const char *jtp_last_error(void) { return g_err.c_str(); }
 #ifndef JTP_SOURCE_ID
 #define JTP_SOURCE_ID "unknown"
 #endif
-const char *jtp_version(void) { return "jtprop 0.5.0 (gfx950, HIP, RCCL p2p) src:" JTP_SOURCE_ID; }
+const char *jtp_version(void) { return "jtprop 0.6.0 (gfx950, HIP, RCCL p2p) src:" JTP_SOURCE_ID; }
 
 int jtp_host_alloc(void **ptr, size_t bytes) {
     if (!ptr) return set_err(JTP_EINVAL, "null argument");

@@ -290,7 +290,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
     int64_t sm_off[NI], sm_ps[NI];
     int sm_npart[NI], sm_nfree[NI], sm_lds[NI];
     bool sm_same[NI];
-    uint32_t sm_fp[NI][4];
+    uint32_t sm_fp[NI][4], sm_hiv[NI];
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         const JtMsg &m = tk.msg[k];
@@ -307,6 +307,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
         sm_lds[k] = m.lds_off;
         sm_same[k] = m.same_launch != 0;
         sm_fp[k][0] = fp[0], sm_fp[k][1] = fp[1], sm_fp[k][2] = fp[2], sm_fp[k][3] = fp[3];
+        sm_hiv[k] = jt_sub_hi(fp, m.nfree, lane);
     }
     // ... and what the flush needs.  Collect pass: kept in registers (read after the loop these are one more dependent round
     // trip on the hand-over to the parent: config 2 collect 2.52 -> 2.40 ms).  Distribute pass: the registers they would occupy
@@ -477,6 +478,15 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
             }
             // Sub-boxes of a workgroup's size and more: one thread per entry and round of 256 entries.  Where entry `it` * 256 + tid
             // of message k's sub-box lies in the message (copy pc):
+            // (round 6: the part of the bits above the thread's own eight comes from a 32-row table, row j in lane j - jt_sub_hi, as in
+            //  the flush; the scalar deposit loop this replaces ran for every entry of every message: ~20 scalar instructions each)
+#ifndef JT_STAGE_SCALAR_HI
+            auto entry_at = [&](auto k_tag, int it, int pc) {
+                constexpr int k = decltype(k_tag)::value;
+                const int idx = idx_t[k] + __builtin_amdgcn_readlane((int)sm_hiv[k], it);
+                return src[k] + ((int64_t)pc * ps[k] + idx);
+            };
+#else
             auto entry_at = [&](auto k_tag, int it, int pc) {
                 constexpr int k = decltype(k_tag)::value;
                 int idx = idx_t[k];
@@ -485,6 +495,7 @@ __device__ __forceinline__ void jt_pass(const JtTask &tk, const JtBlock &bk, con
                     if (b < sm_nfree[k]) idx += ((it >> (b - 8)) & 1) << JT_FPOS(sm_fp[k], b);
                 return src[k] + ((int64_t)pc * ps[k] + idx);
             };
+#endif
             // ... single-copy messages first, ALL of them in lock step: the loads of a round - up to eight entries per thread and
             // message (four when there are three messages or more: registers) - leave together, so a task with two or three
             // such messages pays one round trip to memory where it paid one per message (round 5: the unit tasks of config 3 are
