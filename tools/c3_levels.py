@@ -14,7 +14,7 @@ for i in range(H):
 sizes = {v: K for v in names.values()}
 tree = jt.create_junction_tree(factors, sizes)
 node_vars = [list(c) for c in tree.clique_tree.maxcliques] + [list(s) for s in tree.separators]
-plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32")
+plan = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", cover=None if os.environ.get("C3_NO_COVER") else tree.cover())
 plan.fill_synthetic(1, [8.0 ** -(len(c) - 1) for c in tree.clique_tree.maxcliques])
 for _ in range(2):
     plan.propagate()
@@ -29,12 +29,12 @@ widths = collections.Counter(len(c) for c in tree.clique_tree.maxcliques)
 print("clique widths:", dict(widths))
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for x in L:
-    key = (x["phase"], "reduce" if x["variant"] == 16 else ("<=1MB" if x["alg_bytes"] < 1e6 else "<=16MB" if x["alg_bytes"] < 16e6 else "<=64MB" if x["alg_bytes"] < 64e6 else ">64MB"))
+    key = (x["phase"], "reduce" if x["variant"] == 16 else ("<=512 blocks" if x["nblocks"] <= 512 else "<=1024 blocks" if x["nblocks"] <= 1024 else "<=2048 blocks" if x["nblocks"] <= 2048 else ">2048 blocks"))
     a = agg[key]
     a[0] += 1; a[1] += x["ms"]; a[2] += x["alg_bytes"]
 for key in sorted(agg):
     n, ms, b = agg[key]
-    print("phase %d %-8s: %4d launches %8.3f ms (%4.1f %%)  %8.1f MB  %7.0f GB/s  avg %.1f us" % (key[0], key[1], n, ms, 100 * ms / tot, b / 1e6, b / max(ms, 1e-9) / 1e6, ms / n * 1e3))
+    print("phase %d %-14s: %4d launches %8.3f ms (%4.1f %%)  %8.1f MB  %7.0f GB/s  avg %.1f us" % (key[0], key[1], n, ms, 100 * ms / tot, b / 1e6, b / max(ms, 1e-9) / 1e6, ms / n * 1e3))
 big = sorted(L, key=lambda x: -x["ms"])[:8]
 for x in big:
     print("   slowest: phase %d level %d  %5d blocks %3d tasks %.1f MB  %.3f ms  %.0f GB/s" % (x["phase"], x["level"], x["nblocks"], x["ntasks"], x["alg_bytes"] / 1e6, x["ms"], x["alg_bytes"] / x["ms"] / 1e6))

@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): bench lines, rocprofv3 kernel trace + stats, PMC passes for HBM traffic
 # (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, never combined with a trace domain).  Everything lands under
 # gpurun_out/prof/; tools/summarize_profiles.py turns it into gpurun_out/prof/summary/, whose files are committed
-# under profiles/ as r05_* (tools/publish_profiles.py).  Every text file starts with the id of the library build it was measured on (the JSON
+# under profiles/ as r06_* (tools/publish_profiles.py).  Every text file starts with the id of the library build it was measured on (the JSON
 # bench lines carry it in config.library; hbm_traffic*.json in "source_id"): bench.py quotes roofline.traffic only
 # when that id is the running library's.
 #   bash tools/collect_profiles.sh            (needs lib/libjtprop_stamps.so = build.py --out ... -DJT_STAMPS of the same sources)
@@ -43,10 +43,8 @@ if [ -f $L/libjtprop_stamps.so ]; then
   export JTPROP_LIB=$L/libjtprop_stamps.so JTP_DEBUG=2
   hdr $OUT/stage_times.txt; timeout 300 python3 tools/stamps.py >> $OUT/stage_times.txt 2>&1
   hdr $OUT/stage_times_c2.txt; STAMPS_SUMMARY=1 timeout 300 python3 tools/stamps.py c2 1000 >> $OUT/stage_times_c2.txt 2>&1
-  hdr $OUT/stage_times_c3.txt; STAMPS_SUMMARY=1 timeout 600 python3 tools/stamps.py c3 167 >> $OUT/stage_times_c3.txt 2>&1
   hdr $OUT/stage_times_multiset8.txt; timeout 300 python3 tools/stamps.py multi 8 >> $OUT/stage_times_multiset8.txt 2>&1
   hdr $OUT/stage_times_rank0_of_8.txt; STAMPS_SUMMARY=1 timeout 300 python3 tools/stamps.py ranks 8 0 >> $OUT/stage_times_rank0_of_8.txt 2>&1
-  hdr $OUT/timeline_c3.txt; timeout 600 python3 tools/timeline.py c3 167 2>&1 | awk 'NR % 50 == 1 || /phase/' >> $OUT/timeline_c3.txt
   unset JTPROP_LIB JTP_DEBUG
 fi
 echo "benches done" > $OUT/progress.txt

@@ -1,15 +1,15 @@
 """Copy what tools/collect_profiles.sh brought back (gpurun_out/prof) into profiles/ under this round's names.
     python tools/publish_profiles.py [rNN]"""
 import json, os, shutil, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 P, D = os.path.join("gpurun_out", "prof"), "profiles"
 for f in ("bench", "bench_driver_form", "bench_batch4", "bench_c2", "bench_c3", "bench_c5_multiset8", "bench_c5_multiset16", "bench_c5_multiset64", "bench_c5_multiset512", "bench_c5_share16"):
     shutil.copy(os.path.join(P, f + ".json"), os.path.join(D, "%s_%s.json" % (rnd, f)))
 shutil.copy(os.path.join(P, "kt_bench.json"), os.path.join(D, rnd + "_bench_under_rocprof.json"))
 shutil.copy(os.path.join(P, "bench_level.json"), os.path.join(D, rnd + "_bench_level_launches.json"))
-for f in ("per_launch", "rank_time_8", "odd_cardinalities", "stage_times", "stage_times_multiset8", "stage_times_rank0_of_8", "timeline_c3", "c3_api", "c3_api_column_sweep", "counters_c3"):
+for f in ("per_launch", "rank_time_8", "odd_cardinalities", "stage_times", "stage_times_multiset8", "stage_times_rank0_of_8", "c3_api", "c3_api_column_sweep", "counters_c3"):
     shutil.copy(os.path.join(P, f + ".txt"), os.path.join(D, "%s_%s.txt" % (rnd, f)))
-for c in ("c2", "c3"):          # STAMPS_SUMMARY=1 still prints a line per level: keep every tenth, and the medians
+for c in ("c2",):          # (config 3 runs the lean unit pass, which carries no time stamps: round 6)          # STAMPS_SUMMARY=1 still prints a line per level: keep every tenth, and the medians
     L = open(os.path.join(P, "stage_times_%s.txt" % c)).read().splitlines()
     lv = [l for l in L[1:] if " level " in l]
     keep = [L[0], "# STAMPS_SUMMARY=1 python tools/stamps.py %s ...: one line per level (every 10th kept here), then the medians over the levels" % c]
