@@ -189,6 +189,7 @@ struct KernelTable {
             case JT_K_MULTI_DISTRIBUTE: return jt_multi_flow<T>;
             case JT_K_SINGLE: return jt_single<T>;
             case JT_K_MARGINALS: return jt_marginals<T>;
+            case JT_K_LEAN_SINGLE: return jt_lean_single<T>;
         }
         return nullptr;
     }
@@ -209,7 +210,7 @@ static const char *k_names[JT_K_COUNT] = {
     "jt_distribute<T, 0, 0>", "jt_distribute<T, 0, 1>", "jt_distribute<T, 0, 2>", "jt_distribute<T, 0, 3>",
     "jt_distribute<T, 1, 0>", "jt_distribute<T, 1, 1>", "jt_distribute<T, 1, 2>", "jt_distribute<T, 1, 3>",
     "jt_collect_level<T>", "jt_distribute_level<T>", "jt_collect_flow<T>", "jt_distribute_flow<T>", "jt_reduce_level<T>",
-    "jt_multi_flow<T>", "jt_multi_flow<T>", "jt_single<T>", "jt_propagate_flow<T>", "jt_marginals<T>",
+    "jt_multi_flow<T>", "jt_multi_flow<T>", "jt_single<T>", "jt_propagate_flow<T>", "jt_marginals<T>", "jt_lean_single<T>",
 };
 
 struct BatchBuffers {
@@ -234,6 +235,7 @@ struct BatchBuffers {
 
 // device tables of one list of marginal requests (jtp_get_marginals), kept for the next call
 struct MargBatch {
+    int lean_nblocks = 0, lean_lds = 0;  // the first workgroups of the unit list have a lean record (jt_lean_single)
     std::vector<int32_t> key;            // n, cliques, var_off, var_ids
     JtTask *d_tasks = nullptr;
     JtBlock *d_blocks = nullptr;
@@ -1946,6 +1948,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         // Requests on ONE clique share passes over its belief table, JT_MAX_OUT of them per pass (a pairwise model asks a
         // clique for two or three factor marginals: round 3 read the table once per request - config 3: 1831 reads of 878
         // tables, 2.1 x the bytes).  Multi-set plans marginalise psi x messages directly and keep one request per task.
+        std::vector<char> lean_later;                        // per task: a unit clique's marginals (single-set plans)
         std::vector<std::vector<int>> groups;
         {
             std::map<int, int> open;                         // clique -> its group that still has room
@@ -1991,6 +1994,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
                 bk.task = (uint32_t)tasks.size();
                 (direct ? ublocks : blocks).push_back(bk);
             }
+            lean_later.push_back(direct && hp.pn[clique].unit && !pl->multiset);
             if (direct) ulds = std::max(ulds, tk.lds_bytes);
             else lds = std::max(lds, tk.lds_bytes);
             for (size_t j = 0; j < grp.size(); ++j) {
@@ -2031,7 +2035,17 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
             descs[i].dst_off = total_out;
             total_out += elems[i];
         }
+        // (round 6) marginals of unit cliques run the lean pass: the records are made once every output's place is known
+        for (size_t t = 0; t < tasks.size(); ++t)
+            if (lean_later[t]) jtp_make_lean(hp, tasks[t], itab, true);
+        // (their workgroups first in the list of the cliques that keep no table: a launch of jt_lean_single, then jt_single for the rest)
+        std::stable_partition(ublocks.begin(), ublocks.end(), [&](const JtBlock &bk) { return tasks[bk.task].lean_off > 0; });
+        int n_lean_blocks = 0, lean_lds = 0;
+        for (const JtBlock &bk : ublocks)
+            if (tasks[bk.task].lean_off > 0) ++n_lean_blocks, lean_lds = std::max(lean_lds, tasks[bk.task].lds_bytes);
         mb = new MargBatch();
+        mb->lean_nblocks = n_lean_blocks;
+        mb->lean_lds = lean_lds;
         mb->key = key;
         mb->n = n;
         mb->nblocks = (int)blocks.size();
@@ -2085,7 +2099,14 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         plain.ev = b.ev_any || pl->multiset ? b.ev : nullptr;
         plain.fix_shift = b.fix_shift(plain.cur_off);
         plain.out_shift = (int64_t)(((intptr_t)mb->scratch - (intptr_t)(b.msg + plain.cur_off)) / 8);
-        launch_variant(pl, JT_K_SINGLE, mb->unit_nblocks, mb->unit_lds, s, mb->d_tasks, mb->d_blocks + mb->nblocks, mb->d_itab, b.psi, b.bel, b.msg, plain);
+        // (round 6) the tasks with a lean record through jt_lean_single while the evidence set observes nothing
+        const int n_lean = plain.ev == nullptr ? mb->lean_nblocks : 0;
+        if (n_lean > 0) {
+            HIP_TRY(raise_lds(hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get(JT_K_LEAN_SINGLE, 0) : (const void *)KernelTable<double>::get(JT_K_LEAN_SINGLE, 0), mb->lean_lds));
+            launch_variant(pl, JT_K_LEAN_SINGLE, n_lean, mb->lean_lds, s, mb->d_tasks, mb->d_blocks + mb->nblocks, mb->d_itab, b.psi, b.bel, b.msg, plain);
+        }
+        if (mb->unit_nblocks > n_lean)
+            launch_variant(pl, JT_K_SINGLE, mb->unit_nblocks - n_lean, mb->unit_lds, s, mb->d_tasks, mb->d_blocks + mb->nblocks + n_lean, mb->d_itab, b.psi, b.bel, b.msg, plain);
     }
     hipLaunchKernelGGL(jt_marg_unpack, dim3(mb->max_grid_x, mb->n), dim3(256), 0, s, mb->d_descs, mb->scratch, mb->stage);
     HIP_TRY(hipGetLastError());

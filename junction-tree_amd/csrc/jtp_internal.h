@@ -174,7 +174,7 @@ struct JtLeanMsg {             // 32 ints
     int32_t w_hi[8];           // ... b = 8..12 (three spare)
     int32_t t_w[8];            // sub-box slot weights of the six lane bits, then the two wave bits
 };
-struct JtLean {                // 5 * 32 + 16 = 176 ints
+struct JtLean {                // 5 * 32 + 16 = 176 ints (+ JtLeanMore)
     JtLeanMsg in[JT_MAX_IN];   // [0, n_e): depend on the element bits; [n_e, n_in): do not
     JtLeanMsg out;
     int32_t n_in, n_e;
@@ -187,7 +187,13 @@ struct JtLean {                // 5 * 32 + 16 = 176 ints
     int64_t tmap_off;          // JtTask::tmap_off
     int64_t itab_off;          // JtTask::itab_off
     int32_t some_norow;        // 1: some row of the workgroups' loop nest does not exist (JT_NO_ROW in the iteration table)
-    int32_t pad;
+    int32_t n_out;             // 1, or - read-out tasks (jtp_get_marginals: up to JT_MAX_OUT marginals of one unit clique per pass) - 2 or 3:
+                               // the further outputs are in the JtLeanMore record right behind this one
+};
+struct JtLeanMore {            // 2 * 32 + 16 = 80 ints
+    JtLeanMsg out[JT_MAX_OUT - 1];
+    int32_t rmask[JT_MAX_OUT - 1], red_e[JT_MAX_OUT - 1], red_lane[JT_MAX_OUT - 1], red_wave[JT_MAX_OUT - 1], out_pstride[JT_MAX_OUT - 1];
+    int32_t pad[6];
 };
 
 // per-launch arguments of the message-passing kernels
@@ -329,5 +335,6 @@ enum {
     JT_K_SINGLE,                                    // one task list, any mix of modes and neighbour counts (read-out)
     JT_K_BOTH_FLOW,                                 // collect and distribute in ONE dataflow launch (Segment::phase 2)
     JT_K_MARGINALS,                                 // read-out: up to JT_MAX_OUT marginals of one belief table per pass over it
+    JT_K_LEAN_SINGLE,                               // read-out: marginals of unit cliques by the lean pass (round 6, jt_lean_single)
     JT_K_COUNT
 };

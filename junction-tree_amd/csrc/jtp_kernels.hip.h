@@ -1280,12 +1280,21 @@ __global__ __launch_bounds__(JT_THREADS) void jt_reduce_level(const JtTask *__re
 // table depends on the element bits (NE = 0) the VEC elements of a thread share ONE product and one accumulator.
 // Product order: in[0] * in[1] * ... in the RECORD's order (element-dependent tables first) - a fixed order, the same in every
 // launch mode; the generic pass multiplies in JtTask order, so the two agree to rounding, not bit for bit.
-template <typename T, int NIN, int NE, bool FLOW>
+// NOUT > 1 (read-out tasks only, jt_unit_single: up to three marginals of psi x every incoming table of a unit clique in one pass): every
+// output accumulates the same product and folds after its own runs of rows; outputs 1 and 2 are described by the JtLeanMore record
+// behind the lean record.
+template <typename T, int NIN, int NE, bool FLOW, int NOUT = 1>
 __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk, const int *__restrict__ itab,
                                              double *__restrict__ msg_arena, const JtFlow &fl, uint32_t *flow_ctl) {
     constexpr int VEC = 16 / sizeof(T);               // elements of a thread per row (the plan's thread part: 256 threads x VEC)
     constexpr int NI = NIN > 0 ? NIN : 1;
     constexpr int NACC = NE > 0 ? VEC : 1;
+    const JtLeanMore &lx = *reinterpret_cast<const JtLeanMore *>(&ln + 1);       // (read only where NOUT > 1)
+    auto outm = [&](auto j_tag) -> const JtLeanMsg & {
+        constexpr int j = decltype(j_tag)::value;
+        if constexpr (j == 0) return ln.out;
+        else return lx.out[j - 1];
+    };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int total = ln.total;
@@ -1341,7 +1350,12 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
         const int r = (nent[k] + JT_THREADS - 1) >> 8;
         rounds = r > rounds ? r : rounds;
     }
-    const uint32_t out_lo = lo_of(ln.out), out_hiv = hi_of(ln.out);
+    uint32_t out_lo[NOUT], out_hiv[NOUT];
+    jt_static_for<NOUT>([&](auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        out_lo[j] = lo_of(outm(j_tag));
+        out_hiv[j] = hi_of(outm(j_tag));
+    });
     uint64_t wait_t0 = 0;
     for (int attempt = 0;; ++attempt) {
         const int settle_attempt = ln.settle ? attempt : 0;
@@ -1369,9 +1383,11 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
             }
         }
         if (attempt == 0) {
-            double *sub = reinterpret_cast<double *>(smem + ln.out.lds_off);
-            const int n = 1 << ln.out.nfree;
-            for (int s = tid; s < n; s += JT_THREADS) sub[s] = 0.0;
+            jt_static_for<NOUT>([&](auto j_tag) {
+                double *sub = reinterpret_cast<double *>(smem + outm(j_tag).lds_off);
+                const int n = 1 << outm(j_tag).nfree;
+                for (int s = tid; s < n; s += JT_THREADS) sub[s] = 0.0;
+            });
         }
         if constexpr (!FLOW || NIN == 0) {
             __syncthreads();
@@ -1442,21 +1458,32 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
             }
         }
     }
-    double *out_sub = reinterpret_cast<double *>(smem + ln.out.lds_off);
-    const int thr_out = slot_of(ln.out);
-    const int o_ew0 = ln.out.e_w[0], o_ew1 = ln.out.e_w[1];
-    const int red_e = ln.red_e, red_lane = ln.red_lane, red_wave = ln.red_wave;
-    const int rmask = ln.rmask;
-    const bool rep = (lane & red_lane) == 0;
-    const int nph = 1 << __builtin_popcount((unsigned)red_wave);
-    int myph = 0;
-    if (red_wave == 1) myph = wave & 1;
-    else if (red_wave == 2) myph = wave >> 1;
-    else if (red_wave == 3) myph = wave;
+    double *out_sub[NOUT];
+    int thr_out[NOUT], o_ew0[NOUT], o_ew1[NOUT], red_e[NOUT], red_lane[NOUT], red_wave[NOUT], rmask[NOUT], nph[NOUT], myph[NOUT];
+    bool rep[NOUT];
+    jt_static_for<NOUT>([&](auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        const JtLeanMsg &m = outm(j_tag);
+        out_sub[j] = reinterpret_cast<double *>(smem + m.lds_off);
+        thr_out[j] = slot_of(m);
+        o_ew0[j] = m.e_w[0], o_ew1[j] = m.e_w[1];
+        red_e[j] = j == 0 ? ln.red_e : lx.red_e[j > 0 ? j - 1 : 0];
+        red_lane[j] = j == 0 ? ln.red_lane : lx.red_lane[j > 0 ? j - 1 : 0];
+        red_wave[j] = j == 0 ? ln.red_wave : lx.red_wave[j > 0 ? j - 1 : 0];
+        rmask[j] = j == 0 ? ln.rmask : lx.rmask[j > 0 ? j - 1 : 0];
+        rep[j] = (lane & red_lane[j]) == 0;
+        nph[j] = 1 << __builtin_popcount((unsigned)red_wave[j]);
+        myph[j] = 0;
+        if (red_wave[j] == 1) myph[j] = wave & 1;
+        else if (red_wave[j] == 2) myph[j] = wave >> 1;
+        else if (red_wave[j] == 3) myph[j] = wave;
+    });
 
-    double acc[NACC];
+    double acc[NOUT][NACC];
 #pragma unroll
-    for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
+    for (int j = 0; j < NOUT; ++j)
+#pragma unroll
+        for (int e = 0; e < NACC; ++e) acc[j][e] = 0.0;
     // (the record orders the tables its own way; a table's column of the iteration table is its place in JtTask::msg - picked once)
     int tcol[NI];
 #pragma unroll
@@ -1465,39 +1492,40 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
         tcol[k] = sk == 0 ? trow[1] : (sk == 1 ? trow[2] : (sk == 2 ? trow[3] : trow[4]));
     }
 
-    // fold this thread's sums of one run of rows into the outgoing sub-box (jt_pass: same sums, same order)
-    auto epilogue = [&](const int oo) {
+    // fold this thread's sums of one run of rows into outgoing sub-box j (jt_pass: same sums, same order)
+    auto epilogue = [&](auto j_tag, const int oo) {
+        constexpr int j = decltype(j_tag)::value;
         double a[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) a[e] = ((dead >> e) & 1u) ? 0.0 : acc[NE > 0 ? e : 0];
+        for (int e = 0; e < VEC; ++e) a[e] = ((dead >> e) & 1u) ? 0.0 : acc[j][NE > 0 ? e : 0];
         if constexpr (VEC == 4) {
-            if (red_e & 1) {
+            if (red_e[j] & 1) {
                 a[0] += a[1];
                 a[2] += a[3];
             }
-            if (red_e & 2) {
+            if (red_e[j] & 2) {
                 a[0] += a[2];
                 a[1] += a[3];
             }
         } else {
-            if (red_e & 1) a[0] += a[1];
+            if (red_e[j] & 1) a[0] += a[1];
         }
-        jt_lane_sums<VEC>(a, red_lane);
-        const int slot = oo + thr_out;
-        for (int ph = 0; ph < nph; ++ph) {
-            if (rep && myph == ph) {
+        jt_lane_sums<VEC>(a, red_lane[j]);
+        const int slot = oo + thr_out[j];
+        for (int ph = 0; ph < nph[j]; ++ph) {
+            if (rep[j] && myph[j] == ph) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    if ((e & red_e) == 0) {
-                        const int eo = ((e & 1) ? o_ew0 : 0) + ((e & 2) ? o_ew1 : 0);
-                        __hip_atomic_fetch_add(&out_sub[slot + eo], a[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((e & red_e[j]) == 0) {
+                        const int eo = ((e & 1) ? o_ew0[j] : 0) + ((e & 2) ? o_ew1[j] : 0);
+                        __hip_atomic_fetch_add(&out_sub[j][slot + eo], a[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
-            if (nph > 1) __syncthreads();
+            if (nph[j] > 1) __syncthreads();
         }
 #pragma unroll
-        for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
+        for (int e = 0; e < NACC; ++e) acc[j][e] = 0.0;
     };
 
 #pragma unroll
@@ -1527,12 +1555,14 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
     };
     auto use = [&](const Entries &x) {
         if constexpr (NIN == 0) {
-            acc[0] += 1.0;
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) acc[j][0] += 1.0;
         } else if constexpr (NE == 0) {
             double w = x.c[0];
 #pragma unroll
             for (int k = 1; k < NIN; ++k) w *= x.c[k];
-            acc[0] += w;
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) acc[j][0] += w;
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -1541,7 +1571,8 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
                 for (int k = 1; k < NE; ++k) w *= x.e[k][e];
 #pragma unroll
                 for (int k = NE; k < NIN; ++k) w *= x.c[k - NE];
-                acc[e] += w;
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) acc[j][e] += w;
             }
         }
     };
@@ -1552,7 +1583,10 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
         for (int i = 0; i < total; ++i) {
             fetch(i + 1 < total ? i + 1 : i, nxt);
             if (!CHECK || (uint32_t)__builtin_amdgcn_readlane(trow[0], i) != JT_NO_ROW) use(cur);
-            if ((i & rmask) == rmask) epilogue(__builtin_amdgcn_readlane(trow[1 + JT_MAX_IN], i));
+            jt_static_for<NOUT>([&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+                if ((i & rmask[j]) == rmask[j]) epilogue(j_tag, __builtin_amdgcn_readlane(trow[1 + JT_MAX_IN + j], i));
+            });
             cur = nxt;
         }
     };
@@ -1561,20 +1595,22 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
         else rows(std::integral_constant<bool, false>{});
     }
 
-    // ---- flush the outgoing sub-box as this chunk's partial copy; the same entries of the other arena half become "unwritten"
+    // ---- flush the outgoing sub-boxes as this chunk's partial copies; the same entries of the other arena half become "unwritten"
     __syncthreads();
-    {
-        const int64_t at = ln.out.off + (int64_t)bk.pnum[0] * ln.out_pstride + bk.gbase[JT_MAX_IN];
+    jt_static_for<NOUT>([&](auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        const JtLeanMsg &m = outm(j_tag);
+        const int64_t at = m.off + (int64_t)bk.pnum[j] * (j == 0 ? ln.out_pstride : lx.out_pstride[j > 0 ? j - 1 : 0]) + bk.gbase[JT_MAX_IN + j];
         double *dst = msg_arena + fl.cur_off + at + fl.out_shift;
         double *oth = msg_arena + fl.oth_off + at;
         const bool mark = fl.oth_off >= 0;
-        const int n = 1 << ln.out.nfree;
+        const int n = 1 << m.nfree;
         for (int s = tid, it = 0; s < n; s += JT_THREADS, ++it) {
-            const uint32_t idx = out_lo + (uint32_t)__builtin_amdgcn_readlane((int)out_hiv, it);
-            jt_msg_store<FLOW>(dst + idx, out_sub[s]);
+            const uint32_t idx = out_lo[j] + (uint32_t)__builtin_amdgcn_readlane((int)out_hiv[j], it);
+            jt_msg_store<FLOW>(dst + idx, out_sub[j][s]);
             if (mark) oth[idx] = __longlong_as_double((long long)JT_UNWRITTEN);
         }
-    }
+    });
 }
 
 // (which of the ten row loops: incoming tables x those among them that depend on the element bits)
@@ -1595,6 +1631,36 @@ __device__ __forceinline__ void jt_unit_lean_dispatch(const JtLean &ln, const Jt
         default: JT_LEAN(3, 3);                           // (jtp_make_lean: at most three incoming tables)
     }
 #undef JT_LEAN
+}
+
+// Read-out tasks of unit cliques (jtp_get_marginals -> jt_single; no launch waits on anything): up to four incoming tables - the parent's
+// message, the static table and two children, all of them - and one to three marginals per pass.
+template <typename T>
+__device__ __forceinline__ void jt_unit_lean_readout(const JtLean &ln, const JtBlock &bk, const int *__restrict__ itab,
+                                                     double *__restrict__ msg, const JtFlow &fl) {
+#define JT_LEAN_OUT(NIN, NE)                                                                          \
+    if (ln.n_out == 1) jt_unit_lean<T, NIN, NE, false, 1>(ln, bk, itab, msg, fl, nullptr);            \
+    else if (ln.n_out == 2) jt_unit_lean<T, NIN, NE, false, 2>(ln, bk, itab, msg, fl, nullptr);       \
+    else jt_unit_lean<T, NIN, NE, false, 3>(ln, bk, itab, msg, fl, nullptr);                          \
+    break
+    switch (ln.n_in * 8 + ln.n_e) {
+        case 0: JT_LEAN_OUT(0, 0);
+        case 8: JT_LEAN_OUT(1, 0);
+        case 9: JT_LEAN_OUT(1, 1);
+        case 16: JT_LEAN_OUT(2, 0);
+        case 17: JT_LEAN_OUT(2, 1);
+        case 18: JT_LEAN_OUT(2, 2);
+        case 24: JT_LEAN_OUT(3, 0);
+        case 25: JT_LEAN_OUT(3, 1);
+        case 26: JT_LEAN_OUT(3, 2);
+        case 27: JT_LEAN_OUT(3, 3);
+        case 32: JT_LEAN_OUT(4, 0);
+        case 33: JT_LEAN_OUT(4, 1);
+        case 34: JT_LEAN_OUT(4, 2);
+        case 35: JT_LEAN_OUT(4, 3);
+        default: JT_LEAN_OUT(4, 4);
+    }
+#undef JT_LEAN_OUT
 }
 
 // A dataflow workgroup whose record says "lean" (JT_BLOCK_LEAN) goes from its workgroup record straight to the task's lean record:
@@ -2512,6 +2578,17 @@ __global__ __launch_bounds__(JT_THREADS) void jt_single(const JtTask *__restrict
     }
 }
 
+// Marginals of unit cliques by the lean pass (round 6): every task of the list has a lean record (jtp_get_marginals makes them) and the
+// evidence set observes nothing (the engine sends the list through jt_single otherwise).  A kernel of its own: jt_single holds the
+// generic passes of up to four inputs and three outputs, whose registers would halve the occupancy of these loops.
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, 4) void jt_lean_single(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                                const int *__restrict__ itab, const T *__restrict__ psi,
+                                                                T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    const JtBlock &bk = blk[blockIdx.x];
+    jt_unit_lean_readout<T>(*reinterpret_cast<const JtLean *>(itab + tasks[bk.task].lean_off), bk, itab, msg, fl);
+}
+
 // Read-out of single-set plans (jtp_get_marginals, CliqueGraph.marginalize junctiontree.py:229-274): a pass over a BELIEF
 // table (the `psi` argument) that forms one to JT_MAX_OUT marginals of it at once - the requests of a model's factors on one
 // clique share the read of its table.  Bound: HBM read, sizeof(T) per element.
@@ -2905,10 +2982,34 @@ __global__ __launch_bounds__(256) void jt_msg_unpack(JtPackDesc d, const double 
 
 #ifndef JT_INST_TU
 // batched marginal read-out: request blockIdx.y, entries strided over blockIdx.x
+// (round 6: a factor marginal is a few dozen entries of hundreds of partial copies - one per workgroup of the pass that formed it; a
+//  thread per entry added them one after the other, 94 us for config 3's 1831 requests.  A request of at most 128 entries now spreads
+//  its copies over 256 / entries thread groups - group g takes copies g, g + G, ... - whose sums are added in group order: a fixed
+//  order, the same bits on every call.)
 __global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restrict__ descs, const double *__restrict__ scratch,
                                                       double *__restrict__ stage) {
     const JtMargDesc &m = descs[blockIdx.y];
-    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < m.d.host_elems; h += (int64_t)gridDim.x * blockDim.x) {
+    __shared__ double part[256];
+    const int64_t ne = m.d.host_elems;
+    if (ne <= 128 && gridDim.x == 1) {
+        int w = 1;
+        while (w < ne) w <<= 1;                                   // entries rounded up to a power of two
+        const int G = 256 / w, g = (int)threadIdx.x / w, h = (int)threadIdx.x % w;
+        double u = 0.0;
+        if (h < ne) {
+            const uint32_t x = jt_host_to_dev(m.d, h);
+            for (int p = g; p < m.npart; p += G) u += scratch[m.src_off + (int64_t)p * m.pstride + x];
+        }
+        part[threadIdx.x] = u;
+        __syncthreads();
+        if (g == 0 && h < ne) {
+            double t = part[h];
+            for (int k = 1; k < G; ++k) t += part[k * w + h];
+            stage[m.dst_off + h] = t;
+        }
+        return;
+    }
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < ne; h += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t x = jt_host_to_dev(m.d, h);
         double u = 0.0;
         for (int p = 0; p < m.npart; ++p) u += scratch[m.src_off + (int64_t)p * m.pstride + x];
@@ -2931,6 +3032,7 @@ __global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restri
     X template __global__ void jt_distribute_level<T>(JT_KARGS(T));          \
     X template __global__ void jt_reduce_level<T>(JT_KARGS(T));              \
     X template __global__ void jt_single<T>(JT_KARGS(T));                    \
+    X template __global__ void jt_lean_single<T>(JT_KARGS(T));               \
     X template __global__ void jt_marginals<T>(JT_KARGS(T));
 #define JT_INST_SHAPE(X, T)                                                  \
     X template __global__ void jt_collect<T, 0>(JT_KARGS(T));                \

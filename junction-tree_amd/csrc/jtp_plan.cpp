@@ -639,15 +639,20 @@ JtBlock jtp_make_block(const HostPlan &hp, const JtTask &tk, uint32_t task_index
 // The lean record of a unit task (JtLean, jtp_internal.h), appended to `itab` at a 64-byte boundary; JtTask::lean_off says where
 // (0: the task runs the generic pass - it keeps a table, has several outputs, stores a belief, belongs to a plan with mixed-radix
 // rows or to a multi-set plan, or stages a message of several partial copies).  JTP_NO_LEAN=1: no task gets one.
-void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab) {
+void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, bool readout) {
     tk.lean_off = 0;
-    if (hp.knobs.no_lean || hp.tmix || hp.multiset) return;
-    if (tk.kind != 0 || !tk.unit || tk.mode != 0 || tk.n_out != 1 || tk.n_in > 3 || tk.bel_off >= 0 || tk.vgroups) return;
+    if (hp.knobs.no_lean || hp.tmix || (hp.multiset && !readout)) return;
+    // (tasks of a propagate: one outgoing message, at most three incoming tables - ten row loops in the dataflow kernels; read-out
+    //  tasks, whose kernel is off the hot path: up to three marginals of psi x ALL incoming tables of a unit clique)
+    const int max_in = readout ? JT_MAX_IN : 3, max_out = readout ? JT_MAX_OUT : 1;
+    if (tk.kind != 0 || !tk.unit || tk.mode != 0 || tk.n_out < 1 || tk.n_out > max_out || tk.n_in > max_in || tk.bel_off >= 0 || tk.vgroups) return;
     for (int k = 0; k < tk.n_in; ++k)
         if (tk.msg[k].npart != 1) return;
     if ((tk.debug & ~2) != 0) return;                 // (the JTP_DEBUG timing experiments are switches of the generic pass)
     JtLean ln;
+    JtLeanMore more;
     memset(&ln, 0, sizeof ln);
+    memset(&more, 0, sizeof more);
     auto fill = [&](JtLeanMsg &lm, const JtMsg &m, int src) {
         lm.off = m.off;
         lm.nfree = m.nfree;
@@ -664,28 +669,42 @@ void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab) {
         for (int k = 0; k < tk.n_in; ++k)
             if ((tk.msg[k].e_dep != 0) == (pass == 0)) fill(ln.in[n++], tk.msg[k], k);
     for (int k = 0; k < tk.n_in; ++k) ln.n_e += tk.msg[k].e_dep ? 1 : 0;
-    const JtMsg &mo = tk.msg[JT_MAX_IN];
-    fill(ln.out, mo, JT_MAX_IN);
+    for (int j = 0; j < tk.n_out; ++j) {
+        const JtMsg &mo = tk.msg[JT_MAX_IN + j];
+        const int rmask = (1 << ((tk.out_run >> (8 * j)) & 0xffu)) - 1;
+        if (j == 0) {
+            fill(ln.out, mo, JT_MAX_IN);
+            ln.rmask = rmask;
+            ln.red_e = mo.red_e, ln.red_lane = mo.red_lane, ln.red_wave = mo.red_wave;
+            ln.out_pstride = mo.pstride;
+        } else {
+            fill(more.out[j - 1], mo, JT_MAX_IN + j);
+            more.rmask[j - 1] = rmask;
+            more.red_e[j - 1] = mo.red_e, more.red_lane[j - 1] = mo.red_lane, more.red_wave[j - 1] = mo.red_wave;
+            more.out_pstride[j - 1] = mo.pstride;
+        }
+    }
     ln.n_in = tk.n_in;
+    ln.n_out = tk.n_out;
     ln.total = tk.total;
-    ln.rmask = (1 << (tk.out_run & 0xffu)) - 1;
-    ln.red_e = mo.red_e, ln.red_lane = mo.red_lane, ln.red_wave = mo.red_wave;
     ln.settle = tk.settle;
-    ln.out_pstride = mo.pstride;
     ln.tmap_off = tk.tmap_off;
     ln.itab_off = tk.itab_off;
     if (tk.tmap_off >= 0) {
         const int n_t = 1 << hp.TB;
         for (int x = 0; x < n_t; ++x)
             if (itab[(size_t)tk.tmap_off + x] < 0) ln.some_invalid = 1;
-    } else
-        ln.some_invalid = 0;
+    }
     for (int i = 0; i < tk.total; ++i)
         if ((uint32_t)itab[(size_t)tk.itab_off + (size_t)i * JT_NCOL] == JT_NO_ROW) ln.some_norow = 1;
     while (itab.empty() || itab.size() % 16) itab.push_back(0);
     tk.lean_off = (int64_t)itab.size();
     const int32_t *w = reinterpret_cast<const int32_t *>(&ln);
     itab.insert(itab.end(), w, w + sizeof ln / 4);
+    if (tk.n_out > 1) {
+        const int32_t *w2 = reinterpret_cast<const int32_t *>(&more);
+        itab.insert(itab.end(), w2, w2 + sizeof more / 4);
+    }
 }
 
 PlanKnobs jtp_read_knobs() {

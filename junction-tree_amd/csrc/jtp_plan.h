@@ -118,7 +118,7 @@ struct VirtualFill { JtPackDesc d; };   // all-ones table of a virtual clique (1
 struct HostPlan;
 // decode chunk number -> workgroup record (element base, message bases, partial numbers)
 JtBlock jtp_make_block(const HostPlan &hp, const JtTask &tk, uint32_t task_index, uint32_t chunk);
-void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab);
+void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, bool readout = false);
 
 // Development knobs, read from the environment ONCE per plan (jtp_read_knobs, at the top of jtp_build_plan):
 // nothing else in the product path calls getenv while planning or propagating.

@@ -21,7 +21,7 @@ JTP_SHARE_POTENTIALS = 32
 JTP_FLOW_TICKETS = 16
 JTP_MULTISET = 64
 JTP_NO_COMPACT = 128
-N_VARIANTS = 22
+N_VARIANTS = 23
 MAX_VARS = 32            # variables per node the C ABI takes (JT_MAX_VARS); engine.Plan keeps one-state variables beyond that on the host
 
 

@@ -127,6 +127,58 @@ def test_evidence_sets_through_the_public_api(golden):
                 close(o, w, what="%s %r" % (name, observed))
 
 
+def test_evidence_sets_over_a_chain_of_64_by_64_separators_run_as_a_multi_set_plan():
+    """A chain whose separators are 64 x 64 doubles (32 KiB each, beyond the 16 KiB a multi-set pass gives one evidence set's
+    sub-boxes IF a workgroup had to hold a whole separator): the planner cuts the cliques so that a workgroup touches a slice of
+    each - the plan is a multi-set plan (`plan.evidence_mode`), not the one-pass-per-set fall-back, and every set agrees with the
+    oracle's `propagate` on indicator-multiplied factors.  (What IS refused: cliques of a row or two whose separators are nearly
+    the clique itself - DESIGN.md section 7.)"""
+    import warnings
+    rng = np.random.default_rng(11)
+    n, k = 6, 64
+    names = ["x%d" % i for i in range(n + 2)]
+    sizes = {v: k for v in names}
+    factors = [[names[i], names[i + 1], names[i + 2]] for i in range(n)]
+    values = [rng.uniform(0.5, 1.5, (k, k, k)) / k for _ in factors]
+    tree = jt.create_junction_tree(factors, sizes)
+    assert max(int(np.prod([sizes[v] for v in sp])) for sp in tree.separators) == k * k
+    evidence_sets = [{}, {names[0]: 3}, {names[3]: 60, names[7]: 1}, {names[2]: 0, names[4]: 63, names[5]: 17}, {names[1]: 5}]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # (the fall-back announces itself with a RuntimeWarning)
+        got = tree.propagate_evidence_sets(values, evidence_sets)
+    plan = tree._memo["evidence_plan"]
+    assert plan.evidence_mode.startswith("multiset"), plan.evidence_mode
+    assert plan.stats()["flow_fallbacks"] == 0
+    for observed, out in zip(evidence_sets, got):
+        xs = [v.copy() for v in values]
+        for var, state in observed.items():
+            f = next(i for i, fv in enumerate(factors) if var in fv)
+            ind = np.zeros(k)
+            ind[state] = 1.0
+            shape = [1, 1, 1]
+            shape[factors[f].index(var)] = k
+            xs[f] = xs[f] * ind.reshape(shape)
+        want = _joint_marginals_chain(factors, sizes, xs)
+        for o, w in zip(out, want):
+            close(o, w, what="%r" % (observed,))
+    engine.clear_plan_cache()
+
+
+def _joint_marginals_chain(factors, sizes, xs):
+    """Factor marginals of a chain of overlapping triples by exact forward / backward sums (numpy, float64): the oracle of
+    `test_evidence_sets_over_a_chain_of_64_by_64_separators...` (the brute-force joint of eight 64-state variables is out of reach)."""
+    n = len(factors)
+    fwd = [None] * n          # fwd[i][b, c]: everything left of factor i summed out, over its first two variables
+    fwd[0] = np.ones(xs[0].shape[:2])
+    for i in range(1, n):
+        fwd[i] = np.einsum("ab,abc->bc", fwd[i - 1], xs[i - 1])
+    bwd = [None] * n          # bwd[i][b, c]: everything right of factor i, over its last two variables
+    bwd[n - 1] = np.ones(xs[n - 1].shape[1:])
+    for i in range(n - 2, -1, -1):
+        bwd[i] = np.einsum("bcd,cd->bc", xs[i + 1], bwd[i + 1])
+    return [fwd[i][:, :, None] * xs[i] * bwd[i][None, :, :] for i in range(n)]
+
+
 def test_hand_built_tree_like_reference_test(golden):
     g = golden("networks.npz")
     net = g.meta["networks"]["abcdefgh"]
