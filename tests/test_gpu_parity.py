@@ -1439,8 +1439,8 @@ def test_multiset_plans_with_odd_cardinalities_share_evidence_free_subtrees_whil
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_skipped_producers_re_arm_the_partial_copies_their_reduce_tasks_sum(monkeypatch, dtype):
+@pytest.mark.parametrize("dtype,mode", [("f64", "flow"), ("f32", "flow"), ("f64", "tickets"), ("f32", "levels")])
+def test_skipped_producers_re_arm_the_partial_copies_their_reduce_tasks_sum(monkeypatch, dtype, mode):
     """Round 6 (advisor, round 5): a multi-set plan that shares evidence-free subtrees skips a collect task for a group whose sets observe
     nothing below it.  Where a REDUCE task sums that producer's partial copies, the copies are entries of their own - a skipped
     producer used to leave them alone, so when evidence moved into the subtree, out of it and back in, the reduce task of the third
@@ -1453,8 +1453,12 @@ def test_skipped_producers_re_arm_the_partial_copies_their_reduce_tasks_sum(monk
     pots = synthetic.potentials_for(spec, seed=8)
     cast = [p.astype(np.float32) for p in pots] if dtype == "f32" else pots
     nb = 8
-    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, n_batch=nb, share_potentials=True, multiset=True)
+    # (round 6: with active lists a workgroup of one run of eight sets waits for entries of another run's workgroup - also in ticket order,
+    #  also with one launch per level)
+    plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype=dtype, n_batch=nb, share_potentials=True, multiset=True,
+                       flow_tickets=(mode == "tickets"), level_launches=(mode == "levels"))
     d = plan.describe()
+    assert all(L["blk_off"] % 8 == 0 and L["nblocks"] % 8 == 0 for L in d["launches"])      # (every level starts on a multiple of eight records)
     ups = [s for s in d["pseps"] if s["up_red_task"] >= 0]
     assert ups, "this tree must have upward reduce tasks"
     # a variable private to the subtree below a separator with an upward reduce task (it is in the child clique, not in the separator)
@@ -1480,8 +1484,51 @@ def test_skipped_producers_re_arm_the_partial_copies_their_reduce_tasks_sum(monk
             for node in (0, sp["child"], sp["node"], spec["n_cliques"] - 1):
                 close(plan.belief(node, batch=b), w[node], rtol=tol, what="round %d set %d node %d" % (rnd, b, node))
     st = plan.stats()
-    assert st["flow_fallbacks"] == 0 and st["launch_mode"] == "flow"
+    assert st["flow_fallbacks"] == 0 and st["launch_mode"] == {"flow": "flow", "tickets": "flow_tickets", "levels": "level"}[mode]
     plan.close()
+
+
+@pytest.mark.gpu
+def test_lean_and_generic_unit_passes_agree(monkeypatch):
+    """Round 6: the lean unit pass (`jt_unit_lean`, the default) and the generic one (`JTP_NO_LEAN=1`) on a lattice whose junction tree is
+    mostly unit cliques: every factor marginal of both against the oracle's `propagate`, the two against each other to rounding (the
+    lean record orders a task's incoming tables its own way: another product order), dataflow and per-level launches of the lean pass
+    bit for bit, the same propagate ten times the same bits."""
+    factors, sizes, values = synthetic.lattice_mrf(5, 16, 4, dtype=np.float64)
+    want = None
+    outs = {}
+    for mode in ("lean", "generic", "lean_levels"):
+        if mode == "generic":
+            monkeypatch.setenv("JTP_NO_LEAN", "1")
+        else:
+            monkeypatch.delenv("JTP_NO_LEAN", raising=False)
+        engine.clear_plan_cache()
+        tree = jt.create_junction_tree(factors, sizes)
+        if want is None:
+            ct = tree.clique_tree
+            want = oracle.propagate(tree.tree, tree.separators, ct.maxcliques, ct.factor_to_maxclique, factors, sizes, values)
+        if mode == "lean_levels":
+            tree._opts["level_launches"] = True
+        out = tree.propagate(values)
+        plan = tree.plan("f64")
+        d = plan.describe()
+        n_lean = sum(1 for t in d["tasks"] if t["lean_off"] > 0)
+        assert (n_lean > 0) == (mode != "generic") and plan.stats()["n_unit_cliques"] > 0
+        assert plan.stats()["launch_mode"] == ("level" if mode == "lean_levels" else "flow")
+        if mode == "lean":
+            for rep in range(10):
+                again = tree.propagate(values, changed=[])
+                for a, b in zip(out, again):
+                    np.testing.assert_array_equal(a, b)
+        outs[mode] = [o.copy() for o in out]
+    engine.clear_plan_cache()
+    for mode in outs:
+        for o, w in zip(outs[mode], want):
+            close(o, w, what=mode)
+    for a, b in zip(outs["lean"], outs["generic"]):
+        close(a, b, what="lean against generic")
+    for a, b in zip(outs["lean"], outs["lean_levels"]):
+        np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.gpu
