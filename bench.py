@@ -310,6 +310,9 @@ def sub_c3(device, source_id, steps=10, api_calls=5, lattice_w=167):
         # every factor table new on every call; the caller SAYS so (`changed="all"`, round 6: nothing is compared, the factor lists are
         # not looked at again) - and, beside it, the call that leaves the comparison to the library (one vectorised pass over all tables)
         api, api_cmp = [], []
+        import gc
+        gc.collect()
+        gc.disable()          # (as timeit does: a collection of this process's whole heap - four configs' worth of objects - is not the call's)
         for r in range(api_calls):
             vals = [v * np.float32(1.0 + 1e-3 * (r + 1)) for v in values]
             plan.sync()
@@ -323,6 +326,7 @@ def sub_c3(device, source_id, steps=10, api_calls=5, lattice_w=167):
             t0 = time.perf_counter()
             out = tree.propagate(vals)
             api_cmp.append((time.perf_counter() - t0) * 1e3)
+        gc.enable()
         out = tree.propagate(values)
         z = plan.z()
         sums = np.array([m.sum() for m in out])
