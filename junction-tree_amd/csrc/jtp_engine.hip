@@ -236,6 +236,7 @@ struct BatchBuffers {
 // device tables of one list of marginal requests (jtp_get_marginals), kept for the next call
 struct MargBatch {
     int lean_nblocks = 0, lean_lds = 0;  // the first workgroups of the unit list have a lean record (jt_lean_single)
+    std::vector<JtTask> h_tasks;         // multi-set plans with active lists: the records as planned (readout_redirect patches copies of them)
     std::vector<int32_t> key;            // n, cliques, var_off, var_ids
     JtTask *d_tasks = nullptr;
     JtBlock *d_blocks = nullptr;
@@ -319,7 +320,7 @@ struct jtp_plan {
     bool act_dirty = false;
     JtFanout *d_fanout = nullptr;
     int n_fanout = 0, cap_fanout = 0;
-    struct BeliefTask { JtTask *d_task = nullptr; JtBlock *d_blk = nullptr; int *d_tab = nullptr; int nblocks = 0, lds = 0; };
+    struct BeliefTask { JtTask *d_task = nullptr; JtBlock *d_blk = nullptr; int *d_tab = nullptr; int nblocks = 0, lds = 0; JtTask h_task; };
     std::vector<BeliefTask> belief_tasks;
     std::vector<hipStream_t> streams;
     std::vector<BatchBuffers> bufs;
@@ -1430,12 +1431,14 @@ static int multiset_lds(const HostPlan &hp, const Launch &L) {
 //     variable in the subtree below c;
 //   downward task: every caller's slot (and the padding slots behind them, which exist: the last group as before).
 // A consumer stages an upward message of slot s from s's own arena where s is on the producer's list, from slot 0 where it is not
-// (JtFlow::skip = member); the copy pass behind the propagate (jt_multi_fanout) then gives every other caller's set its copy -
-// values in this propagate's half, markers in the other, and the markers of the partial copies a reduce task would sum.
+// (JtFlow::skip = member) - and so does the read-out (readout_redirect): nobody copies slot 0's messages into the other sets' arenas
+// (round 5 and the first form of this round did, behind every propagate: 7 % of a 64-set step).  The entries of a (task, slot) off the
+// lists stay "unwritten" in both arena halves; those of a pair that LEAVES a list are set back to that, once, here.
 static int rebuild_active(jtp_plan *pl, hipStream_t s) {
     const HostPlan &hp = pl->hp;
     const int cap = pl->n_groups * JT_MSETS, set0 = pl->set0, S = hp.n_batch;
     const size_t nt = hp.tasks.size(), np = hp.pn.size();
+    const std::vector<uint8_t> was = pl->member_host;       // the lists of the last propagate (empty: none yet)
     pl->member_host.assign(nt * cap, 0);
     pl->act_ids_host.assign(nt * cap, 0);
     pl->act_n_host.assign(nt, 0);
@@ -1462,12 +1465,16 @@ static int rebuild_active(jtp_plan *pl, hipStream_t s) {
     };
     std::vector<uint16_t> everyone;
     for (int slot = set0; slot < cap; ++slot) everyone.push_back((uint16_t)slot);
+    // What leaves a list is reset: the entries of a (collect task, slot) that was on the task's list for the last propagate and is not
+    // now hold that propagate's values - in the halves' turn the task would find them "written" when the slot comes back (its reduce
+    // task sums the partial copies it finds without a marker).  Both halves of such messages, partial copies included, are marked
+    // "unwritten" ONCE, here; entries of pairs that stay off the lists are never read (consumers and read-out go to slot 0) nor written.
     std::vector<JtFanout> fan;
-    auto fan_out = [&](int64_t off, int64_t count, int flags, const std::vector<uint16_t> &slots) {
+    auto reset = [&](int64_t off, int64_t count, const std::vector<uint16_t> &slots) {
         for (size_t i = 0; i < slots.size(); i += JT_MSETS) {
             JtFanout f;
             memset(&f, 0, sizeof f);
-            f.off = off, f.count = (int32_t)count, f.flags = flags;
+            f.off = off, f.count = (int32_t)count, f.flags = JT_FANOUT_RESET;
             for (int j = 0; j < JT_MSETS; ++j) f.slot[j] = i + j < slots.size() ? slots[i + j] : (uint16_t)0xffffu;
             fan.push_back(f);
         }
@@ -1475,14 +1482,18 @@ static int rebuild_active(jtp_plan *pl, hipStream_t s) {
     for (size_t p = 0; p < np; ++p) {
         const PNode &pn = hp.pn[p];
         if (pn.collect_task >= 0) {
-            std::vector<uint16_t> list(1, (uint16_t)0), rest;
-            for (int slot = set0; slot < set0 + S; ++slot) (below[(size_t)slot * np + p] ? list : rest).push_back((uint16_t)slot);
+            std::vector<uint16_t> list(1, (uint16_t)0), left;
+            for (int slot = set0; slot < set0 + S; ++slot) {
+                const bool on = below[(size_t)slot * np + p] != 0;
+                if (on) list.push_back((uint16_t)slot);
+                else if (!was.empty() && was[(size_t)pn.collect_task * cap + slot]) left.push_back((uint16_t)slot);
+            }
             put(pn.collect_task, list);
             const PSep &sp = hp.ps[pn.psep];
             put(sp.up_red_task, list);
-            if (!rest.empty()) {
-                fan_out(sp.up_roff, ((int64_t)sp.up_rnpart) << sp.nbits, 0, rest);
-                if (sp.up_red_task >= 0) fan_out(sp.up_off, ((int64_t)sp.up_npart) << sp.nbits, JT_FANOUT_MARK_ONLY, rest);
+            if (!left.empty()) {
+                reset(sp.up_roff, ((int64_t)sp.up_rnpart) << sp.nbits, left);
+                if (sp.up_red_task >= 0) reset(sp.up_off, ((int64_t)sp.up_npart) << sp.nbits, left);
             }
         }
     }
@@ -1517,6 +1528,17 @@ static int rebuild_active(jtp_plan *pl, hipStream_t s) {
     HIP_TRY(hipStreamSynchronize(s));                    // (the sources are host vectors)
     pl->n_fanout = (int)fan.size();
     pl->act_dirty = false;
+    if (pl->n_fanout > 0) {
+        JtFlow fl;
+        memset(&fl, 0, sizeof fl);
+        fl.set_stride = pl->set_stride;
+        fl.oth_off = std::max<int64_t>(hp.msg_doubles, 2);          // (the second half starts here: the pass marks both)
+        hipLaunchKernelGGL(jt_multi_fanout, dim3(pl->n_fanout), dim3(256), 0, s, pl->d_fanout, pl->msg_all, fl);
+        HIP_TRY(hipGetLastError());
+        // (the marks cover the partial copies of chunks that do not exist, which nobody writes again: set back to their zeros)
+        if (pl->d_init[0] || pl->d_init[1])
+            if (int rc = zero_padding(pl, pl->msg_all, pl->n_groups * JT_MSETS, s)) return rc;
+    }
     return JTP_OK;
 }
 
@@ -1621,12 +1643,6 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 launch(L.phase, L.blk_off, L.nblocks, multiset_lds(hp, L), -1, 0u);
             }
         }
-        if (pl->n_fanout > 0)        // the messages of the skipped tasks, into the sets' own arenas (read-out, next propagate's markers)
-            hipLaunchKernelGGL(jt_multi_fanout, dim3(pl->n_fanout), dim3(256), 0, s, pl->d_fanout, pl->msg_all, fl);
-        // (the copy pass marks every entry of a copied message "unwritten" in the other half - also the partial copies of chunks that do
-        //  not exist, which nobody would write again: those are set back to their zeros)
-        if (pl->n_fanout > 0 && fl.oth_off >= 0 && (pl->d_init[0] || pl->d_init[1]))
-            if (int rc = zero_padding(pl, pl->msg_all, pl->n_groups * JT_MSETS, s, fl.oth_off ? 2 : 1)) return rc;
         if (prof) {
             if (!mid_done) HIP_TRY(hipEventRecord(pl->ev[ev_base + 1], s));
             HIP_TRY(hipEventRecord(pl->ev[ev_base + 2], s));
@@ -1775,6 +1791,21 @@ int jtp_sync(jtp_plan *pl) {
 
 // ------------------------------------------------------------------------------------------ data out
 
+// Multi-set plans with active lists (rebuild_active): the upward message of a (collect task, arena slot) that is NOT on the task's list
+// exists in slot 0's arena only - nobody copies it into the set's own (round 5 did, after every propagate: 7 % of a 64-set step).  A
+// read-out task of evidence set `batch` takes its inputs from that set's arena; an input formed by such a task has its offset moved
+// back by the slot's distance, i.e. is read from slot 0.  `member_host` describes the lists the LAST propagate ran with.
+static bool readout_redirect(const jtp_plan *pl, int batch, JtTask &tk) {
+    if (!pl->multiset || pl->set0 == 0 || pl->member_host.empty()) return false;
+    const size_t cap = (size_t)pl->n_groups * JT_MSETS, slot = (size_t)(pl->set0 + batch);
+    bool any = false;
+    for (int k = 0; k < tk.n_in; ++k) {
+        const int t = tk.msg[k].src_task;
+        if (t >= 0 && !pl->member_host[(size_t)t * cap + slot]) tk.msg[k].off -= (int64_t)slot * pl->set_stride, any = true;
+    }
+    return any;
+}
+
 int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_t host_dtype) {
     int rc = check_ready(pl, batch);
     if (rc) return rc;
@@ -1819,10 +1850,17 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
                 HIP_TRY(hipMalloc((void **)&bt.d_blk, blocks.size() * sizeof(JtBlock)));
                 HIP_TRY(hipMalloc((void **)&bt.d_tab, std::max<size_t>(itab.size(), 1) * sizeof(int32_t)));
                 HIP_TRY(hipMemcpy(bt.d_task, &tk, sizeof tk, hipMemcpyHostToDevice));
+                bt.h_task = tk;
                 HIP_TRY(hipMemcpy(bt.d_blk, blocks.data(), blocks.size() * sizeof(JtBlock), hipMemcpyHostToDevice));
                 if (!itab.empty()) HIP_TRY(hipMemcpy(bt.d_tab, itab.data(), itab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
                 bt.nblocks = (int)blocks.size();
                 bt.lds = tk.lds_bytes;
+            }
+            if (pl->multiset && pl->set0) {              // (which inputs come from the evidence-free set's arena depends on the set)
+                JtTask patched = bt.h_task;
+                readout_redirect(pl, batch, patched);
+                HIP_TRY(hipStreamSynchronize(s));        // (an earlier read-out's kernel may still read the record)
+                HIP_TRY(hipMemcpy(bt.d_task, &patched, sizeof patched, hipMemcpyHostToDevice));
             }
             JtFlow one;
             memset(&one, 0, sizeof one);
@@ -1873,10 +1911,14 @@ int jtp_get_belief(jtp_plan *pl, int32_t batch, int32_t node, void *host, int32_
     const int grid = (int)std::min<int64_t>((stride + 255) / 256, 4096);
     const int64_t pstride = (int64_t)1 << sp.nbits;
     const double *cur = b.msg + b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));      // the half the last propagate wrote
+    const double *cur_up = cur;
+    if (pl->multiset && pl->set0 && !pl->member_host.empty() && sp.child >= 0 && hp.pn[sp.child].collect_task >= 0 &&
+        !pl->member_host[(size_t)hp.pn[sp.child].collect_task * ((size_t)pl->n_groups * JT_MSETS) + (size_t)(pl->set0 + batch)])
+        cur_up = pl->msg_all + b.cur_off(std::max<int64_t>(hp.msg_doubles, 2));       // (readout_redirect: the evidence-free set's upward message)
     if (host_dtype == JTP_F32)
-        hipLaunchKernelGGL((jt_msg_unpack<float>), dim3(grid), dim3(256), 0, s, d, cur + sp.up_roff, sp.up_rnpart, cur + sp.dn_roff, sp.dn_rnpart, pstride, (float *)pl->stage);
+        hipLaunchKernelGGL((jt_msg_unpack<float>), dim3(grid), dim3(256), 0, s, d, cur_up + sp.up_roff, sp.up_rnpart, cur + sp.dn_roff, sp.dn_rnpart, pstride, (float *)pl->stage);
     else
-        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, cur + sp.up_roff, sp.up_rnpart, cur + sp.dn_roff, sp.dn_rnpart, pstride, (double *)pl->stage);
+        hipLaunchKernelGGL((jt_msg_unpack<double>), dim3(grid), dim3(256), 0, s, d, cur_up + sp.up_roff, sp.up_rnpart, cur + sp.dn_roff, sp.dn_rnpart, pstride, (double *)pl->stage);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, pl->stage, (size_t)stride * hsz, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -2046,6 +2088,7 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         mb = new MargBatch();
         mb->lean_nblocks = n_lean_blocks;
         mb->lean_lds = lean_lds;
+        if (pl->multiset && pl->set0) mb->h_tasks = tasks;
         mb->key = key;
         mb->n = n;
         mb->nblocks = (int)blocks.size();
@@ -2079,6 +2122,12 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
             pl->marg_cache.erase(pl->marg_cache.begin());
         }
         pl->marg_cache.push_back(mb);
+    }
+    if (!mb->h_tasks.empty()) {                          // (multi-set plans with active lists: readout_redirect, per evidence set)
+        std::vector<JtTask> patched = mb->h_tasks;
+        for (JtTask &tk : patched) readout_redirect(pl, batch, tk);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(mb->d_tasks, patched.data(), patched.size() * sizeof(JtTask), hipMemcpyHostToDevice));
     }
     // the kernels that are actually launched below must be allowed this much dynamic LDS
     if (mb->nblocks > 0)

@@ -217,10 +217,9 @@ struct JtFlow {
     uint32_t n_blocks;         // ... and workgroup records per group
     int64_t out_shift;         // added to the address of every outgoing entry (doubles): read-out tasks of multi-set
                                // plans read one set's message arena and write into a scratch buffer elsewhere
-    // multi-set launches: group 0 holds EVIDENCE-FREE sets only; skip[g * n_tasks + t] != 0 = no set of group g observes a variable
-    // in the subtree below task t's clique - the upward message of those sets equals group 0's: the task's workgroups of group g end
-    // at once, its consumers read group 0's copy (JtMsg::src_task), and a copy pass behind the propagate (jt_multi_fanout) puts
-    // the message into the sets' own arenas for the read-out (null: every group computes everything)
+    // multi-set launches with active lists (below): skip[task * cap + slot] != 0 = arena slot `slot` is on the task's list.  A consumer
+    // of an upward message (JtMsg::src_task = the collect task that forms it) takes the entries of every other slot from slot 0, the
+    // evidence-free set (null: every set runs every task)
     const uint8_t *skip;
     uint32_t n_tasks;
     uint32_t cap;              // multi-set launches with active lists: arena slots in all (groups x JT_MSETS)

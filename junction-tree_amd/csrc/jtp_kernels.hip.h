@@ -2442,42 +2442,30 @@ __device__ __forceinline__ void jt_mpass(const JtTask &tk, const JtBlock &bk, co
 #endif
 }
 
-// Evidence-free subtrees (round 5).  Group 0 of a multi-set launch holds evidence-free sets only.  Where no set of group g observes
-// a variable in the subtree below a clique, the upward message of every set of g IS group 0's (with 16 observed variables per set a
-// set's evidence touches at most 16 of 256 cliques: a third of the collect tasks of a group of eight sets meet no evidence at
-// all): that task's workgroups of group g end at once (JtFlow::skip), its consumers stage group 0's copy (JtMsg::src_task), and
-// this copy pass behind the propagate puts the message into the eight sets' own arenas - values in this propagate's half, the
-// "unwritten" marker in the other, exactly what the producer would have left - for the read-out and for the next propagate.
-#define JT_FANOUT_MARK_ONLY 0x40000000
+// Evidence-free subtrees (rounds 5-6).  Arena slot 0 of a multi-set plan holds a set that observes nothing.  The upward message of a
+// clique below which a set observes nothing IS slot 0's: the set is not on that collect task's active list (JtFlow::act_ids), consumers
+// and the read-out take the message from slot 0 (JtFlow::skip / jtp_engine.hip readout_redirect), and the set's own entries of it stay
+// "unwritten" in both arena halves - which this pass restores, once, for the (task, set) pairs that LEAVE a list when the evidence changes.
+#define JT_FANOUT_RESET 0x20000000
 struct JtFanout {
-    int64_t off;               // msg-arena offset (doubles) of what consumers read of the message (the reduced sum where there is one)
+    int64_t off;               // msg-arena offset (doubles) of the entries
     int32_t count;             // doubles
-    int32_t flags;             // JT_FANOUT_MARK_ONLY: nothing is copied, the entries of the OTHER arena half are marked "unwritten" (the
-                               // partial copies a producer that did not run would have re-armed)
-    uint16_t slot[JT_MSETS];   // the arena slots that receive it (0xffff: none)
+    int32_t flags;             // JT_FANOUT_RESET: the entries of BOTH arena halves of the listed slots become "unwritten"
+    uint16_t slot[JT_MSETS];   // the arena slots concerned (0xffff: none)
 };
 #ifndef JT_INST_TU
+// (fl.oth_off: the distance of the second arena half from the first)
 __global__ __launch_bounds__(256) void jt_multi_fanout(const JtFanout *__restrict__ list, double *__restrict__ msg, JtFlow fl) {
     const JtFanout f = list[blockIdx.x];
-    const double *src = msg + fl.cur_off + f.off;                                  // (arena slot 0: the evidence-free set)
-    if (f.flags & JT_FANOUT_MARK_ONLY) {
-        if (fl.oth_off < 0) return;
-        for (int i = threadIdx.x; i < f.count; i += 256)
-#pragma unroll
-            for (int s = 0; s < JT_MSETS; ++s)
-                if (f.slot[s] != 0xffffu) msg[(int64_t)f.slot[s] * fl.set_stride + f.off + i + fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
-        return;
-    }
-    for (int i = threadIdx.x; i < f.count; i += 256) {
-        const double v = src[i];
+    if (!(f.flags & JT_FANOUT_RESET)) return;
+    for (int i = threadIdx.x; i < f.count; i += 256)
 #pragma unroll
         for (int s = 0; s < JT_MSETS; ++s) {
             if (f.slot[s] == 0xffffu) continue;
             double *base = msg + (int64_t)f.slot[s] * fl.set_stride + f.off + i;
-            base[fl.cur_off] = v;
-            if (fl.oth_off >= 0) base[fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
+            base[0] = __longlong_as_double((long long)JT_UNWRITTEN);
+            base[fl.oth_off] = __longlong_as_double((long long)JT_UNWRITTEN);
         }
-    }
 }
 #endif
 

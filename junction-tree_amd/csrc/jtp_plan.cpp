@@ -2431,19 +2431,25 @@ int jtp_build_plan(const jtp_tree_desc *d, HostPlan &hp, std::string &err) {
 // incoming messages of a clique for the read-out tasks: the parent's final downward message, every child's
 // final upward message (what consumers read: the reduced sum where a reduce task exists)
 // (a unit clique's static table comes with them: src.second = -1 marks it, JtMsg::fixed)
-static void neighbour_inputs(const HostPlan &hp, const PNode &p, std::vector<MsgView> &ins, std::vector<std::pair<int64_t, int>> &src) {
+// (`from`: per input, the collect task that forms it - an upward message - or -1: JtMsg::src_task, which tells the engine whose arena a
+//  multi-set plan's read-out takes the message from, jtp_engine.hip readout_redirect)
+static void neighbour_inputs(const HostPlan &hp, const PNode &p, std::vector<MsgView> &ins, std::vector<std::pair<int64_t, int>> &src,
+                             std::vector<int> &from) {
     if (p.psep >= 0) {
         ins.push_back(make_view(p, hp.ps[p.psep], p.psep, false));
         src.push_back({hp.ps[p.psep].dn_roff, hp.ps[p.psep].dn_rnpart});
+        from.push_back(-1);
     }
     if (p.stat >= 0) {
         ins.push_back(make_view(p, hp.statics[p.stat]));
         src.push_back({hp.statics[p.stat].off, -1});
+        from.push_back(-1);
     }
     for (int k : p.children) {
         const PSep &sp = hp.ps[hp.pn[k].psep];
         ins.push_back(make_view(p, sp, hp.pn[k].psep, true));
         src.push_back({sp.up_roff, sp.up_rnpart});
+        from.push_back(hp.pn[k].collect_task);
     }
 }
 
@@ -2478,8 +2484,9 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<std:
     tk.mode = 0;                                 // (several outputs: every one of them the sum over its own complement)
     std::vector<MsgView> ins, outs;
     std::vector<std::pair<int64_t, int>> src;
+    std::vector<int> from;
     // multi-set plans keep no belief table: the marginal is taken of psi * (every incoming message) directly
-    if (with_neighbours) neighbour_inputs(hp, p, ins, src);
+    if (with_neighbours) neighbour_inputs(hp, p, ins, src, from);
     if ((int)ins.size() > JT_MAX_IN) FAIL(JTP_EUNSUPPORTED, "clique with %zu neighbours", ins.size());
     for (const PSep &s : seps) outs.push_back(make_view(p, s, -1, true));
     int real_bits = 0;
@@ -2498,6 +2505,7 @@ int jtp_plan_marginal_task(const HostPlan &hp, int pnode, const std::vector<std:
         tk.msg[k].npart = src[k].second < 0 ? 1 : src[k].second;
         tk.msg[k].fixed = src[k].second < 0 ? 1 : 0;
         tk.msg[k].same_launch = 0;
+        tk.msg[k].src_task = from[k];
     }
     npart.clear();
     for (size_t j = 0; j < out_vars.size(); ++j) npart.push_back(tk.msg[JT_MAX_IN + j].npart);
@@ -2517,7 +2525,8 @@ int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<
     tk.mode = 1;
     std::vector<MsgView> ins, outs;
     std::vector<std::pair<int64_t, int>> src;
-    neighbour_inputs(hp, p, ins, src);
+    std::vector<int> from;
+    neighbour_inputs(hp, p, ins, src, from);
     if ((int)ins.size() > JT_MAX_IN) FAIL(JTP_EUNSUPPORTED, "clique with %zu neighbours", ins.size());
     int real_bits = 0;
     for (int nb : p.nb) real_bits += nb;
@@ -2534,6 +2543,7 @@ int jtp_plan_belief_task(const HostPlan &hp, int pnode, JtTask &tk, std::vector<
         tk.msg[k].npart = src[k].second < 0 ? 1 : src[k].second;
         tk.msg[k].fixed = src[k].second < 0 ? 1 : 0;
         tk.msg[k].same_launch = 0;
+        tk.msg[k].src_task = from[k];
     }
     blocks.clear();
     for (uint32_t f = 0; f < (1u << tk.nF); ++f) blocks.push_back(jtp_make_block(hp, tk, 0u, f));

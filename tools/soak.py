@@ -80,3 +80,43 @@ assert bad == 0 and all(x["flow_fallbacks"] == 0 for x in st)
 for pl in plans:
     pl.close()
 print("soak ok")
+# (round 6) the lean unit pass: a lattice whose junction tree is mostly cliques that keep no table, through the public API
+import junctiontree_amd as jt
+factors, sizes, values = synthetic.lattice_mrf(6, 40, 8)
+tree = jt.create_junction_tree(factors, sizes)
+first = tree.propagate(values)
+plan = tree.plan("f32")
+n_lean = sum(1 for t in plan.describe()["tasks"] if t["lean_off"] > 0)
+t0 = time.perf_counter()
+bad = 0
+for i in range(reps):
+    plan.propagate(sync=False)
+    if i % 100 == 99:
+        out = plan.factor_marginals(tree.clique_tree.factor_graph.factors, tree.clique_tree.factor_to_maxclique)
+        bad += sum(not np.array_equal(a, b) for a, b in zip(out, first))
+plan.sync()
+print("lean    %5d propagates  %.1f s  mismatching checks %d  fallbacks %d  (%d lean tasks, %d cliques without a table)"
+      % (reps, time.perf_counter() - t0, bad, plan.stats()["flow_fallbacks"], n_lean, plan.stats()["n_unit_cliques"]))
+assert bad == 0 and plan.stats()["flow_fallbacks"] == 0 and n_lean > 0
+engine.clear_plan_cache()
+# (round 6) the active lists of a multi-set plan: 64 evidence sets, an evidence-free set, the same evidence every propagate
+spec = synthetic.wide_binary_tree(n_cliques=63, width=16, sep=8, card=2, seed=21)
+plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", n_batch=64, multiset=True)
+plan.fill_synthetic(3, spec["scales"])
+labels = sorted(spec["sizes"])
+for b in range(64):
+    rng = np.random.default_rng(500 + b)
+    plan.set_evidence({labels[i]: int(rng.integers(0, 2)) for i in rng.choice(len(labels), size=6, replace=False)}, batch=b)
+plan.propagate(0, 64)
+z0 = [plan.z(batch=b) for b in range(64)]
+t0 = time.perf_counter()
+bad = 0
+for i in range(reps // 4):
+    plan.propagate(0, 64, sync=False)
+    if i % 50 == 49:
+        plan.sync()
+        bad += sum(plan.z(batch=b) != z0[b] for b in range(0, 64, 5))
+plan.sync()
+print("multi64 %5d x 64 propagates  %.1f s  mismatching checks %d  fallbacks %d" % (reps // 4, time.perf_counter() - t0, bad, plan.stats()["flow_fallbacks"]))
+assert bad == 0 and plan.stats()["flow_fallbacks"] == 0
+plan.close()
