@@ -171,7 +171,8 @@ struct JtLeanMsg {             // 32 ints
     int32_t src;               // the message's index in JtTask::msg / JtBlock::gbase
     int32_t e_w[2];            // sub-box slot weights of the element bits
     int32_t w_lo[8];           // place in the MESSAGE of sub-box index bit b, b = 0..7 (as a weight: 1 << free_pos[b]; 0: b >= nfree)
-    int32_t w_hi[8];           // ... b = 8..12 (three spare)
+    int32_t w_hi[8];           // ... b = 8..12; read-out tasks (jt_lean_single): [5] = partial copies of an incoming message (summed in copy
+                               // order while staging; tasks of a propagate: always one), [6] = doubles between them; [7] spare
     int32_t t_w[8];            // sub-box slot weights of the six lane bits, then the two wave bits
 };
 struct JtLean {                // 5 * 32 + 16 = 176 ints (+ JtLeanMore)

@@ -1283,7 +1283,8 @@ __global__ __launch_bounds__(JT_THREADS) void jt_reduce_level(const JtTask *__re
 // NOUT > 1 (read-out tasks only, jt_unit_single: up to three marginals of psi x every incoming table of a unit clique in one pass): every
 // output accumulates the same product and folds after its own runs of rows; outputs 1 and 2 are described by the JtLeanMore record
 // behind the lean record.
-template <typename T, int NIN, int NE, bool FLOW, int NOUT = 1>
+// COPIES (read-out tasks only): an incoming message may have several partial copies (JtLeanMsg::w_hi[5]), summed in copy order.
+template <typename T, int NIN, int NE, bool FLOW, int NOUT = 1, bool COPIES = false>
 __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk, const int *__restrict__ itab,
                                              double *__restrict__ msg_arena, const JtFlow &fl, uint32_t *flow_ctl) {
     constexpr int VEC = 16 / sizeof(T);               // elements of a thread per row (the plan's thread part: 256 threads x VEC)
@@ -1378,7 +1379,20 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
                     if ((it0 + u) * JT_THREADS + tid >= nent[k]) continue;
                     if (FLOW) c[k][u] = jt_msg_settle<FLOW>(at[k][u], c[k][u], thr_mem[k], settle_attempt);
                     if (FLOW && jt_unwritten(c[k][u])) unready = at[k][u];
-                    sub[(it0 + u) * JT_THREADS + tid] = 0.0 + c[k][u];
+                    double sum = 0.0 + c[k][u];
+                    if constexpr (COPIES) {
+                        const int ncopy = ln.in[k].w_hi[5];
+                        const int64_t cstride = ln.in[k].w_hi[6];
+                        for (int p0 = 1; p0 < ncopy; p0 += 4) {
+                            double d[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) d[q] = p0 + q < ncopy ? jt_msg_load<FLOW>(at[k][u] + (int64_t)(p0 + q) * cstride, thr_mem[k]) : 0.0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (p0 + q < ncopy) sum += d[q];
+                        }
+                    }
+                    sub[(it0 + u) * JT_THREADS + tid] = sum;
                 }
             }
         }
@@ -1639,9 +1653,9 @@ template <typename T>
 __device__ __forceinline__ void jt_unit_lean_readout(const JtLean &ln, const JtBlock &bk, const int *__restrict__ itab,
                                                      double *__restrict__ msg, const JtFlow &fl) {
 #define JT_LEAN_OUT(NIN, NE)                                                                          \
-    if (ln.n_out == 1) jt_unit_lean<T, NIN, NE, false, 1>(ln, bk, itab, msg, fl, nullptr);            \
-    else if (ln.n_out == 2) jt_unit_lean<T, NIN, NE, false, 2>(ln, bk, itab, msg, fl, nullptr);       \
-    else jt_unit_lean<T, NIN, NE, false, 3>(ln, bk, itab, msg, fl, nullptr);                          \
+    if (ln.n_out == 1) jt_unit_lean<T, NIN, NE, false, 1, true>(ln, bk, itab, msg, fl, nullptr);            \
+    else if (ln.n_out == 2) jt_unit_lean<T, NIN, NE, false, 2, true>(ln, bk, itab, msg, fl, nullptr);       \
+    else jt_unit_lean<T, NIN, NE, false, 3, true>(ln, bk, itab, msg, fl, nullptr);                          \
     break
     switch (ln.n_in * 8 + ln.n_e) {
         case 0: JT_LEAN_OUT(0, 0);

@@ -646,8 +646,11 @@ void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, b
     //  tasks, whose kernel is off the hot path: up to three marginals of psi x ALL incoming tables of a unit clique)
     const int max_in = readout ? JT_MAX_IN : 3, max_out = readout ? JT_MAX_OUT : 1;
     if (tk.kind != 0 || !tk.unit || tk.mode != 0 || tk.n_out < 1 || tk.n_out > max_out || tk.n_in > max_in || tk.bel_off >= 0 || tk.vgroups) return;
-    for (int k = 0; k < tk.n_in; ++k)
-        if (tk.msg[k].npart != 1) return;
+    // (incoming messages of several partial copies: the generic pass splits the copies of a small sub-box over the threads, which the
+    //  lock-step staging of the lean pass does not - measured slower inside a propagate; the read-out kernel takes them, copy after copy)
+    if (!readout)
+        for (int k = 0; k < tk.n_in; ++k)
+            if (tk.msg[k].npart != 1) return;
     if ((tk.debug & ~2) != 0) return;                 // (the JTP_DEBUG timing experiments are switches of the generic pass)
     JtLean ln;
     JtLeanMore more;
@@ -661,7 +664,8 @@ void jtp_make_lean(const HostPlan &hp, JtTask &tk, std::vector<int32_t> &itab, b
         lm.src = src;
         lm.e_w[0] = m.e_w[0], lm.e_w[1] = m.e_w[1];
         for (int b = 0; b < 8; ++b) lm.w_lo[b] = b < m.nfree ? 1 << m.free_pos[b] : 0;
-        for (int b = 0; b < 8; ++b) lm.w_hi[b] = 8 + b < m.nfree ? 1 << m.free_pos[8 + b] : 0;
+        for (int b = 0; b < 5; ++b) lm.w_hi[b] = 8 + b < m.nfree ? 1 << m.free_pos[8 + b] : 0;
+        lm.w_hi[5] = m.npart, lm.w_hi[6] = m.pstride, lm.w_hi[7] = 0;
         for (int t = 0; t < 8; ++t) lm.t_w[t] = m.t_w[t];
     };
     int n = 0;

@@ -502,6 +502,8 @@ class _FactorTables:
         self.recs = recs
         self.n_f = n_f
         self.prev = None             # the small tables as last staged
+        # every table small, of one shape, at least one axis: `stage` joins them without touching each
+        self.all_small_alike = bool(n_f > 0 and len(self.big_idx) == 0 and len(shapes[0]) >= 1 and all(tuple(sh) == tuple(shapes[0]) for sh in shapes))
         self.src = (None, None)      # the caller's list objects this was last used with (Plan.stage_factors)
         self.is_small = small
         self.mine = np.asarray([plan.owns(c) for c in plan.cliques], dtype=bool)
@@ -529,10 +531,16 @@ class _FactorTables:
         else:
             if named is not None and named != "all" and isinstance(named, str):
                 raise ValueError('changed: "all" or an iterable of factor indices')
-            if len(self.small_idx):
+            if self.all_small_alike:
+                # (a pairwise model: 1831 tables of one shape - joined along their first axis, which is the same memory as the
+                #  flattened tables one after the other, without a reshape per table)
+                flat = np.concatenate(arrs, dtype=self.np_dtype).reshape(-1)
+            elif len(self.small_idx):
                 flat = np.concatenate([arrs[i].reshape(-1) for i in self.small_idx], dtype=self.np_dtype)
             else:
                 flat = np.empty(0, dtype=self.np_dtype)
+            if len(flat) != self.small_off[-1]:
+                raise ValueError("the factor tables changed their shapes")
             if self.prev is not None and named is None:
                 changed = np.zeros(n_f, dtype=bool)
                 changed[self.big_idx] = True

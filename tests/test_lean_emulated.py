@@ -291,7 +291,8 @@ def test_lean_records_say_what_the_task_records_say():
                 assert lm["flags"] == (1 if m["same_launch"] else 0) | (2 if m["fixed"] else 0)
                 fp = list(m["free_pos"]) + [None] * 16
                 assert lm["w_lo"] == [1 << fp[b] if b < m["nfree"] else 0 for b in range(8)]
-                assert lm["w_hi"] == [1 << fp[8 + b] if 8 + b < m["nfree"] else 0 for b in range(8)]
+                assert lm["w_hi"][:5] == [1 << fp[8 + b] if 8 + b < m["nfree"] else 0 for b in range(5)]
+                assert lm["w_hi"][5:] == [m["npart"], m["pstride"], 0]
                 assert lm["t_w"] == list(m["t_w"]) and lm["e_w"] == list(m["e_w"])
             out = tk["out"][0]
             assert (red_e, red_lane, red_wave, out_pstride) == (out["red_e"], out["red_lane"], out["red_wave"], out["pstride"])
