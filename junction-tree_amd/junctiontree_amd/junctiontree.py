@@ -215,7 +215,10 @@ class JunctionTree:
         changed skips that - and vouches that the factor structure and every other table are what they were."""
         ct = self.clique_tree
         trusted = changed is not None and "plan" in self._memo
-        all_f32 = all(type(x) is np.ndarray and x.dtype == np.float32 for x in xs)
+        if trusted and "all_f32" in self._memo:          # (the caller vouches for the structure - shapes and dtypes with it)
+            all_f32 = self._memo["all_f32"]
+        else:
+            all_f32 = self._memo["all_f32"] = all(type(x) is np.ndarray and x.dtype == np.float32 for x in xs)
         plan = self.plan("f32" if all_f32 else "f64", trusted=trusted)
         # evaluate (junctiontree.py:203-226) on the device: only factor tables cross PCIe, and only those of
         # cliques whose factors changed since this plan last saw them (the reference recomputes every clique on
