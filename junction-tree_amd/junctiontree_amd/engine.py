@@ -611,15 +611,14 @@ class _MarginalRequests:
         self.bounds = out_off
         # (runs of equally shaped results are cut out of the buffer with one reshape: a pairwise model has thousands)
         self.uniform = len(set(self.shapes)) == 1 and n > 0 and len(self.shapes[0]) > 0
+        self._args = (self.cliques.ctypes.data_as(C.POINTER(C.c_int32)), self.var_off.ctypes.data_as(C.POINTER(C.c_int32)),
+                      self.var_ids.ctypes.data_as(C.POINTER(C.c_int32)), self.out_off.ctypes.data_as(C.POINTER(C.c_int64)))
 
     def read(self, plan, batch):
         if self.n == 0:
             return []
         flat = np.empty(self.bounds[-1], dtype=np.float64)
-        _capi.check(plan._lib.jtp_get_marginals(
-            plan._handle, batch, self.n, self.cliques.ctypes.data_as(C.POINTER(C.c_int32)),
-            self.var_off.ctypes.data_as(C.POINTER(C.c_int32)), self.var_ids.ctypes.data_as(C.POINTER(C.c_int32)),
-            self.out_off.ctypes.data_as(C.POINTER(C.c_int64)), flat.ctypes.data_as(C.POINTER(C.c_double))))
+        _capi.check(plan._lib.jtp_get_marginals(plan._handle, batch, self.n, *self._args, flat.ctypes.data_as(C.POINTER(C.c_double))))
         if self.uniform:
             return list(flat.reshape((self.n,) + self.shapes[0]))
         b = self.bounds

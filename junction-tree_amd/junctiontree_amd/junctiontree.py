@@ -193,9 +193,13 @@ class JunctionTree:
         # and a weak reference to the plan it was last given for (dtype, the sizes as they are NOW, its options, and the
         # factor structure its cover was computed from - by value: a recomputed cover may reuse the old list's id)
         sizes = self.clique_tree.factor_graph.sizes
+        hit = self._memo.get("plan")
+        if trusted and hit is not None and hit[0][0] == dtype:      # (`propagate(xs, changed=...)`: sizes, options and factors are vouched for)
+            plan = engine.cached_plan(hit[1], hit[2]())
+            if plan is not None:
+                return plan
         cover = self.cover(trusted=trusted)
         mark = (dtype, tuple(sizes.items()), tuple(sorted(self._opts.items())), self._memo["cover"][0])
-        hit = self._memo.get("plan")
         if hit is not None and hit[0] == mark:
             plan = engine.cached_plan(hit[1], hit[2]())
             if plan is not None:
