@@ -275,10 +275,12 @@ class Plan:
             self.staged_cliques = ft.stage(self, xs, changed)       # (what is looked at is converted there)
             return self.staged_cliques
         arrs = [x if type(x) is np.ndarray else np.asarray(x) for x in xs]
+        shapes = [a.shape for a in arrs]
         all_f32 = all(a.dtype == np.float32 for a in arrs)
-        key = (tuple(map(tuple, factor_labels)), tuple(factor_to_clique), [a.shape for a in arrs], all_f32)
-        if ft is None or ft.key != key:
-            ft = self._factor_tables = _FactorTables(self, key)
+        # (the structure is compared by VALUE on every call - against list copies, with list.__eq__: a tuple key of 1831 label lists
+        #  built anew per call was 0.3 ms of config 3's 7)
+        if ft is None or not (ft.all_f32 == all_f32 and ft.shapes == shapes and ft.f2c == list(factor_to_clique) and _same_lists(ft.labels, factor_labels)):
+            ft = self._factor_tables = _FactorTables(self, (tuple(map(tuple, factor_labels)), tuple(factor_to_clique), shapes, all_f32))
         ft.src = (factor_labels, factor_to_clique)
         self.staged_cliques = ft.stage(self, arrs)
         return self.staged_cliques
@@ -290,9 +292,8 @@ class Plan:
         req = self.__dict__.get("_marginal_requests")
         if trusted and req is not None and req.src[0] is factor_labels and req.src[1] is factor_to_clique:
             return req.read(self, batch)
-        key = (tuple(map(tuple, factor_labels)), tuple(factor_to_clique))
-        if req is None or req.key != key:
-            req = self._marginal_requests = _MarginalRequests(self, key)
+        if req is None or not (req.f2c == list(factor_to_clique) and _same_lists(req.labels, factor_labels)):
+            req = self._marginal_requests = _MarginalRequests(self, (tuple(map(tuple, factor_labels)), tuple(factor_to_clique)))
         req.src = (factor_labels, factor_to_clique)
         return req.read(self, batch)
 
@@ -455,6 +456,8 @@ class _FactorTables:
     def __init__(self, plan, key):
         labels, f2c, shapes, all_f32 = key
         self.key = key
+        # (what later calls are compared with: plain lists, so that `==` against the caller's lists runs in C)
+        self.labels, self.f2c, self.shapes, self.all_f32 = [list(l) for l in labels], list(f2c), list(shapes), all_f32
         self.np_dtype = np.float32 if all_f32 else np.float64
         n_f = len(labels)
         if len(f2c) != n_f or len(shapes) != n_f:
@@ -594,6 +597,7 @@ class _MarginalRequests:
     def __init__(self, plan, key):
         labels, f2c = key
         self.key = key
+        self.labels, self.f2c = [list(l) for l in labels], list(f2c)
         self.src = (None, None)      # the caller's list objects this was last used with (Plan.factor_marginals)
         n = len(labels)
         var_ids, var_off, out_off, self.shapes = [], [0], [0], []
@@ -703,6 +707,17 @@ def plan_cache_info():
     return dict(_cache_stats, plans=len(_cache), device_bytes=sum(_plan_bytes(p) for p in _cache.values()),
                 widened=sum(1 for p in _cache.values() if p.dtype != p.requested_dtype),
                 budget_bytes=_budget(first.device) if first is not None else _cache_budget)
+
+
+def _same_lists(stored, given):
+    """`given` (the caller's label lists, or any sequence of sequences) names what `stored` (a list of lists) does.  The common case -
+    lists of lists - is one C-level `==`; anything else is converted first."""
+    if given == stored:
+        return True
+    try:
+        return [list(x) for x in given] == stored
+    except TypeError:
+        return False
 
 
 class _Key:

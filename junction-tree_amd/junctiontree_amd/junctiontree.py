@@ -162,12 +162,13 @@ class JunctionTree:
         plan keeps no full-size table for a clique that is mostly such axes (`engine.Plan(cover=...)`).  `trusted`: the caller
         vouches that the factor lists are what they were at the last call (`propagate(xs, changed=...)`): the remembered
         cover is returned without looking at them."""
+        from .engine import _same_lists as engine_same_lists
         ct = self.clique_tree
         hit = self._memo.get("cover")
         if trusted and hit is not None:
             return hit[1]
-        mark = (tuple(map(tuple, ct.factor_graph.factors)), tuple(ct.factor_to_maxclique))
-        if hit is not None and hit[0] == mark:
+        # (compared by value against list copies - list.__eq__ runs in C; hit[0] is a version number `plan` keys on)
+        if hit is not None and hit[3] == list(ct.factor_to_maxclique) and engine_same_lists(hit[2], ct.factor_graph.factors):
             return hit[1]
         cover = [[] for _ in ct.maxcliques]
         scalar = [False] * len(ct.maxcliques)
@@ -179,7 +180,7 @@ class JunctionTree:
         for mc, clique in enumerate(ct.maxcliques):
             if scalar[mc]:                                   # (a factor without variables is a value no axis carries: the clique keeps its table)
                 cover[mc] = list(clique)
-        self._memo["cover"] = (mark, cover)
+        self._memo["cover"] = ((hit[0] + 1) if hit is not None else 0, cover, [list(f) for f in ct.factor_graph.factors], list(ct.factor_to_maxclique))
         return cover
 
     def plan(self, dtype="f64", trusted=False):
