@@ -101,6 +101,17 @@ typedef struct jtp_tree_desc {
      * most of it; jtp_plan_describe says which.)  Ignored by JTP_MULTISET plans. */
     const int32_t *cover_off;       /* [n_cliques+1] CSR offsets into cover_ids, or NULL          */
     const int32_t *cover_ids;       /* covered variable ids of each clique (a subset of its own)  */
+    /* The marginals the caller asks for after every propagate (round 6; 0 / NULL: none named): the list jtp_get_marginals will be
+     * called with - per request a clique and the variables to keep, in that order.  JunctionTree.propagate returns factor marginals
+     * only (junctiontree/junctiontree.py:264-274, 327-331), so the list is known when the plan is made.  Requests on cliques that keep
+     * no table are then formed INSIDE the propagate's launch - tasks of their own on the level of the clique's downward messages,
+     * filling slots the dependent levels leave idle - and a jtp_get_marginals call with exactly this list only unpacks them.  A hint:
+     * any other list, an evidence set that observes something, or a plan whose launches cannot take such tasks is served as before. */
+    int32_t fold_n;
+    int32_t fold_pad;
+    const int32_t *fold_cliques;    /* [fold_n] clique of each request                            */
+    const int32_t *fold_var_off;    /* [fold_n+1] CSR offsets into fold_var_ids                   */
+    const int32_t *fold_var_ids;    /* the variables each request keeps                           */
 } jtp_tree_desc;
 
 /* Counters of the last jtp_propagate (device time needs jtp_set_profiling(plan, 1)). */

@@ -236,6 +236,10 @@ struct BatchBuffers {
 // device tables of one list of marginal requests (jtp_get_marginals), kept for the next call
 struct MargBatch {
     int lean_nblocks = 0, lean_lds = 0;  // the first workgroups of the unit list have a lean record (jt_lean_single)
+    // the list is the one the plan was made with (jtp_tree_desc.fold_*) and every request on a clique without a table was folded into
+    // the propagate: `d_descs_fold` says where the propagate left them; the unit launches are then skipped (jtp_get_marginals)
+    bool folded = false;
+    JtMargDesc *d_descs_fold = nullptr;
     std::vector<JtTask> h_tasks;         // multi-set plans with active lists: the records as planned (readout_redirect patches copies of them)
     std::vector<int32_t> key;            // n, cliques, var_off, var_ids
     JtTask *d_tasks = nullptr;
@@ -254,6 +258,7 @@ struct MargBatch {
         if (d_blocks) (void)hipFree(d_blocks);
         if (d_itab) (void)hipFree(d_itab);
         if (d_descs) (void)hipFree(d_descs);
+        if (d_descs_fold) (void)hipFree(d_descs_fold);
         if (scratch) (void)hipFree(scratch);
         if (stage) (void)hipFree(stage);
     }
@@ -2111,6 +2116,29 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         if (e == hipSuccess) e = hipMemcpy(mb->d_blocks, blocks.data(), blocks.size() * sizeof(JtBlock), hipMemcpyHostToDevice);
         if (e == hipSuccess && !itab.empty()) e = hipMemcpy(mb->d_itab, itab.data(), itab.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(mb->d_descs, descs.data(), descs.size() * sizeof(JtMargDesc), hipMemcpyHostToDevice);
+        // the plan's own list: where the folded tasks of the propagate leave these marginals
+        if (e == hipSuccess && !hp.folded.empty() && key == hp.fold_key && !pl->multiset) {
+            bool all = true;
+            std::vector<JtMargDesc> fd = descs;
+            for (int i = 0; i < n; ++i) {
+                const bool direct = hp.pn[cliques[i]].unit;
+                const HostPlan::FoldReq &fr = hp.folded[i];
+                if (!direct) continue;                             // (a belief table: jt_marginals, as ever)
+                if (fr.task < 0 || fr.out_bits != fd[i].d.nbits) {
+                    all = false;
+                    break;
+                }
+                fd[i].src_off = fr.off;
+                fd[i].pstride = (int64_t)1 << fr.out_bits;
+                fd[i].npart = fr.npart;
+                fd[i].in_arena = 1;
+            }
+            if (all) {
+                e = hipMalloc((void **)&mb->d_descs_fold, fd.size() * sizeof(JtMargDesc));
+                if (e == hipSuccess) e = hipMemcpy(mb->d_descs_fold, fd.data(), fd.size() * sizeof(JtMargDesc), hipMemcpyHostToDevice);
+                mb->folded = e == hipSuccess;
+            }
+        }
         if (e != hipSuccess) {
             mb->release();
             delete mb;
@@ -2140,7 +2168,19 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
     // marginalise the BELIEF tables: each is the "potential" argument of a childless collect
     if (mb->nblocks > 0)
         launch_variant(pl, JT_K_MARGINALS, mb->nblocks, mb->lds, s, mb->d_tasks, mb->d_blocks, mb->d_itab, b.bel, b.bel, mb->scratch, plain);
-    if (mb->unit_nblocks > 0) {
+    // Marginals the propagate formed itself (fold_marginals): valid when the last propagate of this evidence set ran them - a dataflow
+    // launch whose distribute segment is jt_propagate_flow, or one launch per level - and the set observes nothing (a clique that hosts
+    // an observed variable has no lean pass).  Then only the belief-table requests are computed here.
+    bool use_fold = false;
+    if (mb->folded && !b.ev_any && b.epoch > 0) {
+        if (pl->launch_mode == 0) use_fold = true;
+        else {
+            use_fold = !hp.segments.empty();
+            for (const Segment &sg : hp.segments)
+                if (sg.phase == 1 && (pl->chain || hp.tmix || !flow_both())) use_fold = false;
+        }
+    }
+    if (mb->unit_nblocks > 0 && !use_fold) {
         // cliques that keep no belief table (multi-set plans: all; else the unit cliques): psi * (the incoming tables)
         // marginalised directly - inputs from the set's message arena (and the fixed arena), outputs into the request list's
         // scratch buffer (JtFlow::out_shift)
@@ -2157,7 +2197,8 @@ int jtp_get_marginals(jtp_plan *pl, int32_t batch, int32_t n, const int32_t *cli
         if (mb->unit_nblocks > n_lean)
             launch_variant(pl, JT_K_SINGLE, mb->unit_nblocks - n_lean, mb->unit_lds, s, mb->d_tasks, mb->d_blocks + mb->nblocks + n_lean, mb->d_itab, b.psi, b.bel, b.msg, plain);
     }
-    hipLaunchKernelGGL(jt_marg_unpack, dim3(mb->max_grid_x, mb->n), dim3(256), 0, s, mb->d_descs, mb->scratch, mb->stage);
+    hipLaunchKernelGGL(jt_marg_unpack, dim3(mb->max_grid_x, mb->n), dim3(256), 0, s, use_fold ? mb->d_descs_fold : mb->d_descs, mb->scratch, mb->stage,
+                       (const double *)(b.msg + b.cur_off(std::max<int64_t>(hp.msg_doubles, 2))));
     HIP_TRY(hipGetLastError());
     bool packed = true;
     for (int i = 0; i < n; ++i) packed = packed && out_off[i + 1] - out_off[i] == mb->elems[i];

@@ -54,6 +54,7 @@
 #define JT_BLOCK_LEAN 4u       // JtBlock::flags: the task has a JtLean record, at int offset first_x[6] | first_x[7] << 32 of the table buffer (a unit task
                                // loads no rows: first_x is otherwise unused; first_x[5] = JtTask::pnode) - a dataflow workgroup reaches it without
                                // reading the task record
+#define JT_BLOCK_FOLD 16u      // JtBlock::flags (with JT_BLOCK_LEAN): a workgroup of a folded marginal task (JtTask::fold): up to four inputs, three outputs
 #define JT_BLOCK_NULL 8u       // JtBlock::flags: no workgroup - multi-set plans pad every launch's block list to a multiple of eight records, so
                                // that the eight records a run of workgroups shares (jt_multi_flow) never span two tree levels
 #define JT_BLOCK_INVALID 1u    // JtBlock::flags: the chunk's own digits do not exist - every row is the zero row (the
@@ -149,6 +150,10 @@ struct JtTask {
     int64_t tmap_off;          // plans with a mixed-radix thread part (HostPlan::tmix, kernels *_mix): offset (ints) in the table
                                // buffer of the clique's thread map - 2^TB entries, entry x = element offset inside a row of
                                // logical thread index x, or -1 where x names no table entry; else -1
+    int32_t fold;              // 1: a marginal task FOLDED into the propagate (jtp_tree_desc.fold_*): a unit clique's psi x every incoming table
+                               // summed onto one to three requested variable sets, scheduled on the level of the clique's downward messages;
+                               // runs the lean pass only (jt_unit_lean<..., NOUT>), is skipped where that cannot run (evidence on the clique)
+    int32_t pad_fold;
     int64_t lean_off;          // > 0: offset (ints, a multiple of 16) in the table buffer of this task's JtLean record - a unit task of
                                // one outgoing message whose incoming tables have one copy each runs jt_unit_lean (round 6) when its
                                // evidence set observes nothing; 0 (what a zeroed record says): the generic pass
@@ -285,7 +290,8 @@ struct JtMargDesc {
     int64_t pstride;           // doubles between partial copies
     int64_t dst_off;           // offset (doubles) in the staging buffer
     int32_t npart;
-    int32_t pad;
+    int32_t in_arena;          // 1: the partial copies were left in the MESSAGE arena by a task folded into the propagate (src_off from the
+                               // base of the half it used), not in the request list's scratch buffer
 };
 
 #define JT_EVAL_MAX_F 8        // factor tables multiplied per pass over a clique (more: further passes that multiply into the table)

@@ -1649,13 +1649,15 @@ __device__ __forceinline__ void jt_unit_lean_dispatch(const JtLean &ln, const Jt
 
 // Read-out tasks of unit cliques (jtp_get_marginals -> jt_single; no launch waits on anything): up to four incoming tables - the parent's
 // message, the static table and two children, all of them - and one to three marginals per pass.
-template <typename T>
+// FLOW: the same tasks FOLDED into a propagate's dataflow launch (JtTask::fold, jtp_plan.cpp fold_marginals): their inputs are messages of
+// this launch, waited for like any other.
+template <typename T, bool FLOW = false>
 __device__ __forceinline__ void jt_unit_lean_readout(const JtLean &ln, const JtBlock &bk, const int *__restrict__ itab,
-                                                     double *__restrict__ msg, const JtFlow &fl) {
+                                                     double *__restrict__ msg, const JtFlow &fl, uint32_t *flow_ctl = nullptr) {
 #define JT_LEAN_OUT(NIN, NE)                                                                          \
-    if (ln.n_out == 1) jt_unit_lean<T, NIN, NE, false, 1, true>(ln, bk, itab, msg, fl, nullptr);            \
-    else if (ln.n_out == 2) jt_unit_lean<T, NIN, NE, false, 2, true>(ln, bk, itab, msg, fl, nullptr);       \
-    else jt_unit_lean<T, NIN, NE, false, 3, true>(ln, bk, itab, msg, fl, nullptr);                          \
+    if (ln.n_out == 1) jt_unit_lean<T, NIN, NE, FLOW, 1, true>(ln, bk, itab, msg, fl, flow_ctl);            \
+    else if (ln.n_out == 2) jt_unit_lean<T, NIN, NE, FLOW, 2, true>(ln, bk, itab, msg, fl, flow_ctl);       \
+    else jt_unit_lean<T, NIN, NE, FLOW, 3, true>(ln, bk, itab, msg, fl, flow_ctl);                          \
     break
     switch (ln.n_in * 8 + ln.n_e) {
         case 0: JT_LEAN_OUT(0, 0);
@@ -1680,12 +1682,22 @@ __device__ __forceinline__ void jt_unit_lean_readout(const JtLean &ln, const JtB
 // A dataflow workgroup whose record says "lean" (JT_BLOCK_LEAN) goes from its workgroup record straight to the task's lean record:
 // one dependent scalar round trip less than through the task record.  (A clique that hosts an observed variable runs the generic pass;
 // first_x[5] = the task's planner node, the index of its entry of the evidence table.)
-template <typename T>
+// FOLD: the kernel can run folded marginal tasks (JT_BLOCK_FOLD; jt_propagate_flow only - the other dataflow kernels end such a
+// workgroup at once, as every kernel does where the clique hosts an observed variable: the engine then forms those marginals by
+// the read-out, jtp_get_marginals).
+template <typename T, bool FOLD = false>
 __device__ __forceinline__ bool jt_lean_block(const JtBlock &bk, const int *__restrict__ itab, double *__restrict__ msg, const JtFlow &fl,
                                               uint32_t *flow_ctl) {
-    if (!(bk.flags & JT_BLOCK_LEAN)) return false;
-    if (fl.ev != nullptr && fl.ev[2 * bk.first_x[5]] != 0) return false;      // (this clique hosts an observed variable: the generic pass)
+    if (!(bk.flags & JT_BLOCK_LEAN)) return (bk.flags & JT_BLOCK_FOLD) != 0;
+    const bool observed = fl.ev != nullptr && fl.ev[2 * bk.first_x[5]] != 0;
     const int64_t at = (int64_t)((uint64_t)bk.first_x[6] | ((uint64_t)bk.first_x[7] << 32));
+    if (bk.flags & JT_BLOCK_FOLD) {
+        if constexpr (FOLD) {
+            if (!observed) jt_unit_lean_readout<T, true>(*reinterpret_cast<const JtLean *>(itab + at), bk, itab, msg, fl, flow_ctl);
+        }
+        return true;
+    }
+    if (observed) return false;                          // (this clique hosts an observed variable: the generic pass)
     jt_unit_lean_dispatch<T, true>(*reinterpret_cast<const JtLean *>(itab + at), bk, itab, msg, fl, flow_ctl);
     return true;
 }
@@ -1695,10 +1707,19 @@ __device__ __forceinline__ bool jt_lean_block(const JtBlock &bk, const int *__re
 // up to three children) - so they are dispatched here, by every kernel that may meet one.
 #define JT_UNIT_PASS(NIN, NOUT, MODE) jt_pass<T, NIN, NOUT, MODE, FLOW, true, TMIX, false, true, false>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry)
 #define JT_UNIT_BELIEF(NIN) jt_pass<T, NIN, 0, 1, FLOW, true, TMIX, false, true, true>(tk, bk, itab, psi, bel, msg, fl, bindex, flow_ctl, t_entry)
-template <typename T, bool FLOW, bool TMIX>
+template <typename T, bool FLOW, bool TMIX, bool FOLD = false>
 __device__ __forceinline__ void jt_unit_collect(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                 T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                 uint32_t *flow_ctl, uint64_t t_entry) {
+    if (tk.fold) {
+        // a marginal task folded into the propagate: the lean pass or nothing (FOLD: the per-level distribute kernel; dataflow
+        // workgroups of such tasks are taken by jt_lean_block before they get here)
+        if constexpr (FOLD && !TMIX && !FLOW) {
+            if (tk.lean_off > 0 && (fl.ev == nullptr || fl.ev[2 * tk.pnode] == 0))
+                jt_unit_lean_readout<T, false>(*reinterpret_cast<const JtLean *>(itab + tk.lean_off), bk, itab, msg, fl);
+        }
+        return;
+    }
     if constexpr (!TMIX) {
         // (round 6) a task of one outgoing message and single-copy inputs on a clique that hosts no observed variable of this
         // evidence set (the engine passes no table at all when nothing is observed): the lean pass
@@ -1798,7 +1819,7 @@ __global__ __launch_bounds__(JT_THREADS, 3) void jt_distribute_level(const JtTas
     const JtBlock &bk = blk[blockIdx.x];
     const JtTask &tk = tasks[bk.task];
     if (tk.unit) {           // (a unit clique's downward messages are marginalisations of their own: mode 0 in the distribute phase)
-        if (tk.mode == 0) jt_unit_collect<T, false, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
+        if (tk.mode == 0) jt_unit_collect<T, false, false, true>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
         else jt_unit_distribute<T, false, false>(tk, bk, itab, psi, bel, msg, fl, blockIdx.x, nullptr, 0);
         return;
     }
@@ -1903,7 +1924,7 @@ __global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_propagate_flow(c
     const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
-    if (jt_lean_block<T>(bk, itab, msg, fl, flow_ctl)) return;
+    if (jt_lean_block<T, true>(bk, itab, msg, fl, flow_ctl)) return;
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
         jt_reduce<true>(tk, bk, msg, fl);
@@ -2988,9 +3009,10 @@ __global__ __launch_bounds__(256) void jt_msg_unpack(JtPackDesc d, const double 
 //  thread per entry added them one after the other, 94 us for config 3's 1831 requests.  A request of at most 128 entries now spreads
 //  its copies over 256 / entries thread groups - group g takes copies g, g + G, ... - whose sums are added in group order: a fixed
 //  order, the same bits on every call.)
-__global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restrict__ descs, const double *__restrict__ scratch,
-                                                      double *__restrict__ stage) {
+__global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restrict__ descs, const double *__restrict__ scratch_buf,
+                                                      double *__restrict__ stage, const double *__restrict__ arena_cur) {
     const JtMargDesc &m = descs[blockIdx.y];
+    const double *scratch = m.in_arena ? arena_cur : scratch_buf;       // (a marginal a folded task left in the message arena)
     __shared__ double part[256];
     const int64_t ne = m.d.host_elems;
     if (ne <= 128 && gridDim.x == 1) {

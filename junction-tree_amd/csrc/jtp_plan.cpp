@@ -757,6 +757,7 @@ PlanKnobs jtp_read_knobs() {
     k.no_ef_share = geti("JTP_EF_SHARE", 0) ? -1 : geti("JTP_NO_EF_SHARE", 0);      // (-1: the evidence-free group whatever the number of sets)
     k.unit_ratio = getd("JTP_UNIT_RATIO", 4.0);
     k.no_lean = geti("JTP_NO_LEAN", 0);
+    k.no_fold = geti("JTP_NO_FOLD", 0);
     return k;
 }
 
@@ -779,6 +780,7 @@ struct PlanBuilder {
     int block_log2_for(int phase, int level, int owner, bool tiny_rule = true) const;
     int read_description();      // validate and copy the caller's description
     int link_nodes();            // cliques, separators, reachability, replicated part
+    int fold_marginals();        // marginal tasks named at plan creation, behind messages()
     int reroot();                // single rank: root at the tree's centre
     int decide_units();          // which cliques keep no table (all ones, or their factors' product as a static table)
     int binarise();              // at most three children per node (virtual all-ones cliques)
@@ -897,6 +899,26 @@ int PlanBuilder::read_description() {
             if (find_var(hp.node_vars[n], v) >= 0) FAIL(JTP_EINVAL, "node %d: variable %d listed twice", n, v);
             hp.node_vars[n].push_back(v);
         }
+    }
+    if (d->fold_n < 0 || (d->fold_n > 0 && (!d->fold_cliques || !d->fold_var_off))) FAIL(JTP_EINVAL, "null array in the description (fold_*)");
+    if (d->fold_n > 0) {
+        if (d->fold_var_off[0] != 0) FAIL(JTP_EINVAL, "fold_var_off[0] must be 0");
+        for (int i = 0; i < d->fold_n; ++i) {
+            const int c = d->fold_cliques[i], a = d->fold_var_off[i], b = d->fold_var_off[i + 1];
+            if (c < 0 || c >= N) FAIL(JTP_EINVAL, "fold request %d: node %d is not a clique", i, c);
+            if (b < a || b - a > JT_MAX_VARS || (b > a && !d->fold_var_ids)) FAIL(JTP_EINVAL, "fold request %d: bad variable list", i);
+            for (int k = a; k < b; ++k)
+                if (d->fold_var_ids[k] < 0 || d->fold_var_ids[k] >= hp.n_vars) FAIL(JTP_EINVAL, "fold request %d: variable %d out of range", i, d->fold_var_ids[k]);
+        }
+        hp.fold_cliques.assign(d->fold_cliques, d->fold_cliques + d->fold_n);
+        hp.fold_var_off.assign(d->fold_var_off, d->fold_var_off + d->fold_n + 1);
+        hp.fold_var_ids.assign(d->fold_var_ids, d->fold_var_ids + d->fold_var_off[d->fold_n]);
+        // (the key jtp_get_marginals makes of a request list: n, cliques, offsets, variables)
+        hp.fold_key.push_back(d->fold_n);
+        hp.fold_key.insert(hp.fold_key.end(), hp.fold_cliques.begin(), hp.fold_cliques.end());
+        hp.fold_key.insert(hp.fold_key.end(), hp.fold_var_off.begin(), hp.fold_var_off.end());
+        hp.fold_key.insert(hp.fold_key.end(), hp.fold_var_ids.begin(), hp.fold_var_ids.end());
+        hp.folded.assign((size_t)d->fold_n, HostPlan::FoldReq());
     }
     hp.lean = d->cover_off != nullptr && !hp.multiset;
     if (d->cover_off) {
@@ -2113,7 +2135,85 @@ int PlanBuilder::messages() {
         else
             for (size_t j = 0; j < p.children.size(); ++j) tk.msg[JT_MAX_IN + j].off = hp.ps[hp.pn[p.children[j]].psep].dn_off;
     }
+    return fold_marginals();
+}
 
+// Marginals named at plan creation (jtp_tree_desc.fold_*; round 6).  `JunctionTree.propagate` returns factor marginals only
+// (junctiontree/junctiontree.py:264-274, 327-331), and a clique that keeps no table has no belief to take them from: the read-out forms
+// psi x (every incoming table) again, per request list, after the propagate - on a tree of such cliques a third of a propagate's work,
+// run behind it.  Here the same tasks (jtp_plan_marginal_task: up to three requests of one clique per pass) become tasks OF the
+// propagate: on the level of the clique's downward messages - their inputs are the final messages, the parent's produced one level up
+// in this launch - where the dependent levels leave slots idle, writing partial copies into a region of the message arena that
+// jtp_get_marginals unpacks.  Only the lean pass runs them (jt_unit_lean<..., NOUT>): single-set plans of one rank, no mixed-radix
+// rows, not a chain (whose distribute kernel is built without them); the engine falls back to the read-out wherever they did not run.
+int PlanBuilder::fold_marginals() {
+    if (hp.folded.empty() || hp.multiset || hp.n_ranks != 1 || hp.tmix || hp.chain_plan || hp.knobs.no_fold || hp.knobs.no_lean || (hp.knobs.debug & ~2)) return JTP_OK;
+    const int n = (int)hp.folded.size();
+    std::vector<std::vector<int>> groups;
+    {
+        std::map<int, int> open;                             // clique -> its group that still has room
+        for (int i = 0; i < n; ++i) {
+            const int c = hp.fold_cliques[i];
+            if (!hp.pn[c].unit || hp.pn[c].real < 0 || !mine(c)) continue;      // (a clique with a belief table: jt_marginals reads that)
+            auto it = open.find(c);
+            if (it == open.end() || (int)groups[it->second].size() >= hp.knobs.marg_group) {
+                open[c] = (int)groups.size();
+                groups.push_back(std::vector<int>());
+            }
+            groups[open[c]].push_back(i);
+        }
+    }
+    for (const std::vector<int> &grp : groups) {
+        const int c = hp.fold_cliques[grp[0]];
+        const PNode &p = hp.pn[c];
+        std::vector<std::vector<int>> ovs;
+        bool ok = true;
+        for (int i : grp) {
+            std::vector<int> ov(hp.fold_var_ids.begin() + hp.fold_var_off[i], hp.fold_var_ids.begin() + hp.fold_var_off[i + 1]);
+            for (size_t a = 0; a < ov.size(); ++a) {
+                ok = ok && find_var(p.vars, ov[a]) >= 0;
+                for (size_t b = 0; b < a; ++b) ok = ok && ov[a] != ov[b];
+            }
+            ovs.push_back(ov);
+        }
+        if (!ok) continue;                                   // (a malformed request: jtp_get_marginals will say so)
+        JtTask tk;
+        std::vector<int32_t> tab;
+        std::vector<int> out_bits, npart;
+        std::vector<JtBlock> blk;
+        std::string err2;
+        if (jtp_plan_marginal_task(hp, c, ovs, tk, tab, out_bits, npart, blk, err2, true) != JTP_OK) continue;
+        if (tk.n_in > JT_MAX_IN || tk.n_out > JT_MAX_OUT || tk.vgroups) continue;
+        tk.fold = 1;
+        tk.debug = hp.knobs.debug;
+        tk.itab_off = (int64_t)hp.itab.size();
+        if (tk.tmap_off >= 0) tk.tmap_off += tk.itab_off;
+        hp.itab.insert(hp.itab.end(), tab.begin(), tab.end());
+        const int t = (int)hp.tasks.size();
+        for (size_t j = 0; j < grp.size(); ++j) {
+            HostPlan::FoldReq &fr = hp.folded[grp[j]];
+            fr.task = t, fr.j = (int)j, fr.npart = npart[j], fr.out_bits = out_bits[j], fr.off = hp.msg_doubles;
+            tk.msg[JT_MAX_IN + j].off = hp.msg_doubles;
+            hp.msg_doubles += ((int64_t)1 << out_bits[j]) * npart[j];
+            hp.msg_doubles = (hp.msg_doubles + 1) & ~(int64_t)1;
+        }
+        // who writes what it reads (finish(): JtMsg::same_launch) - the order of neighbour_inputs
+        std::vector<int> prod;
+        if (p.psep >= 0) {
+            const PSep &sp = hp.ps[p.psep];
+            prod.push_back(sp.dn_red_task >= 0 ? sp.dn_red_task : (sp.dn_task >= 0 ? sp.dn_task : hp.pn[sp.parent].distribute_task));
+        }
+        if (p.stat >= 0) prod.push_back(-1);
+        for (int ch : p.children) {
+            const PSep &sp = hp.ps[hp.pn[ch].psep];
+            prod.push_back(sp.up_red_task >= 0 ? sp.up_red_task : hp.pn[sp.child].collect_task);
+        }
+        hp.tasks.push_back(tk);
+        hp.task_variant.push_back(JT_K_DISTRIBUTE_LEVEL);
+        task_bytes.push_back(0.0);
+        hp.task_producers.push_back(prod);
+        hp.pn[c].fold_tasks.push_back(t);
+    }
     return JTP_OK;
 }
 
@@ -2192,6 +2292,8 @@ int PlanBuilder::schedule() {
                 if (phase == 1) for (int t : p.down_tasks) groups[JT_K_MULTI_DISTRIBUTE].push_back(t);
                 continue;
             }
+            if (phase == 1)
+                for (int t : p.fold_tasks) groups[JT_K_DISTRIBUTE_LEVEL].push_back(t);      // (marginals folded into the propagate)
             if (phase == 1 && !p.down_tasks.empty()) {       // (a unit clique: a task per downward message)
                 for (int t : p.down_tasks) groups[JT_K_DISTRIBUTE_LEVEL].push_back(t);
                 continue;
@@ -2418,9 +2520,10 @@ int PlanBuilder::finish() {
     for (int c = 0; c < N; ++c)
         if (c != hp.root && (hp.owner[c] == hp.rank || (hp.owner[c] == ALL && hp.rank == 0))) hp.n_messages += 2;
     // Lean records (round 6, JtLean): every field of every task is final here
-    for (JtTask &tk : hp.tasks) jtp_make_lean(hp, tk, hp.itab);
+    for (JtTask &tk : hp.tasks) jtp_make_lean(hp, tk, hp.itab, tk.fold != 0);
     for (JtBlock &b : hp.blocks) {
         const int64_t at = hp.tasks[b.task].lean_off;
+        if (hp.tasks[b.task].fold) b.flags |= JT_BLOCK_FOLD;
         if (at > 0) b.flags |= JT_BLOCK_LEAN, b.first_x[5] = (uint32_t)hp.tasks[b.task].pnode, b.first_x[6] = (uint32_t)at, b.first_x[7] = (uint32_t)((uint64_t)at >> 32);
     }
     return JTP_OK;
@@ -2739,7 +2842,7 @@ void jtp_plan_to_json(HostPlan &hp, bool with_tasks) {
             if (t) o << ",";
             o << "{\"pnode\":" << tk.pnode << ",\"kind\":" << tk.kind << ",\"mode\":" << tk.mode << ",\"unit\":" << tk.unit << ",\"setb\":" << tk.setb << ",\"esum\":" << tk.esum << ",\"variant\":" << hp.task_variant[t] << ",\"psi_off\":" << tk.psi_off
               << ",\"bel_off\":" << tk.bel_off << ",\"nbits\":" << tk.nbits << ",\"real_bits\":" << tk.real_bits << ",\"nF\":" << tk.nF << ",\"nA\":" << tk.nA
-              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"keep_rows\":" << tk.keep_rows << ",\"tmap_off\":" << tk.tmap_off << ",\"lean_off\":" << tk.lean_off << ",\"vgroups\":" << tk.vgroups << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
+              << ",\"nR\":" << tk.nR << ",\"settle\":" << tk.settle << ",\"keep_rows\":" << tk.keep_rows << ",\"tmap_off\":" << tk.tmap_off << ",\"fold\":" << tk.fold << ",\"lean_off\":" << tk.lean_off << ",\"vgroups\":" << tk.vgroups << ",\"out_run\":" << tk.out_run << ",\"n_in\":" << tk.n_in << ",\"n_out\":" << tk.n_out
               << ",\"lds_bytes\":" << tk.lds_bytes << ",\"first_x\":";
             json_list(o, tk.first_x, tk.first_x + 8);
             o << ",\"f_x\":";

@@ -44,6 +44,7 @@ struct PNode {                       // a clique of the (binarised) tree
     int64_t tmap_off = -1;           // offset (ints) of tmap in HostPlan::itab
     int collect_task = -1, distribute_task = -1;
     std::vector<int> down_tasks;     // multi-set plans: one task per child (its downward message), child order
+    std::vector<int> fold_tasks;     // marginal tasks folded into the propagate (HostPlan::folded), scheduled with the clique's distribute level
     // UNIT cliques (JtTask::unit): no table on the device.  Virtual cliques of the binarisation, cliques that hold no factor,
     // and cliques whose factors cover only `cover` of their variables (jtp_tree_desc.cover_*): the product of those factors is a
     // STATIC table over the covered variables (HostPlan::statics[stat]) that every task of the clique stages like one more
@@ -156,6 +157,7 @@ struct PlanKnobs {
     int no_vgroups = 0;                                             // JTP_NO_VGROUPS: mixed-radix rows keep one row per step (round 3)
     int keep_invalid = 0;                                           // JTP_KEEP_INVALID: chunks that do not exist stay in the block lists (rounds 2-4)
     int no_unit = 0;                                                // JTP_NO_UNIT: no unit cliques - every clique (virtual ones too) keeps a full table (rounds 1-4)
+    int no_fold = 0;                                                // JTP_NO_FOLD: the marginals named at plan creation (jtp_tree_desc.fold_*) are formed by the read-out as before
     int no_lean = 0;                                                // JTP_NO_LEAN: unit tasks run the generic pass (round 5), no JtLean records
     double unit_ratio = 4.0;                                        // JTP_UNIT_RATIO: a clique becomes a unit clique when its table is at least this many times its covered part
     int marg_group = JT_MAX_OUT;                                    // JTP_MARG_GROUP: marginals of one belief table formed by one pass over it (1: a pass each, round 3)
@@ -198,6 +200,12 @@ struct HostPlan {
     int64_t fix_doubles = 0;             // size of the fixed arena (doubles)
     std::vector<JtPackDesc> stat_pack;   // per real clique with a static table: host array of the clique (axes of uncovered variables have
                                          // length 1) <-> the static table (dev_off = PStatic::off); nvars = 0 for the others
+    // marginals named at plan creation (jtp_tree_desc.fold_*): the request list as jtp_get_marginals keys it, and per request where the
+    // propagate leaves it (task < 0: not folded - the clique keeps a table, or the plan's launches cannot take such tasks)
+    struct FoldReq { int task = -1, j = 0, npart = 0, out_bits = 0; int64_t off = 0; };
+    std::vector<int32_t> fold_key;
+    std::vector<int32_t> fold_cliques, fold_var_off, fold_var_ids;
+    std::vector<FoldReq> folded;
     bool lean = false;                   // the description named covered variables (jtp_tree_desc.cover_*)
     std::string lean_refused;            // ... and that plan was refused for this reason: this one materialises every table (jtp_plan_create)
     bool has_unit = false;               // some task of this rank's is a unit task

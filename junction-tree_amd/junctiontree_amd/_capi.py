@@ -48,6 +48,11 @@ class TreeDesc(C.Structure):
         ("layout_policy", C.c_int32),
         ("cover_off", C.POINTER(C.c_int32)),
         ("cover_ids", C.POINTER(C.c_int32)),
+        ("fold_n", C.c_int32),
+        ("fold_pad", C.c_int32),
+        ("fold_cliques", C.POINTER(C.c_int32)),
+        ("fold_var_off", C.POINTER(C.c_int32)),
+        ("fold_var_ids", C.POINTER(C.c_int32)),
     ]
 
 

@@ -57,7 +57,7 @@ class Plan:
     def __init__(self, tree, node_vars, sizes, dtype="f64", device=0, n_batch=1,
                  n_ranks=1, rank=0, owner=None, plan_only=False, lds_budget=0, block_log2=0,
                  layout_policy=0, split_variants=False, keep_root=False, level_launches=False,
-                 flow_tickets=False, share_potentials=False, multiset=False, no_compact=False, root=None, cover=None):
+                 flow_tickets=False, share_potentials=False, multiset=False, no_compact=False, root=None, cover=None, fold=None):
         self._lib = _capi.lib()
         self._handle = C.c_void_p()
         order, parent, parent_sep, children = flatten_tree(tree)
@@ -143,6 +143,18 @@ class Plan:
                 coff.append(len(cids))
             self._keep += [_int_array(coff), _int_array(cids)]
             d.cover_off, d.cover_ids = [C.cast(a, C.POINTER(C.c_int32)) for a in self._keep[-2:]]
+        # `fold`: (clique of every request, labels of every request) - the marginals the caller will ask for after every propagate
+        # (`factor_marginals` with the model's factors: junctiontree.py:264-274).  Requests on cliques that keep no table are then formed
+        # inside the propagate's launch (jtp_tree_desc.fold_*); the list is built exactly as `_MarginalRequests` builds it.
+        if fold is not None and not multiset and n_ranks == 1:
+            f_cliques, f_labels = fold
+            fv, fo = [], [0]
+            for labs in f_labels:
+                fv += [labels[lab] for lab in labs if lab not in self._trivial]
+                fo.append(len(fv))
+            self._keep += [_int_array([self.abi_of[c] for c in f_cliques] + [0]), _int_array(fo), _int_array(fv + [0])]
+            d.fold_n = len(f_cliques)
+            d.fold_cliques, d.fold_var_off, d.fold_var_ids = [C.cast(a, C.POINTER(C.c_int32)) for a in self._keep[-3:]]
         d.n_cliques = len(cliques)
         d.n_nodes = len(self.node_ids)
         d.dtype = self.dtype
@@ -761,8 +773,11 @@ def plan_for(tree, node_vars, sizes, dtype, return_key=False, **kwargs):
     cover = kwargs.get("cover")
     key = _Key((_freeze(tree), tuple((n, tuple(node_vars[n])) for n in used),
                 tuple(sorted((repr(k), int(sizes[k])) for k in labels)),
-                dtype, tuple(sorted((k, v) for k, v in kwargs.items() if k != "cover")),
-                None if cover is None else tuple(tuple(cover[c]) for c in order)))
+                dtype, tuple(sorted((k, v) for k, v in kwargs.items() if k not in ("cover", "fold"))),
+                None if cover is None else tuple(tuple(cover[c]) for c in order),
+                # (`fold` - the marginals named ahead - is a hint: a plan made with one list serves every other list by the read-out,
+                #  so two models over one tree still share a plan; only WHETHER one was given keys the cache)
+                kwargs.get("fold") is not None))
     plan = _cache.pop(key, None)
     if plan is not None:
         _cache_stats["hits"] += 1

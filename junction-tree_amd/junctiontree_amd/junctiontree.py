@@ -183,7 +183,7 @@ class JunctionTree:
         self._memo["cover"] = ((hit[0] + 1) if hit is not None else 0, cover, [list(f) for f in ct.factor_graph.factors], list(ct.factor_to_maxclique))
         return cover
 
-    def plan(self, dtype="f64", trusted=False):
+    def plan(self, dtype="f64", trusted=False, fold=True):
         """The device plan for the current variable sizes (sizes are read at call time, as
         `junctiontree.py:311` does: the reference's tests condition on evidence by setting
         a size to 1, `tests/test_junctiontree.py:393-411`)."""
@@ -194,7 +194,8 @@ class JunctionTree:
         # and a weak reference to the plan it was last given for (dtype, the sizes as they are NOW, its options, and the
         # factor structure its cover was computed from - by value: a recomputed cover may reuse the old list's id)
         sizes = self.clique_tree.factor_graph.sizes
-        hit = self._memo.get("plan")
+        memo = "plan" if fold else "plan_nofold"
+        hit = self._memo.get(memo)
         if trusted and hit is not None and hit[0][0] == dtype:      # (`propagate(xs, changed=...)`: sizes, options and factors are vouched for)
             plan = engine.cached_plan(hit[1], hit[2]())
             if plan is not None:
@@ -206,8 +207,12 @@ class JunctionTree:
             if plan is not None:
                 return plan
         node_vars = [list(c) for c in self.clique_tree.maxcliques] + [list(s) for s in self.separators]
-        plan, key = engine.plan_for(self.tree, node_vars, sizes, dtype, return_key=True, cover=cover, **self._opts)
-        self._memo["plan"] = (mark, key, weakref.ref(plan))
+        # (`fold`: propagate returns factor marginals only, junctiontree.py:327-331 - the plan is told which, so that those of cliques
+        #  without a table are formed inside the propagate's launch; fold=False: the plan `compute_beliefs` would make of this tree)
+        ct = self.clique_tree
+        extra = {"fold": (tuple(ct.factor_to_maxclique), tuple(map(tuple, ct.factor_graph.factors)))} if fold else {}
+        plan, key = engine.plan_for(self.tree, node_vars, sizes, dtype, return_key=True, cover=cover, **extra, **self._opts)
+        self._memo[memo] = (mark, key, weakref.ref(plan))
         return plan
 
     def propagate(self, xs, changed=None):

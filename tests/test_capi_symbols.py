@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(_capi.TreeDesc) == 120 and ctypes.sizeof(_capi.Stats) == 760
+    assert ctypes.sizeof(_capi.TreeDesc) == 152 and ctypes.sizeof(_capi.Stats) == 760
     lib = _capi.lib()
     assert b"gfx950" in lib.jtp_version()
     assert lib.jtp_kernel_name(0) == b"jt_collect<T, 0>"

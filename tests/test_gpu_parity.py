@@ -1489,6 +1489,66 @@ def test_skipped_producers_re_arm_the_partial_copies_their_reduce_tasks_sum(monk
 
 
 @pytest.mark.gpu
+def test_factor_marginals_folded_into_the_propagate(monkeypatch):
+    """Round 6 (`jtp_tree_desc.fold_*`): `JunctionTree.propagate` returns factor marginals only (`junctiontree.py:327-331`), so its plan is
+    told the list; the requests on cliques that keep no table become tasks of the propagate's own launch and `factor_marginals` with
+    that list only unpacks them.  Same marginals as the read-out forms (JTP_NO_FOLD=1) and as the oracle's `propagate`; dataflow and
+    per-level launches bit for bit; an evidence set that observes something and any OTHER request list are served by the read-out."""
+    factors, sizes, values = synthetic.lattice_mrf(5, 16, 4, dtype=np.float64)
+    outs, want = {}, None
+    # (a lattice this small plans as a chain of latency-bound levels, whose distribute kernel is built without folded tasks: planned
+    #  here as the large ones are)
+    monkeypatch.setenv("JTP_TINY_LEVEL_ELEMS", "0")
+    for mode in ("fold", "nofold", "fold_levels"):
+        if mode == "nofold":
+            monkeypatch.setenv("JTP_NO_FOLD", "1")
+        else:
+            monkeypatch.delenv("JTP_NO_FOLD", raising=False)
+        engine.clear_plan_cache()
+        tree = jt.create_junction_tree(factors, sizes)
+        ct = tree.clique_tree
+        if want is None:
+            want = oracle.propagate(tree.tree, tree.separators, ct.maxcliques, ct.factor_to_maxclique, factors, sizes, values)
+        if mode == "fold_levels":
+            tree._opts["level_launches"] = True
+        out = tree.propagate(values)
+        plan = tree.plan("f64")
+        n_fold = sum(1 for t in plan.describe()["tasks"] if t["fold"])
+        assert (n_fold > 0) == (mode != "nofold"), (mode, n_fold)
+        assert all(t["lean_off"] > 0 and t["unit"] and t["mode"] == 0 and 1 <= t["n_out"] <= 3 for t in plan.describe()["tasks"] if t["fold"])
+        outs[mode] = [o.copy() for o in out]
+        if mode == "fold":
+            # the plain hot-path plan of the same tree has none; a second call gives the same bits
+            assert not any(t["fold"] for t in tree.plan("f64", fold=False).describe()["tasks"])
+            for a, b in zip(tree.propagate(values, changed=[]), out):
+                np.testing.assert_array_equal(a, b)
+            # another request list: the read-out
+            sub = [(ct.factor_to_maxclique[i], factors[i]) for i in (0, 5, 11)]
+            for (c, labs), m in zip(sub, plan.marginals(sub)):
+                close(m, want[[0, 5, 11][sub.index((c, labs))]], what="subset request")
+            # an evidence set that observes something: the folded tasks of cliques that host the variable do not run - the read-out does
+            var = factors[7][0]
+            plan.set_evidence({var: 1})
+            plan.propagate()
+            ev_vals = [v.copy() for v in values]
+            ind = np.zeros(sizes[var])
+            ind[1] = 1.0
+            ev_vals[7] = ev_vals[7] * ind.reshape([-1 if lab == var else 1 for lab in factors[7]])
+            ev_want = oracle.propagate(tree.tree, tree.separators, ct.maxcliques, ct.factor_to_maxclique, factors, sizes, ev_vals)
+            for o, w in zip(plan.factor_marginals(factors, ct.factor_to_maxclique), ev_want):
+                close(o, w, what="with evidence")
+            plan.set_evidence({})
+    engine.clear_plan_cache()
+    for mode in outs:
+        for o, w in zip(outs[mode], want):
+            close(o, w, what=mode)
+    for a, b in zip(outs["fold"], outs["nofold"]):
+        close(a, b, what="folded against read-out")
+    for a, b in zip(outs["fold"], outs["fold_levels"]):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_lean_and_generic_unit_passes_agree(monkeypatch):
     """Round 6: the lean unit pass (`jt_unit_lean`, the default) and the generic one (`JTP_NO_LEAN=1`) on a lattice whose junction tree is
     mostly unit cliques: every factor marginal of both against the oracle's `propagate`, the two against each other to rounding (the

@@ -302,3 +302,52 @@ def test_lean_records_say_what_the_task_records_say():
         for b in d["blocks"]:
             assert bool(b[23] & 4) == (d["tasks"][b[0]]["lean_off"] > 0)
     assert seen > 50
+
+
+def test_marginals_named_at_plan_creation_become_tasks_of_the_propagate():
+    """Round 6 (`jtp_tree_desc.fold_*`, `PlanBuilder::fold_marginals`): the factor marginals a plan is told about at creation - requests on
+    cliques that keep no table - become lean tasks of the distribute phase, on the level of their clique, reading the final messages of
+    the clique's neighbours and writing into a region of the message arena behind the separators'.  Structure only (the GPU tests
+    compare the values with the oracle and with the read-out)."""
+    factors, sizes, _ = synthetic.lattice_mrf(6, 14, 8)
+    tree = jt.create_junction_tree(factors, sizes)
+    ct = tree.clique_tree
+    node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in tree.separators]
+    fold = (tuple(ct.factor_to_maxclique), tuple(map(tuple, factors)))
+    plain = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", plan_only=True, cover=tree.cover()).describe()
+    d = engine.Plan(tree.tree, node_vars, sizes, dtype="f32", plan_only=True, cover=tree.cover(), fold=fold).describe()
+    folded = [(i, t) for i, t in enumerate(d["tasks"]) if t["fold"]]
+    assert folded and not any(t["fold"] for t in plain["tasks"])
+    assert d["msg_doubles"] > plain["msg_doubles"] and d["n_tasks"] == plain["n_tasks"] + len(folded)
+    sep_end = max(max(s["up_off"] + (s["up_npart"] << s["nbits"]), s["dn_off"] + (s["dn_npart"] << s["nbits"]), s["up_roff"] + (s["up_rnpart"] << s["nbits"]),
+                      s["dn_roff"] + (s["dn_rnpart"] << s["nbits"])) for s in d["pseps"])
+    level_of = {}
+    for L in d["launches"]:
+        for t in L["tasks"]:
+            level_of[t] = (L["phase"], L["level"])
+    n_requests = 0
+    for i, t in folded:
+        p = d["pnodes"][t["pnode"]]
+        assert p["unit"] and p["stat"] >= 0 and t["unit"] and t["kind"] == 0 and t["mode"] == 0 and t["lean_off"] > 0
+        assert 1 <= t["n_out"] <= 3 and t["n_in"] <= 4 and t["bel_off"] < 0
+        assert level_of[i] == (1, p["depth"])                       # with the clique's own downward messages
+        # inputs: the parent's final downward message, the static table, every child's final upward message
+        expect = []
+        if p["psep"] >= 0:
+            expect.append(d["pseps"][p["psep"]]["dn_roff"])
+        expect.append(d["statics"][p["stat"]]["off"])
+        expect += [d["pseps"][d["pnodes"][k]["psep"]]["up_roff"] for k in p["children"]]
+        assert [m["off"] for m in t["in"]] == expect and [m["fixed"] for m in t["in"]].count(1) == 1
+        for m in t["out"]:
+            assert m["off"] >= sep_end and m["off"] + m["npart"] * m["pstride"] <= d["msg_doubles"]
+        n_requests += t["n_out"]
+    # every request on a clique without a table is folded, three to a task at most
+    assert n_requests == sum(1 for c in ct.factor_to_maxclique if d["pnodes"][c]["unit"])
+    for b in d["blocks"]:
+        assert bool(b[23] & 16) == bool(d["tasks"][b[0]]["fold"]) and (not (b[23] & 16) or (b[23] & 4))
+    # a chain of latency-bound levels, a multi-set plan: no folded tasks (their launches are built without them)
+    small = synthetic.lattice_mrf(5, 10, 4)
+    st = jt.create_junction_tree(small[0], small[1])
+    snv = [list(c) for c in st.clique_tree.maxcliques] + [list(s) for s in st.separators]
+    sf = (tuple(st.clique_tree.factor_to_maxclique), tuple(map(tuple, small[0])))
+    assert not any(t["fold"] for t in engine.Plan(st.tree, snv, small[1], dtype="f64", plan_only=True, cover=st.cover(), fold=sf).describe()["tasks"])
