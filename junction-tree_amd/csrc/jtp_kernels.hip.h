@@ -1388,8 +1388,15 @@ __device__ __forceinline__ void jt_unit_lean(const JtLean &ln, const JtBlock &bk
 #pragma unroll
                             for (int q = 0; q < 4; ++q) d[q] = p0 + q < ncopy ? jt_msg_load<FLOW>(at[k][u] + (int64_t)(p0 + q) * cstride, thr_mem[k]) : 0.0;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (p0 + q < ncopy) sum += d[q];
+                            for (int q = 0; q < 4; ++q) {
+                                if (p0 + q >= ncopy) continue;
+                                if constexpr (FLOW) {         // (folded marginals: the copies are in the making like the first one)
+                                    const double *ap = at[k][u] + (int64_t)(p0 + q) * cstride;
+                                    d[q] = jt_msg_settle<FLOW>(ap, d[q], thr_mem[k], settle_attempt);
+                                    if (jt_unwritten(d[q])) unready = ap;
+                                }
+                                sum += d[q];
+                            }
                         }
                     }
                     sub[(it0 + u) * JT_THREADS + tid] = sum;

@@ -1546,6 +1546,22 @@ def test_factor_marginals_folded_into_the_propagate(monkeypatch):
         close(a, b, what="folded against read-out")
     for a, b in zip(outs["fold"], outs["fold_levels"]):
         np.testing.assert_array_equal(a, b)
+    # propagates queued back to back on a lattice whose folded tasks read messages that arrive as several partial copies, in the launch
+    # that makes them: every copy is waited for (the first build waited for the first one only; tools/soak.py found NaN marginals)
+    monkeypatch.delenv("JTP_TINY_LEVEL_ELEMS")
+    factors, sizes, values = synthetic.lattice_mrf(6, 40, 8)
+    tree = jt.create_junction_tree(factors, sizes)
+    first = tree.propagate(values)
+    plan = tree.plan("f32")
+    d = plan.describe()
+    assert any(t["fold"] and any(m["npart"] > 1 and m["same_launch"] for m in t["in"]) for t in d["tasks"])
+    for i in range(600):
+        plan.propagate(sync=False)
+        if i % 10 == 9:
+            for a, b in zip(plan.factor_marginals(factors, tree.clique_tree.factor_to_maxclique), first):
+                np.testing.assert_array_equal(a, b)
+    assert plan.stats()["flow_fallbacks"] == 0
+    engine.clear_plan_cache()
 
 
 @pytest.mark.gpu
