@@ -8,6 +8,7 @@ import junctiontree_amd as jt
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t0, n_sets, n_again, n_cond, failed = time.time(), 0, 0, 0, []
+n_fold_plans = n_fold_tasks = 0
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
     wide = os.environ.get("FUZZ_WIDE")        # wider factors (up to 6 variables of up to 5 states) over up to 12 variables
@@ -32,6 +33,9 @@ for seed in range(first, first + n):
         print("seed %d: %s: %s" % (seed, type(exc).__name__, exc), flush=True)
         failed.append(seed)
         continue
+    nft = sum(1 for t in tree.plan("f32" if f32 else "f64").describe()["tasks"] if t["fold"])     # (round 6) marginals formed inside the propagate
+    n_fold_plans += nft > 0
+    n_fold_tasks += nft
     # brute force: the joint over the variables that occur, then every factor's marginal
     order = sorted(used, key=str)
     ax = {v: i for i, v in enumerate(order)}
@@ -98,4 +102,4 @@ for seed in range(first, first + n):
         n_sets += len(sets)
     if (seed - first) % 50 == 49:
         print("seed %d ok (%.0f s)" % (seed, time.time() - t0), flush=True)
-print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint; %d evidence sets through propagate_evidence_sets and %d propagates with some factors changed too; %d graphs conditioned the reference's way (sizes set to 1, factors sliced) (%.0f s); raised: %r" % (n, n_sets, n_again, n_cond, time.time() - t0, failed))
+print("%d random factor graphs through create_junction_tree + propagate agree with the brute-force joint; %d evidence sets through propagate_evidence_sets and %d propagates with some factors changed too; %d graphs conditioned the reference's way (sizes set to 1, factors sliced) (%.0f s); plans with folded marginal tasks: %d (%d tasks); raised: %r" % (n, n_sets, n_again, n_cond, time.time() - t0, n_fold_plans, n_fold_tasks, failed))
