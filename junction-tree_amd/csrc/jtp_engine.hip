@@ -193,14 +193,15 @@ struct KernelTable {
         }
         return nullptr;
     }
-    static fn get_flow(int phase, bool chain, int tmix) {
+    static fn get_flow(int phase, bool chain, int tmix, bool marg) {
         if (tmix == 2) return phase == 0 ? jt_collect_flow_mix<T, true> : jt_distribute_flow_mix<T, true>;
         if (tmix) return phase == 0 ? jt_collect_flow_mix<T, false> : jt_distribute_flow_mix<T, false>;      // (never merged: jtp_plan.cpp finish())
-        if (phase == 2) return jt_propagate_flow<T>;                    // both phases in one launch
+        // (marg: the plan has marginal tasks folded into its distribute phase - the build of the kernel that can run them)
+        if (phase == 2) return marg ? jt_propagate_flow_marg<T> : jt_propagate_flow<T>;          // both phases in one launch
         // The kernel that runs both phases dispatches on the task's mode, so it serves a distribute segment alone as well - and its
         // build of the distribute pass is the faster one (round 5, A/B by environment on one box: config 3 in two launches 8.35 -> 8.13 ms,
         // the whole gain of "one launch"; a rank's share of config 4 at 8 ranks 178 -> 176 us).  JTP_FLOW_BOTH=0: jt_distribute_flow as before.
-        if (phase == 1 && !chain && flow_both()) return jt_propagate_flow<T>;
+        if (phase == 1 && !chain && flow_both()) return marg ? jt_propagate_flow_marg<T> : jt_propagate_flow<T>;
         return phase == 0 ? jt_collect_flow<T> : (chain ? jt_distribute_flow_chain<T> : jt_distribute_flow<T>);
     }
 };
@@ -352,6 +353,7 @@ struct jtp_plan {
     bool prof_per_launch = false;   // event pair per launch instead of three per propagate
     bool flow = true;               // dataflow launches (one per phase) instead of one per level
     bool chain = false;             // the plan is made of latency-bound levels (JtTask::settle): distribute runs the build without spills
+    bool marg_tasks = false;        // some marginal request was folded into the propagate (HostPlan::folded): jt_propagate_flow_marg
     uint32_t *host_abort = nullptr; // pinned: set by a workgroup that gave up waiting
     int flow_fallbacks = 0;         // times that happened (then: one launch per level from there on)
     int fake_comm = 0;              // JTP_FAKE_COMM: 1 = what a rank would receive is filled with ones, what it would send goes nowhere;
@@ -707,6 +709,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
     // through L2 while a dataflow launch has to read through to memory.  Measured 39.6 vs 46.9 ms.
     if (hp.max_lds > 64 * 1024 && !pl->multiset && !hp.knobs.force_flow) pl->flow = false;
     pl->chain = hp.chain_plan;
+    for (const HostPlan::FoldReq &fr : hp.folded) pl->marg_tasks = pl->marg_tasks || fr.task >= 0;
     if (hp.flags & JTP_PLAN_ONLY) {
         *out = pl;
         return JTP_OK;
@@ -856,7 +859,7 @@ int jtp_plan_create(const jtp_tree_desc *desc, jtp_plan **out) {
             CREATE_TRY(raise_lds(kfunc(v), hp.max_lds));
         }
         for (int ph = 0; ph < 3; ++ph) {
-            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain, mixk(hp)) : (const void *)KernelTable<double>::get_flow(ph, pl->chain, mixk(hp));
+            const void *f = hp.dtype == JTP_F32 ? (const void *)KernelTable<float>::get_flow(ph, pl->chain, mixk(hp), pl->marg_tasks) : (const void *)KernelTable<double>::get_flow(ph, pl->chain, mixk(hp), pl->marg_tasks);
             CREATE_TRY(raise_lds(f, hp.max_lds));
         }
     }
@@ -1719,10 +1722,10 @@ int jtp_propagate(jtp_plan *pl, int32_t batch_begin, int32_t batch_end) {
                 fl.blk_base = (uint32_t)sg.blk_off;
                 fl.ticket_base = ticket_run * (uint32_t)sg.nblocks;
                 if (hp.dtype == JTP_F32)
-                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase, pl->chain, mixk(hp)), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                    hipLaunchKernelGGL(KernelTable<float>::get_flow(sg.phase, pl->chain, mixk(hp), pl->marg_tasks), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const float *)bb.psi, (float *)bb.bel, bb.msg, fl);
                 else
-                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase, pl->chain, mixk(hp)), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
+                    hipLaunchKernelGGL(KernelTable<double>::get_flow(sg.phase, pl->chain, mixk(hp), pl->marg_tasks), dim3(sg.nblocks), dim3(JT_THREADS), sg.lds_bytes, s, pl->d_tasks,
                                        pl->d_blocks + sg.blk_off, pl->d_itab, (const double *)bb.psi, (double *)bb.bel, bb.msg, fl);
             } else if (st.kind == 0) {
                 const Launch &L = hp.launches[st.first];

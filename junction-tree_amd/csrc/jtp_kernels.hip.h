@@ -1689,7 +1689,7 @@ __device__ __forceinline__ void jt_unit_lean_readout(const JtLean &ln, const JtB
 // A dataflow workgroup whose record says "lean" (JT_BLOCK_LEAN) goes from its workgroup record straight to the task's lean record:
 // one dependent scalar round trip less than through the task record.  (A clique that hosts an observed variable runs the generic pass;
 // first_x[5] = the task's planner node, the index of its entry of the evidence table.)
-// FOLD: the kernel can run folded marginal tasks (JT_BLOCK_FOLD; jt_propagate_flow only - the other dataflow kernels end such a
+// FOLD: the kernel can run folded marginal tasks (JT_BLOCK_FOLD; jt_propagate_flow_marg only - the other dataflow kernels end such a
 // workgroup at once, as every kernel does where the clique hosts an observed variable: the engine then forms those marginals by
 // the read-out, jtp_get_marginals).
 template <typename T, bool FOLD = false>
@@ -1923,15 +1923,17 @@ __device__ __forceinline__ void jt_distribute_flow_body(const JtTask *__restrict
 // other consumer.  Saves the second launch's cold start and the gap between the launches (~10 us of 620 on the width-20
 // tree); every message is then read through to memory (JtMsg::same_launch), also the upward messages the distribute
 // tasks read, because their producers ran in THIS launch.
-template <typename T>
-__global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_propagate_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
-                                                                   const int *__restrict__ itab, const T *__restrict__ psi,
-                                                                   T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
-    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];
+// FOLD: the build that also runs the marginal tasks folded into the propagate (jt_propagate_flow_marg: plans that have such tasks).  A
+// kernel of its own because the plans without them - every hot path of bench.py - pay for the code otherwise: config 3 5.92 -> 6.07 ms
+// with one kernel for both (A/B on one box, profiles/r06_ab_fold_hot_path.txt).
+template <typename T, bool FOLD>
+__device__ __forceinline__ void jt_propagate_flow_body(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                       const int *__restrict__ itab, const T *__restrict__ psi, T *__restrict__ bel,
+                                                       double *__restrict__ msg, const JtFlow &fl, uint32_t *flow_ctl) {
     const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
     const uint32_t ticket = jt_flow_ticket(fl, flow_ctl);
     const JtBlock &bk = blk[ticket];
-    if (jt_lean_block<T, true>(bk, itab, msg, fl, flow_ctl)) return;
+    if (jt_lean_block<T, FOLD>(bk, itab, msg, fl, flow_ctl)) return;
     const JtTask &tk = tasks[bk.task];
     if (tk.kind != 0) {
         jt_reduce<true>(tk, bk, msg, fl);
@@ -1961,6 +1963,22 @@ __global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_propagate_flow(c
         case 6: jt_pass<T, 3, 2, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
         default: jt_pass<T, 4, 3, 1, true, false, false, true>(tk, bk, itab, psi, bel, msg, fl, ticket, flow_ctl, t_entry); break;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_propagate_flow(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                                   const int *__restrict__ itab, const T *__restrict__ psi,
+                                                                   T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];
+    jt_propagate_flow_body<T, false>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
+}
+
+template <typename T>
+__global__ __launch_bounds__(JT_THREADS, JT_FLOW_WAVES) void jt_propagate_flow_marg(const JtTask *__restrict__ tasks, const JtBlock *__restrict__ blk,
+                                                                        const int *__restrict__ itab, const T *__restrict__ psi,
+                                                                        T *__restrict__ bel, double *__restrict__ msg, JtFlow fl) {
+    __shared__ uint32_t flow_ctl[28 + 8 * JT_MAX_OUT];
+    jt_propagate_flow_body<T, true>(tasks, blk, itab, psi, bel, msg, fl, flow_ctl);
 }
 
 // Two builds of the distribute pass.  Compiled for four waves per SIMD (128 registers, a few spills) a CU holds four
@@ -3079,7 +3097,7 @@ __global__ __launch_bounds__(256) void jt_marg_unpack(const JtMargDesc *__restri
     X template __global__ void jt_distribute<T, 1, 2>(JT_KARGS(T));          \
     X template __global__ void jt_distribute<T, 1, 3>(JT_KARGS(T));
 #define JT_INST_MULTI(X, T) X template __global__ void jt_multi_flow<T>(JT_KARGS(T));
-#define JT_INST_BOTH(X, T) X template __global__ void jt_propagate_flow<T>(JT_KARGS(T));
+#define JT_INST_BOTH(X, T) X template __global__ void jt_propagate_flow<T>(JT_KARGS(T)); X template __global__ void jt_propagate_flow_marg<T>(JT_KARGS(T));
 #define JT_INST_MIX_V(X, T, V)                                                  \
     X template __global__ void jt_collect_level_mix<T, V>(JT_KARGS(T));         \
     X template __global__ void jt_distribute_level_mix<T, V>(JT_KARGS(T));      \
