@@ -1695,7 +1695,7 @@ __device__ __forceinline__ void jt_unit_lean_readout(const JtLean &ln, const JtB
 template <typename T, bool FOLD = false>
 __device__ __forceinline__ bool jt_lean_block(const JtBlock &bk, const int *__restrict__ itab, double *__restrict__ msg, const JtFlow &fl,
                                               uint32_t *flow_ctl) {
-    if (!(bk.flags & JT_BLOCK_LEAN)) return (bk.flags & JT_BLOCK_FOLD) != 0;
+    if (!(bk.flags & JT_BLOCK_LEAN)) return false;        // (a folded task always has a lean record: jtp_plan.cpp finish())
     const bool observed = fl.ev != nullptr && fl.ev[2 * bk.first_x[5]] != 0;
     const int64_t at = (int64_t)((uint64_t)bk.first_x[6] | ((uint64_t)bk.first_x[7] << 32));
     if (bk.flags & JT_BLOCK_FOLD) {
@@ -1718,14 +1718,14 @@ template <typename T, bool FLOW, bool TMIX, bool FOLD = false>
 __device__ __forceinline__ void jt_unit_collect(const JtTask &tk, const JtBlock &bk, const int *__restrict__ itab, const T *__restrict__ psi,
                                                 T *__restrict__ bel, double *__restrict__ msg, const JtFlow &fl, uint32_t bindex,
                                                 uint32_t *flow_ctl, uint64_t t_entry) {
-    if (tk.fold) {
-        // a marginal task folded into the propagate: the lean pass or nothing (FOLD: the per-level distribute kernel; dataflow
-        // workgroups of such tasks are taken by jt_lean_block before they get here)
-        if constexpr (FOLD && !TMIX && !FLOW) {
+    if constexpr (FOLD && !TMIX && !FLOW) {
+        // a marginal task folded into the propagate: the lean pass or nothing.  Only the per-level distribute kernel meets one here
+        // (FOLD): dataflow workgroups of such tasks are taken by jt_lean_block, and no other launch list holds them.
+        if (tk.fold) {
             if (tk.lean_off > 0 && (fl.ev == nullptr || fl.ev[2 * tk.pnode] == 0))
                 jt_unit_lean_readout<T, false>(*reinterpret_cast<const JtLean *>(itab + tk.lean_off), bk, itab, msg, fl);
+            return;
         }
-        return;
     }
     if constexpr (!TMIX) {
         // (round 6) a task of one outgoing message and single-copy inputs on a clique that hosts no observed variable of this

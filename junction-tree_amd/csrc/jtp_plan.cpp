@@ -2521,6 +2521,10 @@ int PlanBuilder::finish() {
         if (c != hp.root && (hp.owner[c] == hp.rank || (hp.owner[c] == ALL && hp.rank == 0))) hp.n_messages += 2;
     // Lean records (round 6, JtLean): every field of every task is final here
     for (JtTask &tk : hp.tasks) jtp_make_lean(hp, tk, hp.itab, tk.fold != 0);
+    // (a folded marginal task runs as a lean task or not at all: without a record - fold_marginals asks for what jtp_make_lean asks for,
+    //  so this does not happen - its requests are the read-out's)
+    for (HostPlan::FoldReq &fr : hp.folded)
+        if (fr.task >= 0 && hp.tasks[fr.task].lean_off <= 0) fr.task = -1;
     for (JtBlock &b : hp.blocks) {
         const int64_t at = hp.tasks[b.task].lean_off;
         if (hp.tasks[b.task].fold) b.flags |= JT_BLOCK_FOLD;
