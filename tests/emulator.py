@@ -130,6 +130,25 @@ class Emulator:
         x = self._dev_index(clique, host_vars, cards)
         return self.bel[p["arena_off"] + x].reshape(cards)
 
+    def folded_marginal(self, task, j, host_vars, cards):
+        """output j of a marginal task folded into the propagate (round 6): the sum of its partial copies in the message arena, as
+        jt_marg_unpack forms it - a plain bit-field table, the LAST requested variable in the lowest bits"""
+        tk = self.d["tasks"][task]
+        assert tk["fold"] and j < tk["n_out"]
+        m = tk["out"][j]
+        p = self.d["pnodes"][tk["pnode"]]
+        nb = {v: p["nb"][i] for i, v in enumerate(p["vars"])}
+        pos, bit = {}, 0
+        for v in reversed(host_vars):
+            pos[v] = bit
+            bit += nb[v]
+        assert m["pstride"] == 1 << bit
+        idx = self._msg_index({"vars": list(pos), "pos": list(pos.values())}, host_vars, cards)
+        tot = np.zeros(len(idx))
+        for q in range(m["npart"]):
+            tot = tot + self.msg[m["off"] + q * m["pstride"] + idx]
+        return tot.reshape(cards)
+
     def sep_belief(self, psep, host_vars, cards):
         s = self.d["pseps"][psep]
         pos = {v: s["pos"][i] for i, v in enumerate(s["vars"])}
@@ -197,6 +216,7 @@ class Emulator:
             assert record[20] == lxF and (record[21] & 1) == (0 if chunk_ok else 1)       # (bit 1: JT_BLOCK_KEEP_ROWS, a cache-policy hint)
             if chunk_ok:
                 assert record[0] == xF and record[11] == tk["psi_off"] + xF and (not tk.get("unit") or tk["psi_off"] == 0)
+                assert bool(record[21] & 16) == bool(tk.get("fold"))       # JT_BLOCK_FOLD (round 6): a marginal task folded into the propagate
                 if record[21] & 4:        # JT_BLOCK_LEAN (round 6): a unit task loads no rows - the last three words say where its lean record is
                     assert tk["unit"] and tk["lean_off"] > 0 and tk["lean_off"] % 16 == 0
                     assert list(record[12:17]) == list(tk["first_x"][:5])
@@ -343,7 +363,7 @@ class Emulator:
             q = p.copy()
             for v in vals:
                 q = q * v
-            contrib = [q]
+            contrib = [q] * n_out      # (several outputs: folded marginal tasks, round 6 - each the sum over its own complement)
         else:
             npar = n_in - n_out
             pre = p.copy()
@@ -459,7 +479,7 @@ class Emulator:
                     assert tk["kind"] == 1 or (tk["mode"] == 0 and tk["variant"] == 17 + launch["phase"] and tk["setb"] in (4096, 16384))
                 else:
                     # (a unit clique's downward messages are marginalisations of their own: mode 0 tasks of the distribute phase)
-                    assert tk["kind"] == 1 or (tk["unit"] and tk["mode"] == 0 and tk["n_out"] == 1) or ((tk["variant"] < 4) == (launch["phase"] == 0) and tk["mode"] == launch["phase"])
+                    assert tk["kind"] == 1 or (tk["unit"] and tk["mode"] == 0 and (tk["n_out"] == 1 or (tk["fold"] and launch["phase"] == 1))) or ((tk["variant"] < 4) == (launch["phase"] == 0) and tk["mode"] == launch["phase"])
                 assert tk["lds_bytes"] <= launch["lds_bytes"]
                 seen.add((t, chunk))
                 self._block(tk, chunk, tk["mode"] == 0, blk[2:])

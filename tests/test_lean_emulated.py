@@ -351,3 +351,53 @@ def test_marginals_named_at_plan_creation_become_tasks_of_the_propagate():
     snv = [list(c) for c in st.clique_tree.maxcliques] + [list(s) for s in st.separators]
     sf = (tuple(st.clique_tree.factor_to_maxclique), tuple(map(tuple, small[0])))
     assert not any(t["fold"] for t in engine.Plan(st.tree, snv, small[1], dtype="f64", plan_only=True, cover=st.cover(), fold=sf).describe()["tasks"])
+
+
+@pytest.mark.parametrize("h,w,card,dtype,sweep", [(3, 7, 4, "f64", False), (4, 8, 2, "f32", False), (3, 6, 4, "f32", True), (5, 6, 2, "f64", False)])
+def test_folded_marginal_tasks_emulated(monkeypatch, h, w, card, dtype, sweep):
+    """Round 6: the task tables of a plan with folded marginal tasks, executed on the CPU: per-level order, then the dataflow order in
+    which every entry a workgroup reads - every partial copy of it - must have been written by an earlier workgroup; the partial copies
+    of each folded output summed as `jt_marg_unpack` sums them, against the oracle's `propagate`; the messages the other tasks form are
+    the plain plan's, bit for bit."""
+    monkeypatch.setenv("JTP_TINY_LEVEL_ELEMS", "0")              # (small lattices plan as chains of latency-bound levels, which carry no folded tasks)
+    factors, sizes, values = synthetic.lattice_mrf(h, w, card)
+    values = [np.asarray(v, dtype=np.float64) for v in values]
+    tree = jt.create_junction_tree(factors, dict(sizes), order=synthetic.lattice_column_order(h, w) if sweep else None)
+    ct = tree.clique_tree
+    f2c = ct.factor_to_maxclique
+    node_vars = [list(c) for c in ct.maxcliques] + [list(s) for s in tree.separators]
+    plan = engine.Plan(tree.tree, node_vars, sizes, dtype=dtype, plan_only=True, cover=tree.cover(), fold=(tuple(f2c), tuple(map(tuple, factors))))
+    plain = engine.Plan(tree.tree, node_vars, sizes, dtype=dtype, plan_only=True, cover=tree.cover())
+    d, d0 = plan.describe(), plain.describe()
+    fold_tasks = [i for i, t in enumerate(d["tasks"]) if t["fold"]]
+    assert fold_tasks and d["tmix"] == 0
+    # which request went to which task: requests on cliques without a table, grouped by clique in request order, three to a task
+    groups, open_ = [], {}
+    for i, c in enumerate(f2c):
+        if not d["pnodes"][plan.abi_of[c]]["unit"]:
+            continue
+        if c not in open_ or len(groups[open_[c]]) >= 3:
+            open_[c] = len(groups)
+            groups.append([])
+        groups[open_[c]].append(i)
+    assert len(groups) == len(fold_tasks) and [len(g) for g in groups] == [d["tasks"][t]["n_out"] for t in fold_tasks]
+    emu, emu0 = Emulator(d), Emulator(d0)
+    pots = ct.evaluate(values)
+    for c in plan.cliques:
+        ids = [plan.var_id[lab] for lab in node_vars[c]]
+        for e, pl in ((emu, plan), (emu0, plain)):
+            e.set_potential(pl.abi_of[c], ids, [sizes[lab] for lab in node_vars[c]], pots[c])
+    emu.propagate()
+    level = emu.msg.copy()
+    emu.propagate_flow()
+    np.testing.assert_array_equal(level, emu.msg)
+    emu0.propagate()
+    np.testing.assert_array_equal(emu.msg[:d0["msg_doubles"]], emu0.msg[:d0["msg_doubles"]])      # the folded outputs lie behind everything else
+    want = oracle.propagate(tree.tree, tree.separators, ct.maxcliques, f2c, factors, sizes, values)
+    for t, grp in zip(fold_tasks, groups):
+        assert d["tasks"][t]["pnode"] == plan.abi_of[f2c[grp[0]]]
+        for j, i in enumerate(grp):
+            got = emu.folded_marginal(t, j, [plan.var_id[lab] for lab in factors[i]], [sizes[lab] for lab in factors[i]])
+            np.testing.assert_allclose(got, want[i], rtol=1e-11, atol=1e-300)
+    plan.close()
+    plain.close()

@@ -63,7 +63,7 @@ for case in cases:
                          "fetch_bytes_per_launch_corrected_x2": fetch, "WRITE_SIZE_KB_per_launch": sum(wv) / len(wv),
                          "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
     # per STEP: every launch of the message-passing kernels in the profiled run (bench.py --steps 5 --warmup 1: six propagates)
-    hot = ("jt_propagate_flow", "jt_collect_flow", "jt_distribute_flow", "jt_distribute_flow_chain", "jt_multi_flow", "jt_multi_fanout", "jt_collect_level",
+    hot = ("jt_propagate_flow", "jt_propagate_flow_marg", "jt_collect_flow", "jt_distribute_flow", "jt_distribute_flow_chain", "jt_multi_flow", "jt_multi_fanout", "jt_collect_level",
            "jt_distribute_level", "jt_reduce_level", "jt_collect_flow_mix", "jt_distribute_flow_mix", "jt_collect_level_mix", "jt_distribute_level_mix")
     per_step = 0.0
     for name, c in pmc.items():
