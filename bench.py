@@ -384,7 +384,7 @@ def sub_c3(device, source_id, steps=10, api_calls=5, lattice_w=167):
                                  "distribute, %d factor marginals, D2H" % (len(factors), staged, len(factors)),
                "ms_per_step": api_ms, "ms_per_step_median": sorted(api)[len(api) // 2], "steps": api_calls,
                "ms_per_step_tables_compared_by_the_library": min(api_cmp),
-               "propagate_with_folded_marginals_ms": folded_wall,
+               "propagate_of_the_api_plan_ms": folded_wall,
                "folded_marginal_tasks": sum(1 for t in plan_api.describe()["tasks"] if t.get("fold")),
                "algorithmic_bytes_per_step": api_alg, "value": api_alg / (api_ms * 1e-3) / 1e9, "unit": "GB/s",
                "frac": api_alg / (api_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bound": "hbm", "hot_path_share": wall / api_ms,

@@ -95,9 +95,12 @@ def build(force=False, verbose=True, extra=(), out=None, jobs=None):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            for old in os.listdir(cache):               # one object per unit and flag set is enough
-                if old.startswith(os.path.splitext(src)[0] + ".") and len(os.listdir(cache)) > 64:
-                    os.remove(os.path.join(cache, old))
+            # (the four newest objects of a unit are kept: the product and a -D variant of it can be rebuilt in turn without either
+            #  pushing the other's objects out)
+            mine = sorted((f for f in os.listdir(cache) if f.startswith(os.path.splitext(src)[0] + ".") and f.endswith(".o")),
+                          key=lambda f: os.path.getmtime(os.path.join(cache, f)))
+            for old in mine[:-3]:
+                os.remove(os.path.join(cache, old))
             tmp_kept = kept + ".tmp%d" % os.getpid()      # (another build may be reading the cache: entries appear whole or not at all)
             shutil.copy(obj, tmp_kept)
             os.replace(tmp_kept, kept)

@@ -758,6 +758,9 @@ PlanKnobs jtp_read_knobs() {
     k.unit_ratio = getd("JTP_UNIT_RATIO", 4.0);
     k.no_lean = geti("JTP_NO_LEAN", 0);
     k.no_fold = geti("JTP_NO_FOLD", 0);
+    k.fold = geti("JTP_FOLD", -1);
+    if (k.fold == 0) k.no_fold = 1;
+    k.fold_slots = geti("JTP_FOLD_SLOTS", 1024);
     return k;
 }
 
@@ -2149,6 +2152,26 @@ int PlanBuilder::messages() {
 int PlanBuilder::fold_marginals() {
     if (hp.folded.empty() || hp.multiset || hp.n_ranks != 1 || hp.tmix || hp.chain_plan || hp.knobs.no_fold || hp.knobs.no_lean || (hp.knobs.debug & ~2)) return JTP_OK;
     const int n = (int)hp.folded.size();
+    if (hp.knobs.fold < 0) {
+        // Where the folded tasks pay (measured, profiles/r06_ab_fold_placement.txt): their workgroups are free where the levels of the
+        // distribute phase leave resident slots of the chip idle (the column-sweep tree of config 3: every level under 1 024 workgroups,
+        // marginals 3.7 -> 0.24 ms for 1.4 ms more propagate), and cost their own work where the levels fill the chip (the min-fill tree:
+        // 6 % of the levels under 1 024; +0.28 ms of propagate for 0.21 ms less read-out, wherever in the launch they are put) - there the
+        // read-out's launch, which waits for nobody, does the same work no slower.  So: fold where at least half of the distribute
+        // levels are under `fold_slots` workgroups (256 CUs x 4).  JTP_FOLD=1: wherever possible; 0: nowhere.
+        std::vector<long> level_blocks(maxdepth + 1, 0);
+        for (int c = 0; c < NP; ++c) {
+            const PNode &p = hp.pn[c];
+            if (!mine(c)) continue;
+            if (!p.down_tasks.empty()) {
+                for (int t : p.down_tasks) level_blocks[p.depth] += 1L << hp.tasks[t].nF;
+            } else if (p.distribute_task >= 0) level_blocks[p.depth] += 1L << hp.tasks[p.distribute_task].nF;
+        }
+        int levels = 0, idle = 0;
+        for (long b : level_blocks)
+            if (b > 0) ++levels, idle += b < hp.knobs.fold_slots ? 1 : 0;
+        if (2 * idle < levels) return JTP_OK;
+    }
     std::vector<std::vector<int>> groups;
     {
         std::map<int, int> open;                             // clique -> its group that still has room

@@ -158,6 +158,8 @@ struct PlanKnobs {
     int keep_invalid = 0;                                           // JTP_KEEP_INVALID: chunks that do not exist stay in the block lists (rounds 2-4)
     int no_unit = 0;                                                // JTP_NO_UNIT: no unit cliques - every clique (virtual ones too) keeps a full table (rounds 1-4)
     int no_fold = 0;                                                // JTP_NO_FOLD: the marginals named at plan creation (jtp_tree_desc.fold_*) are formed by the read-out as before
+    int fold = -1;                                                  // JTP_FOLD: -1 where the distribute levels leave the chip's slots idle (fold_marginals), 1 wherever possible, 0 nowhere
+    int fold_slots = 1024;                                          // JTP_FOLD_SLOTS: workgroups resident on the chip (256 CUs x 4), the rule's threshold per level
     int no_lean = 0;                                                // JTP_NO_LEAN: unit tasks run the generic pass (round 5), no JtLean records
     double unit_ratio = 4.0;                                        // JTP_UNIT_RATIO: a clique becomes a unit clique when its table is at least this many times its covered part
     int marg_group = JT_MAX_OUT;                                    // JTP_MARG_GROUP: marginals of one belief table formed by one pass over it (1: a pass each, round 3)

@@ -1499,6 +1499,9 @@ def test_factor_marginals_folded_into_the_propagate(monkeypatch):
     # (a lattice this small plans as a chain of latency-bound levels, whose distribute kernel is built without folded tasks: planned
     #  here as the large ones are)
     monkeypatch.setenv("JTP_TINY_LEVEL_ELEMS", "0")
+    # (... and the planner folds by itself only where the distribute levels leave the chip's slots idle - the column-sweep tree below;
+    #  JTP_FOLD=1: wherever the plan's form allows)
+    monkeypatch.setenv("JTP_FOLD", "1")
     for mode in ("fold", "nofold", "fold_levels"):
         if mode == "nofold":
             monkeypatch.setenv("JTP_NO_FOLD", "1")
@@ -1562,6 +1565,20 @@ def test_factor_marginals_folded_into_the_propagate(monkeypatch):
                 np.testing.assert_array_equal(a, b)
     assert plan.stats()["flow_fallbacks"] == 0
     engine.clear_plan_cache()
+    # the planner's own choice (no JTP_FOLD): the min-fill tree of that lattice fills the chip level after level - its marginals stay with
+    # the read-out; the column-sweep tree's levels leave slots idle - folded; both give the oracle's marginals
+    monkeypatch.delenv("JTP_FOLD")
+    want = None
+    for order, folds in ((None, False), (synthetic.lattice_column_order(6, 40), True)):
+        tree = jt.create_junction_tree(factors, sizes, order=order)
+        out = tree.propagate(values)
+        assert any(t["fold"] for t in tree.plan("f32").describe()["tasks"]) == folds
+        if want is None:
+            ct = tree.clique_tree
+            want = oracle.propagate(tree.tree, tree.separators, ct.maxcliques, ct.factor_to_maxclique, factors, sizes, [np.asarray(v, dtype=np.float64) for v in values])
+        for o, w in zip(out, want):
+            close(o, w, rtol=RTOL32, what="planner's choice, %s tree" % ("column-sweep" if order else "min-fill"))
+        engine.clear_plan_cache()
 
 
 @pytest.mark.gpu

@@ -304,11 +304,21 @@ def test_lean_records_say_what_the_task_records_say():
     assert seen > 50
 
 
-def test_marginals_named_at_plan_creation_become_tasks_of_the_propagate():
+def test_marginals_named_at_plan_creation_become_tasks_of_the_propagate(monkeypatch):
     """Round 6 (`jtp_tree_desc.fold_*`, `PlanBuilder::fold_marginals`): the factor marginals a plan is told about at creation - requests on
     cliques that keep no table - become lean tasks of the distribute phase, on the level of their clique, reading the final messages of
     the clique's neighbours and writing into a region of the message arena behind the separators'.  Structure only (the GPU tests
     compare the values with the oracle and with the read-out)."""
+    # the planner's own choice first (`fold_marginals`: where at least half of the distribute levels leave the chip's resident slots
+    # idle): the column-sweep tree of a lattice folds, its min-fill tree - level after level fuller than the chip - does not
+    big = synthetic.lattice_mrf(6, 40, 8)
+    for order, folds in ((None, False), (synthetic.lattice_column_order(6, 40), True)):
+        bt = jt.create_junction_tree(big[0], big[1], order=order)
+        bnv = [list(c) for c in bt.clique_tree.maxcliques] + [list(s) for s in bt.separators]
+        bf = (tuple(bt.clique_tree.factor_to_maxclique), tuple(map(tuple, big[0])))
+        bd = engine.Plan(bt.tree, bnv, big[1], dtype="f32", plan_only=True, cover=bt.cover(), fold=bf).describe()
+        assert any(t["fold"] for t in bd["tasks"]) == folds
+    monkeypatch.setenv("JTP_FOLD", "1")                      # from here on: wherever the plan's form allows
     factors, sizes, _ = synthetic.lattice_mrf(6, 14, 8)
     tree = jt.create_junction_tree(factors, sizes)
     ct = tree.clique_tree
@@ -330,7 +340,7 @@ def test_marginals_named_at_plan_creation_become_tasks_of_the_propagate():
         p = d["pnodes"][t["pnode"]]
         assert p["unit"] and p["stat"] >= 0 and t["unit"] and t["kind"] == 0 and t["mode"] == 0 and t["lean_off"] > 0
         assert 1 <= t["n_out"] <= 3 and t["n_in"] <= 4 and t["bel_off"] < 0
-        assert level_of[i] == (1, p["depth"])                       # with the clique's own downward messages
+        assert level_of[i][0] == 1 and level_of[i][1] >= p["depth"]       # on the clique's own level, or a later one that has room (JTP_FOLD_SLOTS)
         # inputs: the parent's final downward message, the static table, every child's final upward message
         expect = []
         if p["psep"] >= 0:
@@ -360,6 +370,7 @@ def test_folded_marginal_tasks_emulated(monkeypatch, h, w, card, dtype, sweep):
     of each folded output summed as `jt_marg_unpack` sums them, against the oracle's `propagate`; the messages the other tasks form are
     the plain plan's, bit for bit."""
     monkeypatch.setenv("JTP_TINY_LEVEL_ELEMS", "0")              # (small lattices plan as chains of latency-bound levels, which carry no folded tasks)
+    monkeypatch.setenv("JTP_FOLD", "1")                          # (... and the planner folds by itself only where the levels leave slots idle)
     factors, sizes, values = synthetic.lattice_mrf(h, w, card)
     values = [np.asarray(v, dtype=np.float64) for v in values]
     tree = jt.create_junction_tree(factors, dict(sizes), order=synthetic.lattice_column_order(h, w) if sweep else None)

@@ -1,6 +1,7 @@
 """Diagnostic (round 6): propagates queued back to back on a plan with folded marginals, the factor marginals compared bit for bit with
 the first call's; every mismatch is printed with its clique.   python3 tools/fold_diag.py [reps] [every]"""
 import os, sys
+os.environ.setdefault("JTP_FOLD", "1")      # (the planner by itself folds only where the distribute levels leave slots idle: not on this tree)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
 import numpy as np
 import junctiontree_amd as jt

@@ -15,7 +15,7 @@ run JTP_EF_SHARE=1 FUZZ_WIDE=1 timeout -k 10 400 python3 tools/gpu_fuzz_api.py 8
 run timeout -k 10 300 python3 tools/gpu_fuzz_wide.py 200 175000
 run timeout -k 10 600 python3 tools/gpu_fuzz_compact.py 200 190000
 # the marginal tasks folded into the propagate (plans of latency-bound levels are built without them: planned here as large trees are)
-run JTP_TINY_LEVEL_ELEMS=0 timeout -k 10 400 python3 tools/gpu_fuzz_api.py 1500 179000
-run JTP_TINY_LEVEL_ELEMS=0 FUZZ_WIDE=1 timeout -k 10 400 python3 tools/gpu_fuzz_api.py 800 180000
+run JTP_FOLD=1 JTP_TINY_LEVEL_ELEMS=0 timeout -k 10 400 python3 tools/gpu_fuzz_api.py 1500 179000
+run JTP_FOLD=1 JTP_TINY_LEVEL_ELEMS=0 FUZZ_WIDE=1 timeout -k 10 400 python3 tools/gpu_fuzz_api.py 800 180000
 run timeout -k 10 900 python3 tools/gpu_fuzz_fold.py 2000 210000
 cat $O

@@ -2,9 +2,10 @@
 cardinality, storage type, min-fill or column-sweep tree, some with unary factors and mixed cardinalities) through the public API -
 whose plan carries the folded tasks - against the SAME tree's plan without them (the read-out, itself checked against the oracle and
 the brute-force joint by the other batteries), and 40 propagates queued back to back that must return the first call's bits.
-    python3 tools/gpu_fuzz_fold.py [count] [first seed]          (JTP_TINY_LEVEL_ELEMS=0 is set here: small lattices plan as large ones do)"""
+    python3 tools/gpu_fuzz_fold.py [count] [first seed]          (JTP_TINY_LEVEL_ELEMS=0 and JTP_FOLD=1 are set here: small lattices plan as large ones do, and fold wherever the plan's form allows)"""
 import os, sys, time
 os.environ.setdefault("JTP_TINY_LEVEL_ELEMS", "0")
+os.environ.setdefault("JTP_FOLD", "1")                  # (wherever the plan's form allows, not only where the planner would by itself)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "junction-tree_amd"))
 import numpy as np
 import junctiontree_amd as jt

@@ -63,7 +63,7 @@ for r in range(3):
 all_bytes = sum(phys.values()) * 4 + st5["fixed_bytes"]
 print("evaluate of ALL %d cliques (first call of a plan): %.2f ms for %.2f GiB written -> %.2f TB/s" % (n_all, min(cold) * 1e3, all_bytes / 2**30, all_bytes / min(cold) / 1e12))
 n_fold = sum(1 for t in plan.describe()["tasks"] if t.get("fold"))
-print("(the API's plan: %d marginal tasks of cliques without a table are folded into its propagate - the \"collect+distribute\" stage below includes them; JTP_NO_FOLD=1: none)" % n_fold)
+print("(the API's plan: %d marginal tasks of cliques without a table are folded into its propagate - the \"collect+distribute\" stage below includes them; the planner folds where the distribute levels leave the chip's slots idle, JTP_FOLD=1 / 0: wherever possible / nowhere)" % n_fold)
 print("propagate() steady state, all %d factor tables new each call: end to end %.2f ms (min of %d; median %.2f)" % (len(factors), min(e2e) * 1e3, reps, sorted(e2e)[reps // 2] * 1e3))
 named = []
 for r in range(reps):           # the caller says what changed (round 6): nothing compared, the factor lists not looked at again

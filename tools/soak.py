@@ -83,22 +83,29 @@ print("soak ok")
 # (round 6) the lean unit pass: a lattice whose junction tree is mostly cliques that keep no table, through the public API
 import junctiontree_amd as jt
 factors, sizes, values = synthetic.lattice_mrf(6, 40, 8)
-tree = jt.create_junction_tree(factors, sizes)
-first = tree.propagate(values)
-plan = tree.plan("f32")
-n_lean = sum(1 for t in plan.describe()["tasks"] if t["lean_off"] > 0)
-t0 = time.perf_counter()
-bad = 0
-for i in range(reps):
-    plan.propagate(sync=False)
-    if i % 100 == 99:
-        out = plan.factor_marginals(tree.clique_tree.factor_graph.factors, tree.clique_tree.factor_to_maxclique)
-        bad += sum(not np.array_equal(a, b) for a, b in zip(out, first))
-plan.sync()
-print("lean    %5d propagates  %.1f s  mismatching checks %d  fallbacks %d  (%d lean tasks, %d cliques without a table)"
-      % (reps, time.perf_counter() - t0, bad, plan.stats()["flow_fallbacks"], n_lean, plan.stats()["n_unit_cliques"]))
-assert bad == 0 and plan.stats()["flow_fallbacks"] == 0 and n_lean > 0
-engine.clear_plan_cache()
+# ... on its min-fill tree (marginals by the read-out: the planner folds where the distribute levels leave slots idle), on its column-sweep
+# tree (marginal tasks folded into the propagate by the planner's own choice), and on the min-fill tree with the folded tasks forced
+for name, order, env in (("lean", None, None), ("folded", synthetic.lattice_column_order(6, 40), None), ("folded+", None, "1")):
+    if env is not None:
+        os.environ["JTP_FOLD"] = env
+    tree = jt.create_junction_tree(factors, sizes, order=order)
+    first = tree.propagate(values)
+    plan = tree.plan("f32")
+    n_lean = sum(1 for t in plan.describe()["tasks"] if t["lean_off"] > 0)
+    n_fold = sum(1 for t in plan.describe()["tasks"] if t["fold"])
+    t0 = time.perf_counter()
+    bad = 0
+    for i in range(reps):
+        plan.propagate(sync=False)
+        if i % 100 == 99:
+            out = plan.factor_marginals(tree.clique_tree.factor_graph.factors, tree.clique_tree.factor_to_maxclique)
+            bad += sum(not np.array_equal(a, b) for a, b in zip(out, first))
+    plan.sync()
+    print("%-8s%5d propagates  %.1f s  mismatching checks %d  fallbacks %d  (%d lean tasks, %d of them folded marginal tasks, %d cliques without a table)"
+          % (name, reps, time.perf_counter() - t0, bad, plan.stats()["flow_fallbacks"], n_lean, n_fold, plan.stats()["n_unit_cliques"]))
+    assert bad == 0 and plan.stats()["flow_fallbacks"] == 0 and n_lean > 0 and (n_fold > 0) == (name != "lean")
+    engine.clear_plan_cache()
+    os.environ.pop("JTP_FOLD", None)
 # (round 6) the active lists of a multi-set plan: 64 evidence sets, an evidence-free set, the same evidence every propagate
 spec = synthetic.wide_binary_tree(n_cliques=63, width=16, sep=8, card=2, seed=21)
 plan = engine.Plan(spec["tree"], spec["node_vars"], spec["sizes"], dtype="f32", n_batch=64, multiset=True)
