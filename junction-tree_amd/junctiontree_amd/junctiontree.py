@@ -234,7 +234,8 @@ class JunctionTree:
         # cliques whose factors changed since this plan last saw them (the reference recomputes every clique on
         # every call and says so in a FIXME, junctiontree.py:206-214)
         _stage_changed_cliques(plan, ct, xs, changed=changed)
-        plan.propagate()
+        # (no wait here: the marginal kernels are enqueued behind the propagate while it runs, and `jtp_get_marginals` waits once for all)
+        plan.propagate(sync=False)
         # marginalize (junctiontree.py:229-274) on the device: one launch for all factors, the factors of one clique
         # sharing the passes over its belief table
         return plan.factor_marginals(ct.factor_graph.factors, ct.factor_to_maxclique, trusted=trusted)
